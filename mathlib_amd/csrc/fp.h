@@ -1,0 +1,260 @@
+// fp.h -- prime-field arithmetic for the MI355X kernels (gfx950).
+//
+// Element = N little-endian 32-bit limbs in Montgomery form, R = 2^(32 N): the same bytes as
+// gnark-crypto's fp.Element / kilic's Fe ([6]uint64 resp. [4]uint64, R = 2^384 / 2^256), the
+// types the reference's drivers hold (driver/kilic/custom.go:24, driver/gurvy/custom.go:24-40), so
+// points and Gt values cross the C ABI with no conversion.
+//
+// fp_mul replaces the reference's only in-tree field multiply, driver/kilic/custom_generic.go:57-175
+// (6x64-bit CIOS).  On CDNA4 the primitive is v_mad_u64_u32 (32x32+64 -> 64, ~4.7 cycles per
+// wave64, measured: profiles/r01_ubench_int.txt), so the limbs are 32-bit and the loop below is a
+// 32-bit CIOS; the result is fully reduced (< p) like the reference's (custom_generic.go:166-174).
+//
+// All functions are __host__ __device__: the same source is unit-tested on the CPU against the
+// oracle (tests/test_host_math.py) and runs in the kernels.  The host build is a TEST artifact;
+// the product path (libmlhip.so) calls these only from device code and from the O(1) host tail.
+#pragma once
+#include <stdint.h>
+#include "curve_constants.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MLHIP_HD __host__ __device__ __forceinline__
+#define MLHIP_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define MLHIP_HD inline
+#define MLHIP_HD_NOINLINE inline
+#endif
+
+namespace mlhip {
+
+template <class C>
+struct Fp {
+  uint32_t l[C::N];
+};
+
+template <class C>
+MLHIP_HD void fp_zero(Fp<C>& r) {
+#pragma unroll
+  for (int i = 0; i < C::N; i++) r.l[i] = 0;
+}
+
+template <class C>
+MLHIP_HD void fp_one(Fp<C>& r) {
+#pragma unroll
+  for (int i = 0; i < C::N; i++) r.l[i] = C::ONE[i];
+}
+
+template <class C>
+MLHIP_HD void fp_from_const(Fp<C>& r, const uint32_t (&k)[C::N]) {
+#pragma unroll
+  for (int i = 0; i < C::N; i++) r.l[i] = k[i];
+}
+
+template <class C>
+MLHIP_HD bool fp_is_zero(const Fp<C>& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < C::N; i++) o |= a.l[i];
+  return o == 0;
+}
+
+template <class C>
+MLHIP_HD bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < C::N; i++) o |= a.l[i] ^ b.l[i];
+  return o == 0;
+}
+
+// r = t - p if t >= p else t   (t < 2p)
+template <class C>
+MLHIP_HD void fp_reduce_once(Fp<C>& r, const uint32_t (&t)[C::N]) {
+  uint32_t d[C::N];
+  uint64_t br = 0;
+#pragma unroll
+  for (int i = 0; i < C::N; i++) {
+    uint64_t s = (uint64_t)t[i] - C::P[i] - br;
+    d[i] = (uint32_t)s;
+    br = (s >> 32) & 1;
+  }
+#pragma unroll
+  for (int i = 0; i < C::N; i++) r.l[i] = br ? t[i] : d[i];
+}
+
+template <class C>
+MLHIP_HD void fp_add(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+  uint32_t t[C::N];
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < C::N; i++) {
+    uint64_t s = (uint64_t)a.l[i] + b.l[i] + c;
+    t[i] = (uint32_t)s;
+    c = s >> 32;
+  }
+  // p < 2^(32N-1) for all three curves, so a + b < 2p never carries out of N limbs
+  fp_reduce_once<C>(r, t);
+}
+
+template <class C>
+MLHIP_HD void fp_dbl(Fp<C>& r, const Fp<C>& a) {
+  fp_add<C>(r, a, a);
+}
+
+template <class C>
+MLHIP_HD void fp_sub(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+  uint32_t d[C::N];
+  uint64_t br = 0;
+#pragma unroll
+  for (int i = 0; i < C::N; i++) {
+    uint64_t s = (uint64_t)a.l[i] - b.l[i] - br;
+    d[i] = (uint32_t)s;
+    br = (s >> 32) & 1;
+  }
+  // add p back when the subtraction borrowed
+  uint32_t mask = (uint32_t)0 - (uint32_t)br;
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < C::N; i++) {
+    uint64_t s = (uint64_t)d[i] + (C::P[i] & mask) + c;
+    r.l[i] = (uint32_t)s;
+    c = s >> 32;
+  }
+}
+
+template <class C>
+MLHIP_HD void fp_neg(Fp<C>& r, const Fp<C>& a) {
+  // -a mod p, with -0 = 0
+  uint32_t nz = 0;
+#pragma unroll
+  for (int i = 0; i < C::N; i++) nz |= a.l[i];
+  uint32_t mask = nz ? 0xffffffffu : 0u;
+  uint64_t br = 0;
+#pragma unroll
+  for (int i = 0; i < C::N; i++) {
+    uint64_t s = (uint64_t)(C::P[i] & mask) - a.l[i] - br;
+    r.l[i] = (uint32_t)s;
+    br = (s >> 32) & 1;
+  }
+}
+
+// r = c ? a : b
+template <class C>
+MLHIP_HD void fp_select(Fp<C>& r, bool c, const Fp<C>& a, const Fp<C>& b) {
+#pragma unroll
+  for (int i = 0; i < C::N; i++) r.l[i] = c ? a.l[i] : b.l[i];
+}
+
+// Montgomery product a*b*R^-1 mod p, fully reduced.  32-bit CIOS: each inner step is one
+// v_mad_u64_u32 (a_j*b_i + 64-bit addend) on the device.
+template <class C>
+MLHIP_HD void fp_mul_inline(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+  constexpr int N = C::N;
+  uint32_t t[N + 2];
+#pragma unroll
+  for (int i = 0; i < N + 2; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    uint64_t c = 0;
+    const uint32_t bi = b.l[i];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      uint64_t acc = (uint64_t)a.l[j] * bi + t[j] + c;
+      t[j] = (uint32_t)acc;
+      c = acc >> 32;
+    }
+    uint64_t acc = (uint64_t)t[N] + c;
+    t[N] = (uint32_t)acc;
+    t[N + 1] = (uint32_t)(acc >> 32);
+    const uint32_t m = t[0] * C::INV;
+    acc = (uint64_t)m * C::P[0] + t[0];
+    c = acc >> 32;
+#pragma unroll
+    for (int j = 1; j < N; j++) {
+      acc = (uint64_t)m * C::P[j] + t[j] + c;
+      t[j - 1] = (uint32_t)acc;
+      c = acc >> 32;
+    }
+    acc = (uint64_t)t[N] + c;
+    t[N - 1] = (uint32_t)acc;
+    t[N] = t[N + 1] + (uint32_t)(acc >> 32);
+  }
+  uint32_t o[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) o[i] = t[i];
+  fp_reduce_once<C>(r, o);
+}
+
+// Out-of-line entry points: one copy of the ~1.2k-instruction multiply per kernel keeps the hot
+// loop inside the instruction cache (an inlined G1 mixed add would be >100 KB of code).
+template <class C>
+MLHIP_HD_NOINLINE void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+  fp_mul_inline<C>(r, a, b);
+}
+
+template <class C>
+MLHIP_HD_NOINLINE void fp_sqr(Fp<C>& r, const Fp<C>& a) {
+  fp_mul_inline<C>(r, a, a);
+}
+
+// a * small constant (k <= 16) by additions
+template <class C>
+MLHIP_HD void fp_mul_small(Fp<C>& r, const Fp<C>& a, int k) {
+  Fp<C> acc, cur = a;
+  fp_zero<C>(acc);
+  while (k) {
+    if (k & 1) fp_add<C>(acc, acc, cur);
+    fp_dbl<C>(cur, cur);
+    k >>= 1;
+  }
+  r = acc;
+}
+
+// a^(p-2): Fermat inversion (0 -> 0).  Used once per pairing (final-exponentiation easy part) and
+// in the O(1) host tail of an MSM; never in a hot loop.
+template <class C>
+MLHIP_HD void fp_inv(Fp<C>& r, const Fp<C>& a) {
+  constexpr int N = C::N;
+  uint32_t e[N];
+  // e = p - 2 (BLS12-377's p ends in ...0001, so the borrow must propagate)
+  uint64_t br = 2;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    uint64_t s = (uint64_t)C::P[i] - br;
+    e[i] = (uint32_t)s;
+    br = (s >> 32) & 1;
+  }
+  Fp<C> acc;
+  fp_one<C>(acc);
+  bool started = false;
+  for (int i = N * 32 - 1; i >= 0; i--) {
+    if (started) fp_sqr<C>(acc, acc);
+    if ((e[i >> 5] >> (i & 31)) & 1) {
+      if (started)
+        fp_mul<C>(acc, acc, a);
+      else {
+        acc = a;
+        started = true;
+      }
+    }
+  }
+  r = acc;
+}
+
+// Montgomery conversion helpers (host-side plumbing and tests)
+template <class C>
+MLHIP_HD void fp_to_mont(Fp<C>& r, const Fp<C>& a) {
+  Fp<C> r2;
+  fp_from_const<C>(r2, C::R2);
+  fp_mul<C>(r, a, r2);
+}
+
+template <class C>
+MLHIP_HD void fp_from_mont(Fp<C>& r, const Fp<C>& a) {
+  Fp<C> one;
+  fp_zero<C>(one);
+  one.l[0] = 1;
+  fp_mul<C>(r, a, one);
+}
+
+}  // namespace mlhip

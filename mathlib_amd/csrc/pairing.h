@@ -1,0 +1,261 @@
+// pairing.h -- optimal-ate Miller loop and final exponentiation (BN254, BLS12-381, BLS12-377), gfx950.
+//
+// Replaces, on the GPU path, the calls the reference's drivers make into gnark-crypto:
+//   MillerLoop            driver/gurvy/bls12381/bls12-381.go:449,458 ; bn254.go:248,257 ; bls12-377.go:245,254
+//   FinalExponentiation   driver/gurvy/bls12381/bls12-381.go:467     ; bn254.go:266     ; bls12-377.go:263
+// and kilic's Engine.AddPair/Result (driver/kilic/bls12-381.go:260-267), which is the composition.
+//
+// Contract: the raw Miller-loop value is only defined up to factors the final
+// exponentiation kills; what is bit-exact is final_exp(miller_loop(..)) = f^(k (p^12-1)/r) with
+// k = 3 (BLS12, Hayashida-Hayasaka-Teruya chain) and k = 2x(6x^2+3x+1) (BN254, Fuentes-Castaneda),
+// the cofactors gnark and kilic use.  Checked against oracle/pyref.py's plain pow().
+//
+// Formulas: homogeneous projective doubling/addition on the twist with line coefficients
+// (Costello-Lange-Naehrig), lines multiplied in sparsely (mul_by_014 for the M-twist, mul_by_034
+// for D-twists), cyclotomic squarings in the hard part.
+#pragma once
+#include "ec.h"
+
+namespace mlhip {
+
+template <class C>
+struct G2Proj {
+  Fp2<C> x, y, z;
+};
+
+template <class C>
+struct Line {
+  Fp2<C> r0, r1, r2;  // r0 pairs with yP, r1 with xP, r2 is the constant coefficient
+};
+
+template <class C>
+MLHIP_HD void fp_halve(Fp<C>& r, const Fp<C>& a) {
+  constexpr int N = C::N;
+  uint32_t mask = (uint32_t)0 - (a.l[0] & 1u);
+  uint32_t t[N];
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    uint64_t s = (uint64_t)a.l[i] + (C::P[i] & mask) + c;
+    t[i] = (uint32_t)s;
+    c = s >> 32;
+  }
+#pragma unroll
+  for (int i = 0; i < N - 1; i++) r.l[i] = (t[i] >> 1) | (t[i + 1] << 31);
+  r.l[N - 1] = t[N - 1] >> 1;
+}
+
+template <class C>
+MLHIP_HD void fp2_halve(Fp2<C>& r, const Fp2<C>& a) {
+  fp_halve<C>(r.c0, a.c0);
+  fp_halve<C>(r.c1, a.c1);
+}
+
+// T <- 2T, line through T,T
+template <class C>
+MLHIP_HD_NOINLINE void g2_double_step(G2Proj<C>& T, Line<C>& l) {
+  Fp2<C> A, B, Cc, E, F, G, H, I, J, EE, t, b3;
+  fp2_mul<C>(A, T.x, T.y);
+  fp2_halve<C>(A, A);
+  fp2_sqr<C>(B, T.y);
+  fp2_sqr<C>(Cc, T.z);
+  fp2_from_const<C>(b3, C::B3_TW);
+  fp2_mul<C>(E, Cc, b3);  // 3 b' Z^2
+  fp2_dbl<C>(F, E);
+  fp2_add<C>(F, F, E);  // 3E
+  fp2_add<C>(G, B, F);
+  fp2_halve<C>(G, G);
+  fp2_add<C>(H, T.y, T.z);
+  fp2_sqr<C>(H, H);
+  fp2_add<C>(t, B, Cc);
+  fp2_sub<C>(H, H, t);  // 2YZ
+  fp2_sub<C>(I, E, B);
+  fp2_sqr<C>(J, T.x);
+  fp2_sqr<C>(EE, E);
+  // X3 = A (B - F) ; Y3 = G^2 - 3 EE ; Z3 = B H
+  fp2_sub<C>(t, B, F);
+  fp2_mul<C>(T.x, A, t);
+  fp2_sqr<C>(G, G);
+  fp2_dbl<C>(t, EE);
+  fp2_add<C>(t, t, EE);
+  fp2_sub<C>(T.y, G, t);
+  fp2_mul<C>(T.z, B, H);
+  fp2_neg<C>(l.r0, H);
+  fp2_dbl<C>(l.r1, J);
+  fp2_add<C>(l.r1, l.r1, J);
+  l.r2 = I;
+}
+
+// T <- T + Q (Q affine), line through T,Q
+template <class C>
+MLHIP_HD_NOINLINE void g2_add_step(G2Proj<C>& T, const Fp2<C>& qx, const Fp2<C>& qy, Line<C>& l) {
+  Fp2<C> O, L, Cc, D, E, F, G, H, t, t2;
+  fp2_mul<C>(t, qy, T.z);
+  fp2_sub<C>(O, T.y, t);
+  fp2_mul<C>(t, qx, T.z);
+  fp2_sub<C>(L, T.x, t);
+  fp2_sqr<C>(Cc, O);
+  fp2_sqr<C>(D, L);
+  fp2_mul<C>(E, L, D);
+  fp2_mul<C>(F, T.z, Cc);
+  fp2_mul<C>(G, T.x, D);
+  fp2_dbl<C>(t, G);
+  fp2_add<C>(H, E, F);
+  fp2_sub<C>(H, H, t);
+  fp2_mul<C>(t2, T.y, E);
+  fp2_mul<C>(T.x, L, H);
+  fp2_sub<C>(t, G, H);
+  fp2_mul<C>(t, O, t);
+  fp2_sub<C>(T.y, t, t2);
+  fp2_mul<C>(T.z, T.z, E);
+  // line
+  fp2_mul<C>(t, L, qy);
+  fp2_mul<C>(t2, qx, O);
+  fp2_sub<C>(l.r2, t2, t);
+  l.r0 = L;
+  fp2_neg<C>(l.r1, O);
+}
+
+template <class C>
+MLHIP_HD void mul_by_line(Fp12<C>& f, const Line<C>& l, const Fp<C>& px, const Fp<C>& py) {
+  Fp2<C> a, b;
+  fp2_mul_fp<C>(a, l.r0, py);
+  fp2_mul_fp<C>(b, l.r1, px);
+  if (C::MTWIST)
+    fp12_mul_by_014<C>(f, l.r2, b, a);
+  else
+    fp12_mul_by_034<C>(f, a, b, l.r2);
+}
+
+// f = prod_k f_{loop,Q_k}(P_k) over n_pairs pairs (shared squaring chain: the reference's Pairing2,
+// driver/gurvy/bls12381/bls12-381.go:457-464).  Pairs containing infinity are skipped, as gnark does.
+// MAXP bounds n_pairs (state is kept per pair).
+template <class C, int MAXP>
+MLHIP_HD void miller_loop(Fp12<C>& f, const Affine<FpField<C>>* P, const Affine<Fp2Field<C>>* Q, int n_pairs) {
+  G2Proj<C> T[MAXP];
+  bool live[MAXP];
+  int any = 0;
+  for (int k = 0; k < n_pairs && k < MAXP; k++) {
+    live[k] = !(affine_is_inf<FpField<C>>(P[k]) | affine_is_inf<Fp2Field<C>>(Q[k]));
+    T[k].x = Q[k].x;
+    T[k].y = Q[k].y;
+    fp2_one<C>(T[k].z);
+    any |= live[k];
+  }
+  fp12_one<C>(f);
+  if (!any) return;
+  Line<C> l;
+  bool first = true;
+  for (int i = C::ATE_BITS - 2; i >= 0; i--) {
+    if (!first) fp12_sqr<C>(f, f);
+    first = false;
+    bool bit = (i >= 64) ? ((C::ATE_HI >> (i - 64)) & 1) : ((C::ATE_LO >> i) & 1);
+    for (int k = 0; k < n_pairs && k < MAXP; k++) {
+      if (!live[k]) continue;
+      g2_double_step<C>(T[k], l);
+      mul_by_line<C>(f, l, P[k].x, P[k].y);
+      if (bit) {
+        g2_add_step<C>(T[k], Q[k].x, Q[k].y, l);
+        mul_by_line<C>(f, l, P[k].x, P[k].y);
+      }
+    }
+  }
+  if (C::IS_BN) {
+    // lines through pi(Q) and -pi^2(Q)
+    for (int k = 0; k < n_pairs && k < MAXP; k++) {
+      if (!live[k]) continue;
+      Fp2<C> x1, y1, x2, y2, g;
+      fp2_conj<C>(x1, Q[k].x);
+      fp2_from_const<C>(g, C::GAMMA1[2]);
+      fp2_mul<C>(x1, x1, g);
+      fp2_conj<C>(y1, Q[k].y);
+      fp2_from_const<C>(g, C::GAMMA1[3]);
+      fp2_mul<C>(y1, y1, g);
+      fp2_from_const<C>(g, C::GAMMA2[2]);
+      fp2_mul<C>(x2, Q[k].x, g);
+      fp2_from_const<C>(g, C::GAMMA2[3]);
+      fp2_mul<C>(y2, Q[k].y, g);
+      fp2_neg<C>(y2, y2);
+      g2_add_step<C>(T[k], x1, y1, l);
+      mul_by_line<C>(f, l, P[k].x, P[k].y);
+      g2_add_step<C>(T[k], x2, y2, l);
+      mul_by_line<C>(f, l, P[k].x, P[k].y);
+    }
+  }
+  if (C::X_NEG) fp12_conj<C>(f, f);
+}
+
+// z^|x| by cyclotomic squarings (z in the cyclotomic subgroup), conjugated when the seed is negative
+template <class C>
+MLHIP_HD_NOINLINE void fp12_expt(Fp12<C>& r, const Fp12<C>& z) {
+  Fp12<C> acc = z;
+  int top = 63;
+  while (!((C::X_ABS >> top) & 1)) top--;
+  for (int i = top - 1; i >= 0; i--) {
+    fp12_cyclo_sqr<C>(acc, acc);
+    if ((C::X_ABS >> i) & 1) fp12_mul<C>(acc, acc, z);
+  }
+  if (C::X_NEG) fp12_conj<C>(acc, acc);
+  r = acc;
+}
+
+// r = f^(k (p^12 - 1)/r_order): the reference's FExp (bls12-381.go:466-468 etc.)
+template <class C>
+MLHIP_HD void final_exp(Fp12<C>& out, const Fp12<C>& f) {
+  Fp12<C> r, t0, t1, t2;
+  // easy part: f^((p^6-1)(p^2+1))
+  fp12_conj<C>(t0, f);
+  fp12_inv<C>(t1, f);
+  fp12_mul<C>(t0, t0, t1);
+  fp12_frob<C, 2>(t1, t0);
+  fp12_mul<C>(r, t1, t0);
+  if (!C::IS_BN) {
+    // hard part, exponent (x-1)^2 (x+p) (x^2+p^2-1) + 3 = 3 (p^4-p^2+1)/r
+    fp12_cyclo_sqr<C>(t0, r);
+    fp12_expt<C>(t1, r);
+    fp12_conj<C>(t2, r);
+    fp12_mul<C>(t1, t1, t2);  // r^(x-1)
+    fp12_expt<C>(t2, t1);     // r^((x-1)x)
+    fp12_conj<C>(t1, t1);
+    fp12_mul<C>(t1, t1, t2);  // r^((x-1)^2)
+    fp12_expt<C>(t2, t1);     // ^x
+    fp12_frob<C, 1>(t1, t1);  // ^p
+    fp12_mul<C>(t1, t1, t2);  // r^((x-1)^2 (x+p))
+    fp12_mul<C>(r, r, t0);    // r^3
+    fp12_expt<C>(t0, t1);     // ^x
+    fp12_expt<C>(t2, t0);     // ^x^2
+    fp12_frob<C, 2>(t0, t1);  // ^p^2
+    fp12_conj<C>(t1, t1);     // ^-1
+    fp12_mul<C>(t1, t1, t2);
+    fp12_mul<C>(t1, t1, t0);  // r^((x-1)^2 (x+p)(x^2+p^2-1))
+    fp12_mul<C>(out, r, t1);
+  } else {
+    // hard part, exponent l0 + l1 p + l2 p^2 + l3 p^3 = 2x(6x^2+3x+1) (p^4-p^2+1)/r
+    //   a = 12x^3+6x^2+6x ; b = a - 2x ; l0 = a + 6x^2 + 1 ; l1 = b ; l2 = a ; l3 = b - 1
+    Fp12<C> fx, f2x, f6x, f6x2, f12x3, a, b;
+    fp12_expt<C>(fx, r);
+    fp12_cyclo_sqr<C>(f2x, fx);
+    fp12_cyclo_sqr<C>(t0, f2x);  // 4x
+    fp12_mul<C>(f6x, t0, f2x);
+    fp12_expt<C>(f6x2, f6x);
+    fp12_cyclo_sqr<C>(t0, f6x2);  // 12x^2
+    fp12_expt<C>(f12x3, t0);
+    fp12_mul<C>(a, f12x3, f6x2);
+    fp12_mul<C>(a, a, f6x);
+    fp12_conj<C>(t0, f2x);
+    fp12_mul<C>(b, a, t0);
+    // result = (a f6x2 r) * frob(b) * frob2(a) * frob3(b conj(r))
+    fp12_mul<C>(t0, a, f6x2);
+    fp12_mul<C>(t0, t0, r);
+    fp12_frob<C, 1>(t1, b);
+    fp12_mul<C>(t0, t0, t1);
+    fp12_frob<C, 2>(t1, a);
+    fp12_mul<C>(t0, t0, t1);
+    fp12_conj<C>(t1, r);
+    fp12_mul<C>(t1, b, t1);
+    fp12_frob<C, 3>(t2, t1);
+    fp12_mul<C>(out, t0, t2);
+  }
+}
+
+}  // namespace mlhip

@@ -1,0 +1,157 @@
+// TEST ARTIFACT -- host (g++) build of the kernels' __host__ __device__ math headers, loaded by
+// tests/test_host_math.py through ctypes and compared with oracle/pyref.py.  It lets the field /
+// curve / pairing formulas be verified in the GPU-less container; it is NOT part of libmlhip.so
+// and nothing in the product path links or loads it.
+#include <stdint.h>
+#include <string.h>
+#include "../../mathlib_amd/csrc/pairing.h"
+
+using namespace mlhip;
+
+template <class C>
+struct Ops {
+  typedef Fp<C> F;
+  typedef Fp2<C> F2;
+  typedef Fp12<C> F12;
+  typedef Affine<FpField<C>> A1;
+  typedef Affine<Fp2Field<C>> A2;
+  typedef XYZZ<FpField<C>> X1;
+  typedef XYZZ<Fp2Field<C>> X2;
+
+  static int fp_op(int op, const void* a, const void* b, void* out) {
+    F x, y, r;
+    memcpy(&x, a, sizeof(F));
+    if (b) memcpy(&y, b, sizeof(F));
+    switch (op) {
+      case 0: fp_mul<C>(r, x, y); break;
+      case 1: fp_add<C>(r, x, y); break;
+      case 2: fp_sub<C>(r, x, y); break;
+      case 3: fp_neg<C>(r, x); break;
+      case 4: fp_inv<C>(r, x); break;
+      case 5: fp_sqr<C>(r, x); break;
+      case 6: fp_halve<C>(r, x); break;
+      case 7: fp_to_mont<C>(r, x); break;
+      case 8: fp_from_mont<C>(r, x); break;
+      default: return -1;
+    }
+    memcpy(out, &r, sizeof(F));
+    return 0;
+  }
+  static int fp2_op(int op, const void* a, const void* b, void* out) {
+    F2 x, y, r;
+    memcpy(&x, a, sizeof(F2));
+    if (b) memcpy(&y, b, sizeof(F2));
+    switch (op) {
+      case 0: fp2_mul<C>(r, x, y); break;
+      case 1: fp2_sqr<C>(r, x); break;
+      case 2: fp2_inv<C>(r, x); break;
+      case 3: fp2_mul_xi<C>(r, x); break;
+      default: return -1;
+    }
+    memcpy(out, &r, sizeof(F2));
+    return 0;
+  }
+  static int fp12_op(int op, const void* a, const void* b, void* out) {
+    F12 x, y, r;
+    memcpy(&x, a, sizeof(F12));
+    if (b) memcpy(&y, b, sizeof(F12));
+    switch (op) {
+      case 0: fp12_mul<C>(r, x, y); break;
+      case 1: fp12_sqr<C>(r, x); break;
+      case 2: fp12_inv<C>(r, x); break;
+      case 3: fp12_frob<C, 1>(r, x); break;
+      case 4: fp12_frob<C, 2>(r, x); break;
+      case 5: fp12_frob<C, 3>(r, x); break;
+      case 6: fp12_cyclo_sqr<C>(r, x); break;
+      case 7: fp12_conj<C>(r, x); break;
+      case 8: fp12_expt<C>(r, x); break;
+      case 9: final_exp<C>(r, x); break;
+      default: return -1;
+    }
+    memcpy(out, &r, sizeof(F12));
+    return 0;
+  }
+  // sum_i (+/-) P_i by mixed additions into one XYZZ accumulator
+  static int g1_sum(const void* pts, const uint8_t* neg, int n, void* out) {
+    X1 acc;
+    xyzz_set_inf<FpField<C>>(acc);
+    const A1* p = (const A1*)pts;
+    for (int i = 0; i < n; i++) xyzz_madd<FpField<C>>(acc, p[i], neg && neg[i]);
+    A1 r;
+    xyzz_to_affine<FpField<C>>(r, acc);
+    memcpy(out, &r, sizeof(A1));
+    return 0;
+  }
+  static int g2_sum(const void* pts, const uint8_t* neg, int n, void* out) {
+    X2 acc;
+    xyzz_set_inf<Fp2Field<C>>(acc);
+    const A2* p = (const A2*)pts;
+    for (int i = 0; i < n; i++) xyzz_madd<Fp2Field<C>>(acc, p[i], neg && neg[i]);
+    A2 r;
+    xyzz_to_affine<Fp2Field<C>>(r, acc);
+    memcpy(out, &r, sizeof(A2));
+    return 0;
+  }
+  // tree sum through xyzz_add (exercises the XYZZ+XYZZ path incl. doubling / inverse branches)
+  static int g1_tree(const void* pts, int n, void* out) {
+    const A1* p = (const A1*)pts;
+    X1* v = new X1[n > 0 ? n : 1];
+    for (int i = 0; i < n; i++) xyzz_from_affine<FpField<C>>(v[i], p[i]);
+    int m = n;
+    while (m > 1) {
+      int h = (m + 1) / 2;
+      for (int i = 0; i + h < m; i++) xyzz_add<FpField<C>>(v[i], v[i + h]);
+      m = h;
+    }
+    X1 acc;
+    if (n > 0) acc = v[0]; else xyzz_set_inf<FpField<C>>(acc);
+    A1 r;
+    xyzz_to_affine<FpField<C>>(r, acc);
+    memcpy(out, &r, sizeof(A1));
+    delete[] v;
+    return 0;
+  }
+  static int g2_tree(const void* pts, int n, void* out) {
+    const A2* p = (const A2*)pts;
+    X2* v = new X2[n > 0 ? n : 1];
+    for (int i = 0; i < n; i++) xyzz_from_affine<Fp2Field<C>>(v[i], p[i]);
+    int m = n;
+    while (m > 1) {
+      int h = (m + 1) / 2;
+      for (int i = 0; i + h < m; i++) xyzz_add<Fp2Field<C>>(v[i], v[i + h]);
+      m = h;
+    }
+    X2 acc;
+    if (n > 0) acc = v[0]; else xyzz_set_inf<Fp2Field<C>>(acc);
+    A2 r;
+    xyzz_to_affine<Fp2Field<C>>(r, acc);
+    memcpy(out, &r, sizeof(A2));
+    delete[] v;
+    return 0;
+  }
+  static int miller(const void* g1s, const void* g2s, int n_pairs, void* out) {
+    F12 f;
+    miller_loop<C, 4>(f, (const A1*)g1s, (const A2*)g2s, n_pairs);
+    memcpy(out, &f, sizeof(F12));
+    return 0;
+  }
+};
+
+#define DISPATCH(curve, call)                 \
+  switch (curve) {                            \
+    case 0: return Ops<Bn254>::call;          \
+    case 1: return Ops<Bls381>::call;         \
+    case 2: return Ops<Bls377>::call;         \
+    default: return -2;                       \
+  }
+
+extern "C" {
+int hm_fp_op(int curve, int op, const void* a, const void* b, void* out) { DISPATCH(curve, fp_op(op, a, b, out)) }
+int hm_fp2_op(int curve, int op, const void* a, const void* b, void* out) { DISPATCH(curve, fp2_op(op, a, b, out)) }
+int hm_fp12_op(int curve, int op, const void* a, const void* b, void* out) { DISPATCH(curve, fp12_op(op, a, b, out)) }
+int hm_g1_sum(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, g1_sum(pts, neg, n, out)) }
+int hm_g2_sum(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, g2_sum(pts, neg, n, out)) }
+int hm_g1_tree(int curve, const void* pts, int n, void* out) { DISPATCH(curve, g1_tree(pts, n, out)) }
+int hm_g2_tree(int curve, const void* pts, int n, void* out) { DISPATCH(curve, g2_tree(pts, n, out)) }
+int hm_miller(int curve, const void* g1s, const void* g2s, int n_pairs, void* out) { DISPATCH(curve, miller(g1s, g2s, n_pairs, out)) }
+}
