@@ -1,0 +1,121 @@
+/* mlhip.h -- C ABI of libmlhip.so: the MI355X (gfx950) backend for the data-parallel hot path of
+ * IBM/mathlib (batched G1/G2 multi-scalar multiplication, Miller loop, final exponentiation).
+ *
+ * This is the boundary a Go `driver/hip` package binds through cgo (INTEGRATION.md shows the stub).
+ * Every entry point replaces one call the reference's drivers make into gnark-crypto / kilic:
+ *
+ *   mlhip_msm_g1          driver/gurvy/bls12381/bls12-381.go:766-783 (G1Jac.MultiExp + FromJacobian),
+ *                         driver/gurvy/bn254.go:232-245, driver/gurvy/bls12-377.go:229-242,
+ *                         driver/kilic/bls12-381.go:247-254
+ *   mlhip_msm_g2          additive (no G2 MSM in driver/math.go); semantics = sum of G2.Mul + Add,
+ *                         driver/gurvy/bls12381/bls12-381.go:342-358
+ *   mlhip_miller_loop     Pairing / Pairing2: bls12-381.go:448-464, bn254.go:247-263, bls12-377.go:244-260
+ *   mlhip_final_exp       FExp: bls12-381.go:466-468, bn254.go:265-267, bls12-377.go:262-264
+ *   mlhip_pairing_batch   FExp(Pairing(g2[i], g1[i])) element-wise (kilic's Pairing is this composition:
+ *                         driver/kilic/bls12-381.go:260-267)
+ *
+ * Memory layout (in and out) is gnark-crypto's in-memory layout, so Go passes unsafe.Pointer(&slice[0])
+ * with no conversion: Fp = k little-endian uint64 limbs in Montgomery form (k = 6 for BLS12-381/377,
+ * 4 for BN254; evidence: driver/gurvy/custom.go:24-40, driver/kilic/custom.go:24-29); G1 affine = {X,Y};
+ * G2 affine = {X.A0,X.A1,Y.A0,Y.A1}; infinity = all-zero; Gt = E12 {C0{B0{A0,A1},B1,B2},C1{..}}
+ * (12 Fp); scalar = 4 uint64 limbs, either fr.Element (Montgomery, scalars_mont = 1) or a plain
+ * little-endian integer (scalars_mont = 0; any 256-bit value, reduced mod r on the device the way
+ * fr.Element.SetBigInt does for the reference's BaseZr scalars, driver/gurvy/bn254.go:239).
+ *
+ * Conventions: every function returns 0 on success and a negative MLHIP_E* code otherwise;
+ * mlhip_last_error() gives the message for the calling thread.  The library is re-entrant
+ * (perf_test.go:382-404 calls Curve methods from many goroutines); it keeps no caller pointer after
+ * return.  There is NO CPU fallback: without a usable HIP device every compute entry point fails
+ * with MLHIP_ENODEVICE (the Go shim panics, matching the reference's driver convention,
+ * driver/gurvy/bn254.go:249-251).
+ */
+#ifndef MLHIP_H
+#define MLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLHIP_CURVE_BN254 0
+#define MLHIP_CURVE_BLS12_381 1
+#define MLHIP_CURVE_BLS12_377 2
+
+#define MLHIP_OK 0
+#define MLHIP_EINVAL (-1)    /* bad argument (unknown curve, window out of range, null pointer) */
+#define MLHIP_ENODEVICE (-2) /* no usable HIP device */
+#define MLHIP_EHIP (-3)      /* a HIP runtime call failed; see mlhip_last_error() */
+#define MLHIP_ENOMEM (-4)
+
+#define MLHIP_GROUP_G1 1
+#define MLHIP_GROUP_G2 2
+
+/* ---- library / device ---------------------------------------------------------------------- */
+int mlhip_version(void);
+const char* mlhip_last_error(void);
+int mlhip_device_count(int* count);
+/* Device used by the calling thread's subsequent calls (default 0).  Nothing touches the GPU
+ * before the first compute call (the reference computes GenGt at package init, math.go:142-255:
+ * importing the backend must not need a GPU). */
+int mlhip_set_device(int device);
+
+/* sizes in bytes for a curve: Fp element, G1 affine, G2 affine, Gt, scalar (always 32) */
+int mlhip_sizes(int curve, size_t* fp, size_t* g1, size_t* g2, size_t* gt);
+
+/* ---- host-buffer entry points (what the cgo shim binds) ------------------------------------- */
+/* out = sum_i [scalars[i]] points[i].  window_c = 0 picks a window from n; BASELINE config 2 uses 16.
+ * n = 0 gives the point at infinity (the reference's MultiExp on empty slices). */
+int mlhip_msm_g1(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
+                 void* out_affine);
+int mlhip_msm_g2(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
+                 void* out_affine);
+
+/* out[k] = prod_{j < pairs_per_product} MillerLoop(g1[k*ppp + j], g2[k*ppp + j]); Pairing = 1, Pairing2 = 2
+ * (pairs_per_product <= 4).  Pairs holding an infinity contribute 1.  NOT final-exponentiated: like gurvy's
+ * Pairing the value is only meaningful after mlhip_final_exp. */
+int mlhip_miller_loop(int curve, const void* g1, const void* g2, size_t pairs_per_product, size_t n_products,
+                      void* out_gt);
+/* out[i] = in[i]^(k (p^12-1)/r), k = 3 (BLS12 curves) or 2x(6x^2+3x+1) (BN254): gnark's and kilic's value */
+int mlhip_final_exp(int curve, const void* in_gt, size_t n, void* out_gt);
+/* out[i] = FExp(Pairing(g2[i], g1[i])) */
+int mlhip_pairing_batch(int curve, const void* g1, const void* g2, size_t n, void* out_gt);
+/* out[i] = a[i] * b[i] in Gt (Gt.Mul, driver/gurvy/bls12381/bls12-381.go:417-419), element-wise over n */
+int mlhip_gt_mul(int curve, const void* a_gt, const void* b_gt, size_t n, void* out_gt);
+
+/* ---- device-resident entry points (points / scalars already in HBM; resident SRS) ----------- */
+typedef struct mlhip_msm_plan mlhip_msm_plan;
+/* Workspace for MSMs of up to max_n points on the calling thread's device. */
+int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhip_msm_plan** plan);
+int mlhip_msm_plan_destroy(mlhip_msm_plan* plan);
+/* d_points / d_scalars are device pointers; stream is a hipStream_t (NULL = default stream).
+ * out_affine is HOST memory; the call returns after the result is there.  When out_xyzz is non-NULL
+ * the un-normalised partial sum (X,Y,ZZ,ZZZ) is written there too (multi-GPU combine). */
+int mlhip_msm_run(mlhip_msm_plan* plan, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
+                  void* stream, void* out_affine, void* out_xyzz);
+/* Phase timings of the last run with profiling on (HIP events on the plan's stream), milliseconds:
+ * [0] digits [1] sort (histogram scan + scatter) [2] bucket accumulation [3] bucket reduction
+ * [4] device total [5] host tail.  Returns the number of values written. */
+int mlhip_msm_plan_set_profiling(mlhip_msm_plan* plan, int on);
+int mlhip_msm_plan_timings(mlhip_msm_plan* plan, float* ms, int cap);
+
+int mlhip_miller_loop_device(int curve, const void* d_g1, const void* d_g2, size_t pairs_per_product,
+                             size_t n_products, void* d_out_gt, void* stream);
+int mlhip_final_exp_device(int curve, const void* d_in_gt, size_t n, void* d_out_gt, void* stream);
+int mlhip_pairing_batch_device(int curve, const void* d_g1, const void* d_g2, size_t n, void* d_out_gt,
+                               void* stream);
+int mlhip_gt_mul_device(int curve, const void* d_a_gt, const void* d_b_gt, size_t n, void* d_out_gt, void* stream);
+
+/* ---- group helpers (host, O(n) tiny): combine per-GPU partial results after the RCCL all-gather */
+int mlhip_g1_sum(int curve, const void* affine_points, size_t n, void* out_affine);
+int mlhip_g2_sum(int curve, const void* affine_points, size_t n, void* out_affine);
+
+/* ---- field kernel (parity / roofline probe): out[i] = a[i] * b[i] (Montgomery), device pointers */
+int mlhip_fp_mul_device(int curve, const void* d_a, const void* d_b, size_t n, int repeat, void* d_out,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLHIP_H */

@@ -1,0 +1,162 @@
+"""ctypes binding of libmlhip.so (C ABI: include/mlhip.h).
+
+The library is the product; this module only declares argument types.  There is no fallback of any
+kind: if the shared object is missing, or a call fails (no GPU, HIP error), an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmlhip.so")
+
+CURVE_BN254, CURVE_BLS12_381, CURVE_BLS12_377 = 0, 1, 2
+GROUP_G1, GROUP_G2 = 1, 2
+ENODEVICE = -2
+
+# every symbol include/mlhip.h declares (tests/test_abi.py checks the library exports them all)
+SYMBOLS = [
+    "mlhip_version",
+    "mlhip_last_error",
+    "mlhip_device_count",
+    "mlhip_set_device",
+    "mlhip_sizes",
+    "mlhip_msm_g1",
+    "mlhip_msm_g2",
+    "mlhip_miller_loop",
+    "mlhip_final_exp",
+    "mlhip_pairing_batch",
+    "mlhip_gt_mul",
+    "mlhip_msm_plan_create",
+    "mlhip_msm_plan_destroy",
+    "mlhip_msm_run",
+    "mlhip_msm_plan_set_profiling",
+    "mlhip_msm_plan_timings",
+    "mlhip_miller_loop_device",
+    "mlhip_final_exp_device",
+    "mlhip_pairing_batch_device",
+    "mlhip_gt_mul_device",
+    "mlhip_g1_sum",
+    "mlhip_g2_sum",
+    "mlhip_fp_mul_device",
+]
+
+
+class MlhipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libmlhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libmlhip.so; raises if it has not been built (python -m mathlib_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "mathlib_amd: %s is missing -- the HIP extension has not been built "
+            "(run `python -m mathlib_amd.build`); there is no CPU fallback" % LIB_PATH
+        )
+    # PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7) but its libraries ask for
+    # it by file name; if /opt/rocm's copy is mapped first the process ends up with two HIP runtimes
+    # and the second one sees no GPU.  Import torch first so both share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = c_void_p, c_size_t, c_int
+    lib.mlhip_version.restype = ci
+    lib.mlhip_last_error.restype = c_char_p
+    lib.mlhip_device_count.argtypes = [POINTER(ci)]
+    lib.mlhip_set_device.argtypes = [ci]
+    lib.mlhip_sizes.argtypes = [ci, POINTER(sz), POINTER(sz), POINTER(sz), POINTER(sz)]
+    for f in (lib.mlhip_msm_g1, lib.mlhip_msm_g2):
+        f.argtypes = [ci, vp, vp, ci, sz, ci, vp]
+    lib.mlhip_miller_loop.argtypes = [ci, vp, vp, sz, sz, vp]
+    lib.mlhip_final_exp.argtypes = [ci, vp, sz, vp]
+    lib.mlhip_pairing_batch.argtypes = [ci, vp, vp, sz, vp]
+    lib.mlhip_gt_mul.argtypes = [ci, vp, vp, sz, vp]
+    lib.mlhip_msm_plan_create.argtypes = [ci, ci, sz, ci, POINTER(vp)]
+    lib.mlhip_msm_plan_destroy.argtypes = [vp]
+    lib.mlhip_msm_run.argtypes = [vp, vp, vp, ci, sz, vp, vp, vp]
+    lib.mlhip_msm_plan_set_profiling.argtypes = [vp, ci]
+    lib.mlhip_msm_plan_timings.argtypes = [vp, POINTER(c_float), ci]
+    lib.mlhip_miller_loop_device.argtypes = [ci, vp, vp, sz, sz, vp, vp]
+    lib.mlhip_final_exp_device.argtypes = [ci, vp, sz, vp, vp]
+    lib.mlhip_pairing_batch_device.argtypes = [ci, vp, vp, sz, vp, vp]
+    lib.mlhip_gt_mul_device.argtypes = [ci, vp, vp, sz, vp, vp]
+    lib.mlhip_g1_sum.argtypes = [ci, vp, sz, vp]
+    lib.mlhip_g2_sum.argtypes = [ci, vp, sz, vp]
+    lib.mlhip_fp_mul_device.argtypes = [ci, vp, vp, sz, ci, vp, vp]
+    for name in SYMBOLS:
+        if name not in ("mlhip_last_error",):
+            getattr(lib, name).restype = ci
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise MlhipError(rc, load().mlhip_last_error().decode(errors="replace"))
+
+
+def sizes(curve: int):
+    lib = load()
+    a, b, c, d = c_size_t(), c_size_t(), c_size_t(), c_size_t()
+    check(lib.mlhip_sizes(curve, byref(a), byref(b), byref(c), byref(d)))
+    return a.value, b.value, c.value, d.value
+
+
+def device_count() -> int:
+    n = c_int()
+    load().mlhip_device_count(byref(n))
+    return n.value
+
+
+class MsmPlan:
+    """Device workspace for repeated MSMs over device-resident points/scalars (include/mlhip.h)."""
+
+    def __init__(self, curve: int, group: int, max_n: int, window_c: int = 0):
+        self._h = c_void_p()
+        lib = load()
+        check(lib.mlhip_msm_plan_create(curve, group, max_n, window_c, byref(self._h)))
+        _, g1, g2, _ = sizes(curve)
+        self.point_bytes = g1 if group == GROUP_G1 else g2
+        self.curve, self.group = curve, group
+
+    def set_profiling(self, on: bool) -> None:
+        check(load().mlhip_msm_plan_set_profiling(self._h, 1 if on else 0))
+
+    def timings(self):
+        buf = (c_float * 6)()
+        k = load().mlhip_msm_plan_timings(self._h, buf, 6)
+        names = ["digits", "sort", "accumulate", "reduce", "device_total", "host_tail"]
+        return {names[i]: float(buf[i]) for i in range(k)}
+
+    def run(self, d_points: int, d_scalars: int, n: int, scalars_mont: bool, stream: int = 0, want_xyzz: bool = False):
+        out = ctypes.create_string_buffer(self.point_bytes)
+        xyzz = ctypes.create_string_buffer(2 * self.point_bytes) if want_xyzz else None
+        check(
+            load().mlhip_msm_run(
+                self._h, c_void_p(d_points), c_void_p(d_scalars), 1 if scalars_mont else 0, n, c_void_p(stream), out, xyzz
+            )
+        )
+        return (out.raw, xyzz.raw) if want_xyzz else out.raw
+
+    def close(self) -> None:
+        if self._h:
+            load().mlhip_msm_plan_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,78 @@
+"""Builds mathlib_amd/libmlhip.so (HIP, gfx950 only) in-tree: one hipcc job per translation unit, in
+parallel, then one link.  `python -m mathlib_amd.build` or `__graft_entry__.build()`.
+
+Objects are cached under mathlib_amd/csrc/_obj and rebuilt when any source/header is newer.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libmlhip.so")
+ARCH = "gfx950"
+
+UNITS = [
+    "api.hip",
+    "tu_msm_bn254.hip",
+    "tu_msm_bls381.hip",
+    "tu_msm_bls377.hip",
+    "tu_pairing_bn254.hip",
+    "tu_pairing_bls381.hip",
+    "tu_pairing_bls377.hip",
+]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fno-gpu-rdc"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _deps_mtime() -> float:
+    m = 0.0
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(root):
+            if f.endswith((".h", ".hip", ".inc")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return m
+
+
+def _compile(unit: str, newest: float, verbose: bool) -> str:
+    src = os.path.join(CSRC, unit)
+    obj = os.path.join(OBJ, unit.replace(".hip", ".o"))
+    if os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+        return obj
+    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (unit, r.stdout, r.stderr))
+    return obj
+
+
+def build(verbose: bool = True, jobs: int | None = None) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    newest = _deps_mtime()
+    jobs = jobs or min(len(UNITS), max(1, (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda u: _compile(u, newest, verbose), UNITS))
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose="-q" not in sys.argv))

@@ -1,0 +1,382 @@
+// api.hip -- the extern "C" surface of libmlhip.so (include/mlhip.h): argument checking, device
+// selection, host-buffer staging and dispatch to the per-curve translation units.  No kernels here.
+// There is no CPU fallback: every compute entry point needs a HIP device (MLHIP_ENODEVICE otherwise).
+#include <cstring>
+#include <string>
+
+#include "ec.h"
+#include "mlhip_internal.h"
+#include "msm_body.h"
+
+using namespace mlhip;
+
+namespace {
+thread_local std::string g_err;
+thread_local int g_device = 0;
+
+int ensure_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return mlhip_rt::fail(MLHIP_ENODEVICE,
+                          std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
+  if (g_device < 0 || g_device >= n) return mlhip_rt::fail(MLHIP_EINVAL, "device index out of range");
+  HIPCHK(hipSetDevice(g_device));
+  return 0;
+}
+
+int ilog2(size_t v) {
+  int l = 0;
+  while (v > 1) {
+    v >>= 1;
+    l++;
+  }
+  return l;
+}
+
+int pick_window(size_t n) {
+  int c = ilog2(n ? n : 1) - 3;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  return c;
+}
+
+template <class F>
+int host_sum(const void* pts, size_t n, void* out) {
+  const Affine<F>* p = (const Affine<F>*)pts;
+  XYZZ<F> acc;
+  xyzz_set_inf<F>(acc);
+  for (size_t i = 0; i < n; i++) xyzz_madd<F>(acc, p[i], false);
+  Affine<F> r;
+  xyzz_to_affine<F>(r, acc);
+  memcpy(out, &r, sizeof(r));
+  return 0;
+}
+
+struct Sizes {
+  size_t fp, g1, g2, gt;
+  int fr_bits;
+};
+
+bool curve_sizes(int curve, Sizes& s) {
+  switch (curve) {
+    case MLHIP_CURVE_BN254:
+      s = {sizeof(Fp<Bn254>), sizeof(Affine<FpField<Bn254>>), sizeof(Affine<Fp2Field<Bn254>>), 12 * sizeof(Fp<Bn254>), Bn254::FR_BITS};
+      return true;
+    case MLHIP_CURVE_BLS12_381:
+      s = {sizeof(Fp<Bls381>), sizeof(Affine<FpField<Bls381>>), sizeof(Affine<Fp2Field<Bls381>>), 12 * sizeof(Fp<Bls381>), Bls381::FR_BITS};
+      return true;
+    case MLHIP_CURVE_BLS12_377:
+      s = {sizeof(Fp<Bls377>), sizeof(Affine<FpField<Bls377>>), sizeof(Affine<Fp2Field<Bls377>>), 12 * sizeof(Fp<Bls377>), Bls377::FR_BITS};
+      return true;
+    default:
+      return false;
+  }
+}
+
+int tu_pairing(int curve, int what, const void* d1, const void* d2, size_t ppp, size_t n, const void* din, void* dout,
+               hipStream_t st) {
+  switch (curve) {
+    case MLHIP_CURVE_BN254: return mlhip_tu_pairing_Bn254(what, d1, d2, ppp, n, din, dout, st);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_pairing_Bls381(what, d1, d2, ppp, n, din, dout, st);
+    case MLHIP_CURVE_BLS12_377: return mlhip_tu_pairing_Bls377(what, d1, d2, ppp, n, din, dout, st);
+    default: return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  }
+}
+
+// host-buffer wrapper around the pairing kernels: upload, run, download
+int pairing_host(int curve, int what, const void* g1, const void* g2, size_t ppp, size_t n, const void* in, void* out) {
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (n == 0) return 0;
+  int rc = ensure_device();
+  if (rc) return rc;
+  void *d1 = nullptr, *d2 = nullptr, *din = nullptr, *dout = nullptr;
+  rc = MLHIP_OK;
+  do {
+    if (what == 1) {
+      if (!in || !out) { rc = mlhip_rt::fail(MLHIP_EINVAL, "null pointer"); break; }
+      if (hipMalloc(&din, n * sz.gt) != hipSuccess || hipMalloc(&dout, n * sz.gt) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc failed"); break; }
+      if (hipMemcpy(din, in, n * sz.gt, hipMemcpyHostToDevice) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy H2D failed"); break; }
+    } else {
+      if (!g1 || !g2 || !out) { rc = mlhip_rt::fail(MLHIP_EINVAL, "null pointer"); break; }
+      size_t np = n * ppp;
+      if (hipMalloc(&d1, np * sz.g1) != hipSuccess || hipMalloc(&d2, np * sz.g2) != hipSuccess || hipMalloc(&dout, n * sz.gt) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc failed"); break; }
+      if (hipMemcpy(d1, g1, np * sz.g1, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d2, g2, np * sz.g2, hipMemcpyHostToDevice) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy H2D failed"); break; }
+    }
+    rc = tu_pairing(curve, what, d1, d2, ppp, n, din, dout, nullptr);
+    if (rc) break;
+    hipError_t e = hipMemcpy(out, dout, n * sz.gt, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e)); break; }
+  } while (0);
+  if (d1) (void)hipFree(d1);
+  if (d2) (void)hipFree(d2);
+  if (din) (void)hipFree(din);
+  if (dout) (void)hipFree(dout);
+  return rc;
+}
+
+int msm_host_buffers(int curve, int group, const void* points, const void* scalars, int mont, size_t n, int window_c,
+                     void* out) {
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (!out) return mlhip_rt::fail(MLHIP_EINVAL, "null output pointer");
+  const size_t ptsz = group == MLHIP_GROUP_G1 ? sz.g1 : sz.g2;
+  if (n == 0) {
+    // the point at infinity, as gnark's MultiExp gives for empty slices (and, via the dropped
+    // error, for mismatched lengths: bls12-381.go:777)
+    memset(out, 0, ptsz);
+    return 0;
+  }
+  if (!points || !scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  mlhip_msm_plan* plan = nullptr;
+  int rc = mlhip_msm_plan_create(curve, group, n, window_c, &plan);
+  if (rc) return rc;
+  void *d_pts = nullptr, *d_sc = nullptr;
+  do {
+    if (hipMalloc(&d_pts, n * ptsz) != hipSuccess || hipMalloc(&d_sc, n * 32) != hipSuccess) {
+      rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of MSM inputs failed");
+      break;
+    }
+    if (hipMemcpy(d_pts, points, n * ptsz, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_sc, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess) {
+      rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy of MSM inputs failed");
+      break;
+    }
+    rc = mlhip_msm_run(plan, d_pts, d_sc, mont, n, nullptr, out, nullptr);
+  } while (0);
+  if (d_pts) (void)hipFree(d_pts);
+  if (d_sc) (void)hipFree(d_sc);
+  mlhip_msm_plan_destroy(plan);
+  return rc;
+}
+
+}  // namespace
+
+namespace mlhip_rt {
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+}  // namespace mlhip_rt
+
+extern "C" {
+
+int mlhip_version(void) { return 100; }
+
+const char* mlhip_last_error(void) { return g_err.c_str(); }
+
+int mlhip_device_count(int* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) n = 0;
+  if (count) *count = n;
+  return 0;
+}
+
+int mlhip_set_device(int device) {
+  if (device < 0) return mlhip_rt::fail(MLHIP_EINVAL, "negative device index");
+  g_device = device;
+  return 0;
+}
+
+int mlhip_sizes(int curve, size_t* fp, size_t* g1, size_t* g2, size_t* gt) {
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (fp) *fp = sz.fp;
+  if (g1) *g1 = sz.g1;
+  if (g2) *g2 = sz.g2;
+  if (gt) *gt = sz.gt;
+  return 0;
+}
+
+int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhip_msm_plan** out) {
+  if (!out) return mlhip_rt::fail(MLHIP_EINVAL, "null plan pointer");
+  *out = nullptr;
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (group != MLHIP_GROUP_G1 && group != MLHIP_GROUP_G2)
+    return mlhip_rt::fail(MLHIP_EINVAL, "group must be 1 (G1) or 2 (G2)");
+  if (max_n == 0 || max_n > ((size_t)1 << 27)) return mlhip_rt::fail(MLHIP_EINVAL, "max_n out of range (1 .. 2^27)");
+  if (window_c == 0) window_c = pick_window(max_n);
+  if (window_c < 4 || window_c > 20) return mlhip_rt::fail(MLHIP_EINVAL, "window_c out of range (4 .. 20)");
+  int rc = ensure_device();
+  if (rc) return rc;
+  mlhip_msm_plan* p = new mlhip_msm_plan();
+  p->curve = curve;
+  p->group = group;
+  p->device = g_device;
+  p->c = window_c;
+  p->W = msm_num_windows(sz.fr_bits, window_c);
+  p->max_n = max_n;
+  p->M = 1u << (window_c - 1);
+  p->L = 8;
+  p->lgL = 3;
+  p->T = p->M / p->L;
+  p->nb = ilog2(p->T);
+  p->nsel = 2 + p->nb;
+  switch (curve) {
+    case MLHIP_CURVE_BN254: rc = mlhip_tu_plan_alloc_Bn254(p); break;
+    case MLHIP_CURVE_BLS12_381: rc = mlhip_tu_plan_alloc_Bls381(p); break;
+    default: rc = mlhip_tu_plan_alloc_Bls377(p); break;
+  }
+  if (rc) {
+    mlhip_msm_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return 0;
+}
+
+int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
+  if (!p) return 0;
+  (void)hipSetDevice(p->device);
+  void* ptrs[] = {p->d_digits, p->d_sorted, p->d_zero, p->d_offsets, p->d_biglist, p->d_buckets, p->d_A, p->d_W0, p->d_out};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  if (p->h_out) (void)hipHostFree(p->h_out);
+  for (int i = 0; i < 5; i++)
+    if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
+  delete p;
+  return 0;
+}
+
+int mlhip_msm_run(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
+                  void* stream, void* out_affine, void* out_xyzz) {
+  if (!p || !out_affine) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  if (n > p->max_n) return mlhip_rt::fail(MLHIP_EINVAL, "n exceeds the plan's max_n");
+  if (n && (!d_points || !d_scalars)) return mlhip_rt::fail(MLHIP_EINVAL, "null device pointer");
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t st = (hipStream_t)stream;
+  switch (p->curve) {
+    case MLHIP_CURVE_BN254: return mlhip_tu_plan_run_Bn254(p, d_points, d_scalars, scalars_mont, n, st, out_affine, out_xyzz);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_plan_run_Bls381(p, d_points, d_scalars, scalars_mont, n, st, out_affine, out_xyzz);
+    default: return mlhip_tu_plan_run_Bls377(p, d_points, d_scalars, scalars_mont, n, st, out_affine, out_xyzz);
+  }
+}
+
+int mlhip_msm_plan_set_profiling(mlhip_msm_plan* p, int on) {
+  if (!p) return mlhip_rt::fail(MLHIP_EINVAL, "null plan");
+  p->profiling = on != 0;
+  return 0;
+}
+
+int mlhip_msm_plan_timings(mlhip_msm_plan* p, float* ms, int cap) {
+  if (!p || !ms) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  int k = cap < 6 ? cap : 6;
+  for (int i = 0; i < k; i++) ms[i] = p->ms[i];
+  return k;
+}
+
+int mlhip_msm_g1(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
+                 void* out_affine) {
+  return msm_host_buffers(curve, MLHIP_GROUP_G1, points, scalars, scalars_mont, n, window_c, out_affine);
+}
+
+int mlhip_msm_g2(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
+                 void* out_affine) {
+  return msm_host_buffers(curve, MLHIP_GROUP_G2, points, scalars, scalars_mont, n, window_c, out_affine);
+}
+
+int mlhip_miller_loop(int curve, const void* g1, const void* g2, size_t ppp, size_t n_products, void* out_gt) {
+  if (ppp < 1 || ppp > 4) return mlhip_rt::fail(MLHIP_EINVAL, "pairs_per_product must be 1..4");
+  return pairing_host(curve, 0, g1, g2, ppp, n_products, nullptr, out_gt);
+}
+
+int mlhip_final_exp(int curve, const void* in_gt, size_t n, void* out_gt) {
+  return pairing_host(curve, 1, nullptr, nullptr, 1, n, in_gt, out_gt);
+}
+
+int mlhip_pairing_batch(int curve, const void* g1, const void* g2, size_t n, void* out_gt) {
+  return pairing_host(curve, 2, g1, g2, 1, n, nullptr, out_gt);
+}
+
+int mlhip_miller_loop_device(int curve, const void* d_g1, const void* d_g2, size_t ppp, size_t n_products,
+                             void* d_out_gt, void* stream) {
+  if (ppp < 1 || ppp > 4) return mlhip_rt::fail(MLHIP_EINVAL, "pairs_per_product must be 1..4");
+  int rc = ensure_device();
+  if (rc) return rc;
+  return tu_pairing(curve, 0, d_g1, d_g2, ppp, n_products, nullptr, d_out_gt, (hipStream_t)stream);
+}
+
+int mlhip_final_exp_device(int curve, const void* d_in_gt, size_t n, void* d_out_gt, void* stream) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  return tu_pairing(curve, 1, nullptr, nullptr, 1, n, d_in_gt, d_out_gt, (hipStream_t)stream);
+}
+
+int mlhip_pairing_batch_device(int curve, const void* d_g1, const void* d_g2, size_t n, void* d_out_gt, void* stream) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  return tu_pairing(curve, 2, d_g1, d_g2, 1, n, nullptr, d_out_gt, (hipStream_t)stream);
+}
+
+int mlhip_gt_mul_device(int curve, const void* d_a, const void* d_b, size_t n, void* d_out, void* stream) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (curve) {
+    case MLHIP_CURVE_BN254: return mlhip_tu_gt_mul_Bn254(d_a, d_b, n, d_out, st);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_gt_mul_Bls381(d_a, d_b, n, d_out, st);
+    case MLHIP_CURVE_BLS12_377: return mlhip_tu_gt_mul_Bls377(d_a, d_b, n, d_out, st);
+    default: return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  }
+}
+
+int mlhip_gt_mul(int curve, const void* a, const void* b, size_t n, void* out) {
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (n == 0) return 0;
+  if (!a || !b || !out) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  int rc = ensure_device();
+  if (rc) return rc;
+  void *da = nullptr, *db = nullptr, *dout = nullptr;
+  do {
+    if (hipMalloc(&da, n * sz.gt) != hipSuccess || hipMalloc(&db, n * sz.gt) != hipSuccess || hipMalloc(&dout, n * sz.gt) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc failed"); break; }
+    if (hipMemcpy(da, a, n * sz.gt, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(db, b, n * sz.gt, hipMemcpyHostToDevice) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy H2D failed"); break; }
+    rc = mlhip_gt_mul_device(curve, da, db, n, dout, nullptr);
+    if (rc) break;
+    hipError_t e = hipMemcpy(out, dout, n * sz.gt, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e)); break; }
+  } while (0);
+  if (da) (void)hipFree(da);
+  if (db) (void)hipFree(db);
+  if (dout) (void)hipFree(dout);
+  return rc;
+}
+
+int mlhip_g1_sum(int curve, const void* pts, size_t n, void* out) {
+  if (!out || (n && !pts)) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  switch (curve) {
+    case MLHIP_CURVE_BN254: return host_sum<FpField<Bn254>>(pts, n, out);
+    case MLHIP_CURVE_BLS12_381: return host_sum<FpField<Bls381>>(pts, n, out);
+    case MLHIP_CURVE_BLS12_377: return host_sum<FpField<Bls377>>(pts, n, out);
+    default: return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  }
+}
+
+int mlhip_g2_sum(int curve, const void* pts, size_t n, void* out) {
+  if (!out || (n && !pts)) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  switch (curve) {
+    case MLHIP_CURVE_BN254: return host_sum<Fp2Field<Bn254>>(pts, n, out);
+    case MLHIP_CURVE_BLS12_381: return host_sum<Fp2Field<Bls381>>(pts, n, out);
+    case MLHIP_CURVE_BLS12_377: return host_sum<Fp2Field<Bls377>>(pts, n, out);
+    default: return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  }
+}
+
+int mlhip_fp_mul_device(int curve, const void* d_a, const void* d_b, size_t n, int repeat, void* d_out, void* stream) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (curve) {
+    case MLHIP_CURVE_BN254: return mlhip_tu_fp_mul_Bn254(d_a, d_b, n, repeat, d_out, st);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_fp_mul_Bls381(d_a, d_b, n, repeat, d_out, st);
+    case MLHIP_CURVE_BLS12_377: return mlhip_tu_fp_mul_Bls377(d_a, d_b, n, repeat, d_out, st);
+    default: return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  }
+}
+
+}  // extern "C"

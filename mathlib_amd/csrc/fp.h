@@ -185,16 +185,77 @@ MLHIP_HD void fp_mul_inline(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
   fp_reduce_once<C>(r, o);
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host-side variant for the O(1) tail of an MSM (window combination + to-affine, ~3k field
+// multiplications per call): same CIOS on 64-bit limbs (the element's bytes are identical, the
+// host is little-endian).  Tests build with MLHIP_HOST_USE_DEVICE_PATH to exercise the 32-bit
+// device code on the CPU instead.
+template <class C>
+inline void fp_mul_host64(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+  constexpr int N = C::N / 2;
+  typedef unsigned __int128 u128;
+  uint64_t A[N], B[N], Pm[N], t[N + 2];
+  for (int i = 0; i < N; i++) {
+    A[i] = a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+    B[i] = b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+    Pm[i] = C::P[2 * i] | ((uint64_t)C::P[2 * i + 1] << 32);
+  }
+  for (int i = 0; i < N + 2; i++) t[i] = 0;
+  for (int i = 0; i < N; i++) {
+    u128 c = 0;
+    for (int j = 0; j < N; j++) {
+      u128 acc = (u128)A[j] * B[i] + t[j] + c;
+      t[j] = (uint64_t)acc;
+      c = acc >> 64;
+    }
+    u128 acc = (u128)t[N] + c;
+    t[N] = (uint64_t)acc;
+    t[N + 1] = (uint64_t)(acc >> 64);
+    uint64_t m = t[0] * C::INV64;
+    acc = (u128)m * Pm[0] + t[0];
+    c = acc >> 64;
+    for (int j = 1; j < N; j++) {
+      acc = (u128)m * Pm[j] + t[j] + c;
+      t[j - 1] = (uint64_t)acc;
+      c = acc >> 64;
+    }
+    acc = (u128)t[N] + c;
+    t[N - 1] = (uint64_t)acc;
+    t[N] = t[N + 1] + (uint64_t)(acc >> 64);
+  }
+  uint64_t d[N];
+  unsigned br = 0;
+  for (int i = 0; i < N; i++) {
+    u128 s = (u128)t[i] - Pm[i] - br;
+    d[i] = (uint64_t)s;
+    br = (unsigned)((s >> 64) & 1);
+  }
+  for (int i = 0; i < N; i++) {
+    uint64_t v = br ? t[i] : d[i];
+    r.l[2 * i] = (uint32_t)v;
+    r.l[2 * i + 1] = (uint32_t)(v >> 32);
+  }
+}
+#endif
+
 // Out-of-line entry points: one copy of the ~1.2k-instruction multiply per kernel keeps the hot
 // loop inside the instruction cache (an inlined G1 mixed add would be >100 KB of code).
 template <class C>
 MLHIP_HD_NOINLINE void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(MLHIP_HOST_USE_DEVICE_PATH)
   fp_mul_inline<C>(r, a, b);
+#else
+  fp_mul_host64<C>(r, a, b);
+#endif
 }
 
 template <class C>
 MLHIP_HD_NOINLINE void fp_sqr(Fp<C>& r, const Fp<C>& a) {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(MLHIP_HOST_USE_DEVICE_PATH)
   fp_mul_inline<C>(r, a, a);
+#else
+  fp_mul_host64<C>(r, a, a);
+#endif
 }
 
 // a * small constant (k <= 16) by additions

@@ -1,0 +1,47 @@
+// mlhip_internal.h -- shared declarations of libmlhip.so's translation units (one per curve and
+// kernel family, so the build parallelises; see mathlib_amd/build.py).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/mlhip.h"
+
+namespace mlhip_rt {
+int fail(int code, const std::string& msg);
+}
+
+#define HIPCHK(x)                                                                                             \
+  do {                                                                                                        \
+    hipError_t e_ = (x);                                                                                      \
+    if (e_ != hipSuccess) return mlhip_rt::fail(MLHIP_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct mlhip_msm_plan {
+  int curve, group, device, c, W, L, lgL, nb, nsel;
+  size_t max_n;
+  uint32_t M, T;
+  size_t pt_size, xyzz_size;
+  uint32_t *d_digits = nullptr, *d_sorted = nullptr, *d_zero = nullptr, *d_offsets = nullptr, *d_biglist = nullptr;
+  uint32_t *d_counts = nullptr, *d_cursor = nullptr, *d_bigcount = nullptr;  // views into d_zero
+  size_t zero_bytes = 0;
+  void *d_buckets = nullptr, *d_A = nullptr, *d_W0 = nullptr, *d_out = nullptr;
+  void* h_out = nullptr;
+  bool profiling = false;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float ms[6] = {0, 0, 0, 0, 0, 0};
+};
+
+
+// per-curve entry points, defined in tu_msm_<curve>.hip / tu_pairing_<curve>.hip
+#define MLHIP_DECLARE_CURVE(NAME)                                                                                   \
+  int mlhip_tu_plan_alloc_##NAME(mlhip_msm_plan* p);                                                                \
+  int mlhip_tu_plan_run_##NAME(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n,  \
+                               hipStream_t st, void* out_affine, void* out_xyzz);                                   \
+  int mlhip_tu_pairing_##NAME(int what, const void* d_g1, const void* d_g2, size_t ppp, size_t n, const void* d_in, \
+                              void* d_out, hipStream_t st);                                                         \
+  int mlhip_tu_fp_mul_##NAME(const void* d_a, const void* d_b, size_t n, int repeat, void* d_out, hipStream_t st);   \
+  int mlhip_tu_gt_mul_##NAME(const void* d_a, const void* d_b, size_t n, void* d_out, hipStream_t st);
+MLHIP_DECLARE_CURVE(Bn254)
+MLHIP_DECLARE_CURVE(Bls381)
+MLHIP_DECLARE_CURVE(Bls377)

@@ -1,0 +1,125 @@
+// msm_body.h -- per-thread bodies of the Pippenger MSM kernels (gfx950), shared with the host-side
+// emulation used by tests/test_host_math.py (each body is __host__ __device__ and takes the global
+// thread index explicitly, so the CPU test can replay a launch thread by thread).
+//
+// Replaces gnark-crypto's MultiExp behind the reference's MultiScalarMul
+// (driver/gurvy/bls12381/bls12-381.go:766-783, driver/gurvy/bn254.go:232-245,
+// driver/gurvy/bls12-377.go:229-242): signed-digit windows, bucket accumulation in XYZZ
+// coordinates, bucket reduction, window combination.  Data layout and pipeline: DESIGN.md section 3.
+#pragma once
+#include "ec.h"
+
+namespace mlhip {
+
+// ---- scalar handling -------------------------------------------------------------------------
+// Scalars arrive as 8 little-endian 32-bit words: either gnark's fr.Element (Montgomery, R = 2^256;
+// what driver/gurvy/bls12381 passes, bls12-381.go:772) or a plain integer (any 256-bit value; it is
+// reduced mod r here, as fr.Element.SetBigInt does for the BaseZr curves, bn254.go:239).
+template <class C>
+MLHIP_HD void fr_canonical(uint32_t (&s)[8], const uint32_t* in, bool mont) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = in[i];
+  t[8] = 0;
+  if (mont) {
+    // Montgomery reduction: t <- t * 2^-256 mod r
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint32_t m = t[0] * C::FR_INV;
+      uint64_t acc = (uint64_t)m * C::FR[0] + t[0];
+      uint64_t c = acc >> 32;
+#pragma unroll
+      for (int j = 1; j < 8; j++) {
+        acc = (uint64_t)m * C::FR[j] + t[j] + c;
+        t[j - 1] = (uint32_t)acc;
+        c = acc >> 32;
+      }
+      acc = (uint64_t)t[8] + c;
+      t[7] = (uint32_t)acc;
+      t[8] = (uint32_t)(acc >> 32);
+    }
+  }
+  // reduce below r (a 256-bit input is < 16 r for every supported curve)
+  for (int it = 0; it < 16; it++) {
+    uint32_t d[8];
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint64_t x = (uint64_t)t[i] - C::FR[i] - br;
+      d[i] = (uint32_t)x;
+      br = (x >> 32) & 1;
+    }
+    bool ge = (t[8] != 0) | (br == 0);
+    if (!ge) break;
+    t[8] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = d[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) s[i] = t[i];
+}
+
+MLHIP_HD int msm_num_windows(int fr_bits, int c) { return (fr_bits + 1 + c - 1) / c; }
+
+// Signed window digits: value v_w = bits[wc, (w+1)c) + carry; v_w > 2^(c-1) => v_w -= 2^c, carry 1.
+// Encoded as 0 (skip) or (magnitude << 1) | sign with magnitude in [1, 2^(c-1)] -> bucket magnitude-1.
+template <class C>
+MLHIP_HD void msm_digits_body(size_t i, size_t n, const uint32_t* scalars, bool mont, int c, int W,
+                              uint32_t* digits /* [W][n] */) {
+  uint32_t s[8];
+  fr_canonical<C>(s, scalars + 8 * i, mont);
+  uint32_t carry = 0;
+  const uint32_t half = 1u << (c - 1);
+  for (int w = 0; w < W; w++) {
+    int bit = w * c;
+    uint32_t v = 0;
+    if (bit < 256) {
+      int word = bit >> 5, sh = bit & 31;
+      uint64_t two = s[word];
+      if (word + 1 < 8) two |= (uint64_t)s[word + 1] << 32;
+      v = (uint32_t)((two >> sh) & ((1u << c) - 1));
+    }
+    v += carry;
+    uint32_t enc;
+    if (v > half) {
+      // v == 2^c (all-ones window plus carry) is digit 0 with a carry, not "minus zero"
+      uint32_t mag = (1u << c) - v;
+      enc = mag ? ((mag << 1) | 1u) : 0u;
+      carry = 1;
+    } else {
+      enc = v << 1;  // 0 when v == 0
+      carry = 0;
+    }
+    digits[(size_t)w * n + i] = enc;
+  }
+}
+
+// ---- bucket accumulation ---------------------------------------------------------------------
+// One thread owns bucket g = w*M + b: adds the points listed in sorted[offset .. offset+count).
+template <class F>
+MLHIP_HD void msm_accumulate_range(XYZZ<F>& acc, const Affine<F>* points, const uint32_t* sorted, size_t begin,
+                                   size_t end, size_t stride) {
+  for (size_t k = begin; k < end; k += stride) {
+    uint32_t e = sorted[k];
+    xyzz_madd<F>(acc, points[e & 0x7fffffffu], (e >> 31) != 0);
+  }
+}
+
+// ---- bucket reduction, level 1 ---------------------------------------------------------------
+// Thread t of window w owns buckets [t*L, (t+1)*L): A = sum B_b ; W0 = sum_i i * B_{tL+i}.
+template <class F, int L>
+MLHIP_HD void msm_chunk_body(size_t g, const XYZZ<F>* buckets, XYZZ<F>* A, XYZZ<F>* W0, int l_eff) {
+  const XYZZ<F>* b = buckets + g * (size_t)l_eff;
+  XYZZ<F> acc, w0;
+  xyzz_set_inf<F>(acc);
+  xyzz_set_inf<F>(w0);
+  for (int i = l_eff - 1; i >= 1; i--) {
+    xyzz_add<F>(acc, b[i]);
+    xyzz_add<F>(w0, acc);
+  }
+  xyzz_add<F>(acc, b[0]);
+  A[g] = acc;
+  W0[g] = w0;
+}
+
+}  // namespace mlhip

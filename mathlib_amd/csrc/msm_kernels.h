@@ -1,0 +1,300 @@
+// msm_kernels.h -- Pippenger MSM kernels and their launch sequence (gfx950).  Included by the per-curve
+// translation units tu_msm_<curve>.hip.  Pipeline and data layout: DESIGN.md section 3.
+//   k_digits      scalars -> signed window digits [W][n] + per-bucket histogram (global atomics)
+//   k_scan        exclusive scan of the W*M bucket counts
+//   k_scatter     counting-sort scatter: point indices grouped by (window, bucket)
+//   k_accumulate  one thread per bucket: XYZZ += points[idx] (mixed additions, gathered reads)
+//   k_accumulate_big  buckets longer than BIG_BUCKET: one workgroup each, LDS tree (degenerate inputs)
+//   k_chunks      level-1 bucket reduction: per 8 consecutive buckets, sum and locally weighted sum
+//   k_masked_sums level-2: per window, plain / bit-masked sums of the chunk sums (LDS tree)
+//   host tail     Horner over <= W*c bit positions + one inversion (O(1) work, 64-bit limbs)
+// Replaces gnark-crypto's MultiExp behind MultiScalarMul (reference
+// driver/gurvy/bls12381/bls12-381.go:766-783, driver/gurvy/bn254.go:232-245, driver/gurvy/bls12-377.go:229-242).
+#pragma once
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+#include "mlhip_internal.h"
+#include "msm_body.h"
+
+namespace mlhip {
+
+constexpr uint32_t BIG_BUCKET = 256;  // entries above which a bucket is summed by a whole workgroup
+constexpr int CHUNK_L = 8;            // buckets per level-1 reduction thread
+
+// ------------------------------------------------------------------------------------ kernels
+template <class C>
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
+                                                uint32_t M, uint32_t* __restrict__ digits,
+                                                uint32_t* __restrict__ counts) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    msm_digits_body<C>(i, n, scalars, mont != 0, c, W, digits);
+    for (int w = 0; w < W; w++) {
+      uint32_t d = digits[(size_t)w * n + i];
+      if (d) atomicAdd(&counts[(size_t)w * M + (d >> 1) - 1], 1u);
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                               size_t total) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x;
+  size_t per = (total + 1023) / 1024;
+  size_t lo = (size_t)tid * per, hi = lo + per;
+  if (lo > total) lo = total;
+  if (hi > total) hi = total;
+  uint32_t s = 0;
+  for (size_t k = lo; k < hi; k++) s += counts[k];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t base = part[tid] - s;
+  for (size_t k = lo; k < hi; k++) {
+    offsets[k] = base;
+    base += counts[k];
+  }
+}
+
+static __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ digits, size_t n, int W, uint32_t M,
+                                                 const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                                 uint32_t* __restrict__ sorted) {
+  size_t total = (size_t)W * n;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    uint32_t d = digits[idx];
+    if (!d) continue;
+    size_t w = idx / n;
+    size_t i = idx - w * n;
+    size_t g = w * M + (d >> 1) - 1;
+    uint32_t pos = offsets[g] + atomicAdd(&cursor[g], 1u);
+    sorted[pos] = (uint32_t)i | ((d & 1u) << 31);
+  }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict__ points,
+                                                    const uint32_t* __restrict__ sorted,
+                                                    const uint32_t* __restrict__ offsets,
+                                                    const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                    uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
+                                                    XYZZ<F>* __restrict__ buckets) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_buckets) return;
+  uint32_t cnt = counts[g];
+  if (cnt > BIG_BUCKET) {
+    uint32_t pos = atomicAdd(big_count, 1u);
+    big_list[pos] = (uint32_t)g;
+    return;
+  }
+  XYZZ<F> acc;
+  xyzz_set_inf<F>(acc);
+  size_t begin = offsets[g];
+  msm_accumulate_range<F>(acc, points, sorted, begin, begin + cnt, 1);
+  buckets[g] = acc;
+}
+
+// LDS tree sum of one XYZZ per thread; result valid in sh[0] after return (all threads must call)
+template <class F, int BLOCK>
+__device__ void block_tree_sum(XYZZ<F>* sh, const XYZZ<F>& mine) {
+  const int tid = threadIdx.x;
+  sh[tid] = mine;
+  __syncthreads();
+  for (int s = BLOCK / 2; s > 0; s >>= 1) {
+    if (tid < s) {
+      XYZZ<F> a = sh[tid];
+      xyzz_add<F>(a, sh[tid + s]);
+      sh[tid] = a;
+    }
+    __syncthreads();
+  }
+}
+
+template <class F, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_accumulate_big(const Affine<F>* __restrict__ points,
+                                                          const uint32_t* __restrict__ sorted,
+                                                          const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ counts,
+                                                          const uint32_t* __restrict__ big_list,
+                                                          const uint32_t* __restrict__ big_count,
+                                                          XYZZ<F>* __restrict__ buckets) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  const uint32_t nbig = *big_count;
+  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    uint32_t g = big_list[bi];
+    size_t begin = offsets[g];
+    size_t end = begin + counts[g];
+    XYZZ<F> acc;
+    xyzz_set_inf<F>(acc);
+    msm_accumulate_range<F>(acc, points, sorted, begin + threadIdx.x, end, BLOCK);
+    block_tree_sum<F, BLOCK>(sh, acc);
+    if (threadIdx.x == 0) buckets[g] = sh[0];
+    __syncthreads();
+  }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_chunks(const XYZZ<F>* __restrict__ buckets, size_t n_chunks, int l_eff,
+                                                XYZZ<F>* __restrict__ A, XYZZ<F>* __restrict__ W0) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_chunks) return;
+  msm_chunk_body<F, CHUNK_L>(g, buckets, A, W0, l_eff);
+}
+
+// block (w, sel): sel 0 -> sum_t W0[w][t]; sel 1 -> sum_t A[w][t]; sel 2+k -> sum over t with bit k set of A[w][t]
+template <class F, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_masked_sums(const XYZZ<F>* __restrict__ A, const XYZZ<F>* __restrict__ W0,
+                                                       uint32_t T, int nsel, XYZZ<F>* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  const uint32_t w = blockIdx.x / nsel;
+  const int sel = blockIdx.x % nsel;
+  const XYZZ<F>* src = (sel == 0 ? W0 : A) + (size_t)w * T;
+  XYZZ<F> acc;
+  xyzz_set_inf<F>(acc);
+  if (sel < 2) {
+    for (uint32_t t = threadIdx.x; t < T; t += BLOCK) xyzz_add<F>(acc, src[t]);
+  } else {
+    const int k = sel - 2;
+    const uint32_t lowmask = (1u << k) - 1u;
+    for (uint32_t j = threadIdx.x; j < T / 2; j += BLOCK) {
+      uint32_t t = ((j >> k) << (k + 1)) | (1u << k) | (j & lowmask);
+      xyzz_add<F>(acc, src[t]);
+    }
+  }
+  block_tree_sum<F, BLOCK>(sh, acc);
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+template <class F>
+int plan_alloc(mlhip_msm_plan* p) {
+  const size_t nbuckets = (size_t)p->W * p->M;
+  p->pt_size = sizeof(Affine<F>);
+  p->xyzz_size = sizeof(XYZZ<F>);
+  HIPCHK(hipMalloc(&p->d_digits, (size_t)p->W * p->max_n * 4));
+  HIPCHK(hipMalloc(&p->d_sorted, (size_t)p->W * p->max_n * 4));
+  p->zero_bytes = (2 * nbuckets + 4) * 4;
+  HIPCHK(hipMalloc(&p->d_zero, p->zero_bytes));
+  p->d_counts = p->d_zero;
+  p->d_cursor = p->d_zero + nbuckets;
+  p->d_bigcount = p->d_zero + 2 * nbuckets;
+  HIPCHK(hipMalloc(&p->d_offsets, nbuckets * 4));
+  HIPCHK(hipMalloc(&p->d_biglist, nbuckets * 4));
+  HIPCHK(hipMalloc(&p->d_buckets, nbuckets * p->xyzz_size));
+  HIPCHK(hipMalloc(&p->d_A, (size_t)p->W * p->T * p->xyzz_size));
+  HIPCHK(hipMalloc(&p->d_W0, (size_t)p->W * p->T * p->xyzz_size));
+  HIPCHK(hipMalloc(&p->d_out, (size_t)p->W * p->nsel * p->xyzz_size));
+  HIPCHK(hipHostMalloc(&p->h_out, (size_t)p->W * p->nsel * p->xyzz_size, hipHostMallocDefault));
+  for (int i = 0; i < 5; i++) HIPCHK(hipEventCreate(&p->ev[i]));
+  return 0;
+}
+
+// Horner over bit positions: total = sum_w 2^(cw) [ out[w][0] + out[w][1] + L * sum_k 2^k out[w][2+k] ]
+template <class F>
+void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
+  const XYZZ<F>* o = reinterpret_cast<const XYZZ<F>*>(p->h_out);
+  const int npos = p->W * p->c;
+  std::vector<XYZZ<F>> slot(npos);
+  for (int i = 0; i < npos; i++) xyzz_set_inf<F>(slot[i]);
+  for (int w = 0; w < p->W; w++) {
+    XYZZ<F> s = o[w * p->nsel + 0];
+    xyzz_add<F>(s, o[w * p->nsel + 1]);
+    slot[w * p->c] = s;
+    for (int k = 0; k < p->nb; k++) slot[w * p->c + p->lgL + k] = o[w * p->nsel + 2 + k];
+  }
+  xyzz_set_inf<F>(total);
+  bool started = false;
+  for (int i = npos - 1; i >= 0; i--) {
+    if (started) {
+      XYZZ<F> d;
+      xyzz_dbl<F>(d, total);
+      total = d;
+    }
+    if (!xyzz_is_inf<F>(slot[i])) {
+      xyzz_add<F>(total, slot[i]);
+      started = true;
+    }
+  }
+}
+
+template <class C, class F>
+int plan_run(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n, hipStream_t st,
+             void* out_affine, void* out_xyzz) {
+  typedef Affine<F> A;
+  typedef XYZZ<F> X;
+  X total;
+  if (n == 0) {
+    xyzz_set_inf<F>(total);
+  } else {
+    const size_t nbuckets = (size_t)p->W * p->M;
+    const bool prof = p->profiling;
+    HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
+    if (prof) HIPCHK(hipEventRecord(p->ev[0], st));
+    {
+      size_t blocks = (n + 255) / 256;
+      if (blocks > 65536) blocks = 65536;
+      k_digits<C><<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->M,
+                                                                 p->d_digits, p->d_counts);
+    }
+    if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
+    k_scan<<<dim3(1), dim3(1024), 0, st>>>(p->d_counts, p->d_offsets, nbuckets);
+    {
+      size_t total_e = (size_t)p->W * n;
+      size_t blocks = (total_e + 255) / 256;
+      if (blocks > 262144) blocks = 262144;
+      k_scatter<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(p->d_digits, n, p->W, p->M, p->d_offsets, p->d_cursor,
+                                                               p->d_sorted);
+    }
+    if (prof) HIPCHK(hipEventRecord(p->ev[2], st));
+    k_accumulate<F><<<dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+        (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_biglist, p->d_bigcount,
+        (X*)p->d_buckets);
+    {
+      constexpr int BB = sizeof(X) <= 192 ? 256 : 128;  // 48 KB of LDS per block
+      k_accumulate_big<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>((const A*)d_points, p->d_sorted,
+                                                                            p->d_offsets, p->d_counts, p->d_biglist,
+                                                                            p->d_bigcount, (X*)p->d_buckets);
+    }
+    if (prof) HIPCHK(hipEventRecord(p->ev[3], st));
+    {
+      size_t n_chunks = (size_t)p->W * p->T;
+      k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                   p->L, (X*)p->d_A, (X*)p->d_W0);
+      constexpr int RB = sizeof(X) <= 192 ? 256 : 128;  // 48 KB of LDS per block
+      k_masked_sums<F, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), RB * sizeof(X), st>>>(
+          (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+    }
+    if (prof) HIPCHK(hipEventRecord(p->ev[4], st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->W * p->nsel * sizeof(X), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    auto t0 = std::chrono::steady_clock::now();
+    host_tail<F>(p, total);
+    A r;
+    xyzz_to_affine<F>(r, total);
+    memcpy(out_affine, &r, sizeof(A));
+    if (out_xyzz) memcpy(out_xyzz, &total, sizeof(X));
+    if (prof) {
+      for (int i = 0; i < 4; i++) HIPCHK(hipEventElapsedTime(&p->ms[i], p->ev[i], p->ev[i + 1]));
+      HIPCHK(hipEventElapsedTime(&p->ms[4], p->ev[0], p->ev[4]));
+      p->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+  }
+  A r;
+  xyzz_to_affine<F>(r, total);
+  memcpy(out_affine, &r, sizeof(A));
+  if (out_xyzz) memcpy(out_xyzz, &total, sizeof(X));
+  return 0;
+}
+
+
+}  // namespace mlhip

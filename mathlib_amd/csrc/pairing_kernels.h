@@ -1,0 +1,103 @@
+// pairing_kernels.h -- batched pairing kernels (one pairing per lane; Fp12 state lives in scratch).
+// Included by tu_pairing_<curve>.hip.  Replaces MillerLoop / FinalExponentiation behind the reference's
+// Pairing, Pairing2 and FExp (driver/gurvy/bls12381/bls12-381.go:448-468, bn254.go:247-267, bls12-377.go:244-264).
+#pragma once
+#include "mlhip_internal.h"
+#include "pairing.h"
+
+namespace mlhip {
+
+template <class C>
+__global__ void __launch_bounds__(64) k_miller(const Affine<FpField<C>>* __restrict__ g1,
+                                               const Affine<Fp2Field<C>>* __restrict__ g2, int ppp, size_t n,
+                                               Fp12<C>* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp12<C> f;
+  miller_loop<C, 4>(f, g1 + i * ppp, g2 + i * ppp, ppp);
+  out[i] = f;
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) k_final_exp(const Fp12<C>* __restrict__ in, size_t n, Fp12<C>* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp12<C> f = in[i], r;
+  final_exp<C>(r, f);
+  out[i] = r;
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) k_pairing(const Affine<FpField<C>>* __restrict__ g1,
+                                                const Affine<Fp2Field<C>>* __restrict__ g2, size_t n,
+                                                Fp12<C>* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp12<C> f, r;
+  miller_loop<C, 1>(f, g1 + i, g2 + i, 1);
+  final_exp<C>(r, f);
+  out[i] = r;
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_fp_mul(const Fp<C>* __restrict__ a, const Fp<C>* __restrict__ b, size_t n,
+                                                int repeat, Fp<C>* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp<C> x = a[i], y = b[i], r;
+  fp_mul<C>(r, x, y);
+  for (int k = 1; k < repeat; k++) fp_mul<C>(r, r, y);
+  out[i] = r;
+}
+
+template <class C>
+int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, size_t n, const void* d_in, void* d_out,
+                   hipStream_t st) {
+  if (n == 0) return 0;
+  unsigned blocks = (unsigned)((n + 63) / 64);
+  typedef Affine<FpField<C>> A1;
+  typedef Affine<Fp2Field<C>> A2;
+  switch (what) {
+    case 0:
+      k_miller<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, (Fp12<C>*)d_out);
+      break;
+    case 1:
+      k_final_exp<C><<<dim3(blocks), dim3(64), 0, st>>>((const Fp12<C>*)d_in, n, (Fp12<C>*)d_out);
+      break;
+    default:
+      k_pairing<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, (Fp12<C>*)d_out);
+      break;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+
+// out[i] = a[i] * b[i] in Fp12 (Gt.Mul, reference driver/gurvy/bls12381/bls12-381.go:417-419)
+template <class C>
+__global__ void __launch_bounds__(64) k_gt_mul(const Fp12<C>* __restrict__ a, const Fp12<C>* __restrict__ b, size_t n,
+                                               Fp12<C>* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp12<C> x = a[i], y = b[i], r;
+  fp12_mul<C>(r, x, y);
+  out[i] = r;
+}
+
+template <class C>
+int gt_mul_device(const void* d_a, const void* d_b, size_t n, void* d_out, hipStream_t st) {
+  k_gt_mul<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_a, (const Fp12<C>*)d_b, n,
+                                                                 (Fp12<C>*)d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <class C>
+int fp_mul_device(const void* d_a, const void* d_b, size_t n, int repeat, void* d_out, hipStream_t st) {
+  k_fp_mul<C><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const Fp<C>*)d_a, (const Fp<C>*)d_b, n, repeat,
+                                                                    (Fp<C>*)d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mlhip

@@ -4,7 +4,9 @@
 // and nothing in the product path links or loads it.
 #include <stdint.h>
 #include <string.h>
+#include <vector>
 #include "../../mathlib_amd/csrc/pairing.h"
+#include "../../mathlib_amd/csrc/msm_body.h"
 
 using namespace mlhip;
 
@@ -129,6 +131,28 @@ struct Ops {
     delete[] v;
     return 0;
   }
+  // window digits of one scalar, exactly as k_digits computes them (n = 1 layout: digits[w])
+  static int digits(const void* scalar, int mont, int c, uint32_t* out, int cap) {
+    int W = msm_num_windows(C::FR_BITS, c);
+    if (W > cap) return -3;
+    msm_digits_body<C>(0, 1, (const uint32_t*)scalar, mont != 0, c, W, out);
+    return W;
+  }
+  // level-1 bucket reduction body over an array of n_chunks*L affine "buckets"; returns A and W0 as affine
+  static int chunks(const void* pts, int n_chunks, void* outA, void* outW0) {
+    const A1* p = (const A1*)pts;
+    std::vector<X1> b(n_chunks * 8), A(n_chunks), W0(n_chunks);
+    for (int i = 0; i < n_chunks * 8; i++) xyzz_from_affine<FpField<C>>(b[i], p[i]);
+    for (int g = 0; g < n_chunks; g++) msm_chunk_body<FpField<C>, 8>(g, b.data(), A.data(), W0.data(), 8);
+    for (int g = 0; g < n_chunks; g++) {
+      A1 r;
+      xyzz_to_affine<FpField<C>>(r, A[g]);
+      memcpy((char*)outA + g * sizeof(A1), &r, sizeof(A1));
+      xyzz_to_affine<FpField<C>>(r, W0[g]);
+      memcpy((char*)outW0 + g * sizeof(A1), &r, sizeof(A1));
+    }
+    return 0;
+  }
   static int miller(const void* g1s, const void* g2s, int n_pairs, void* out) {
     F12 f;
     miller_loop<C, 4>(f, (const A1*)g1s, (const A2*)g2s, n_pairs);
@@ -153,5 +177,7 @@ int hm_g1_sum(int curve, const void* pts, const uint8_t* neg, int n, void* out) 
 int hm_g2_sum(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, g2_sum(pts, neg, n, out)) }
 int hm_g1_tree(int curve, const void* pts, int n, void* out) { DISPATCH(curve, g1_tree(pts, n, out)) }
 int hm_g2_tree(int curve, const void* pts, int n, void* out) { DISPATCH(curve, g2_tree(pts, n, out)) }
+int hm_digits(int curve, const void* scalar, int mont, int c, uint32_t* out, int cap) { DISPATCH(curve, digits(scalar, mont, c, out, cap)) }
+int hm_chunks(int curve, const void* pts, int n_chunks, void* outA, void* outW0) { DISPATCH(curve, chunks(pts, n_chunks, outA, outW0)) }
 int hm_miller(int curve, const void* g1s, const void* g2s, int n_pairs, void* out) { DISPATCH(curve, miller(g1s, g2s, n_pairs, out)) }
 }

@@ -1,0 +1,269 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/mlhip.h), against the committed
+golden vectors (tests/golden, produced by oracle/pyref.py) -- bit-exact, this is integer work.
+Mirrors the reference's own checks: MSM == sum of scalar multiples (math_test.go:323-346),
+FExp(Pairing(..)) equalities (math_test.go:423-470), serialized-byte comparison (math_test.go:879-911).
+"""
+import ctypes
+
+import pytest
+
+from conftest import load_golden, load_msm1000
+
+pytestmark = pytest.mark.gpu
+
+CURVES = ["BN254", "BLS12-381", "BLS12-377"]
+
+
+def _h(s):
+    return bytes.fromhex(s)
+
+
+@pytest.fixture(scope="module")
+def lib(mlhip):
+    l = mlhip.load()
+    assert mlhip.device_count() >= 1, "no GPU visible: the product path has no CPU fallback"
+    return l
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_fp_mul_kernel_known_answers(lib, mlhip, curve):
+    import torch
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    a = b"".join(_h(c["a"]) for c in g["fp_mul"])
+    b = b"".join(_h(c["b"]) for c in g["fp_mul"])
+    exp = b"".join(_h(c["ab"]) for c in g["fp_mul"])
+    n = len(g["fp_mul"])
+    da = torch.frombuffer(bytearray(a), dtype=torch.uint8).cuda()
+    db = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+    out = torch.zeros(len(exp), dtype=torch.uint8, device="cuda")
+    mlhip.check(lib.mlhip_fp_mul_device(cid, da.data_ptr(), db.data_ptr(), n, 1, out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert bytes(out.cpu().numpy().tobytes()) == exp
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("window_c", [0, 4, 7, 12, 16])
+def test_msm_g1_golden_cases(lib, mlhip, curve, window_c):
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, g1b, _, _ = mlhip.sizes(cid)
+    for case in g["msm_g1"]:
+        pts = b"".join(_h(p) for p in case["points"])
+        scs = b"".join(_h(s) for s in case["scalars"])
+        out = ctypes.create_string_buffer(g1b)
+        mlhip.check(lib.mlhip_msm_g1(cid, pts, scs, 0, len(case["points"]), window_c, out))
+        assert out.raw == _h(case["expected"]), (curve, case["name"], window_c)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_g1_montgomery_scalars(lib, mlhip, curve):
+    """fr.Element (Montgomery) scalars, the form the gurvy BLS12-381 driver passes (bls12-381.go:772)."""
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    r = int(g["r"], 16)
+    _, g1b, _, _ = mlhip.sizes(cid)
+    case = next(c for c in g["msm_g1"] if c["name"] == "n10_random")
+    pts = b"".join(_h(p) for p in case["points"])
+    scs = b"".join((int(s) % r * (1 << 256) % r).to_bytes(32, "little") for s in case["scalars_int"])
+    out = ctypes.create_string_buffer(g1b)
+    mlhip.check(lib.mlhip_msm_g1(cid, pts, scs, 1, 10, 0, out))
+    assert out.raw == _h(case["expected"])
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_g1_empty(lib, mlhip, curve):
+    g = load_golden(curve)
+    _, g1b, _, _ = mlhip.sizes(g["curve_id"])
+    out = ctypes.create_string_buffer(b"\xff" * g1b, g1b)
+    mlhip.check(lib.mlhip_msm_g1(g["curve_id"], None, None, 0, 0, 0, out))
+    assert out.raw == bytes(g1b)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("window_c", [0, 10, 16])
+def test_msm_g1_1000_points(lib, mlhip, curve, window_c):
+    """BASELINE config 1 shape (1k-point G1 MSM), on every curve."""
+    g = load_golden(curve)
+    fpb, g1b, _, _ = mlhip.sizes(g["curve_id"])
+    pts, scs, exp = load_msm1000(curve, fpb)
+    out = ctypes.create_string_buffer(g1b)
+    mlhip.check(lib.mlhip_msm_g1(g["curve_id"], pts, scs, 0, 1000, window_c, out))
+    assert out.raw == exp
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("window_c", [0, 8, 16])
+def test_msm_g2_golden_cases(lib, mlhip, curve, window_c):
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, _, g2b, _ = mlhip.sizes(cid)
+    for case in g["msm_g2"]:
+        pts = b"".join(_h(p) for p in case["points"])
+        scs = b"".join(_h(s) for s in case["scalars"])
+        out = ctypes.create_string_buffer(g2b)
+        mlhip.check(lib.mlhip_msm_g2(cid, pts, scs, 0, len(case["points"]), window_c, out))
+        assert out.raw == _h(case["expected"]), (curve, case["name"], window_c)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_pairing_batch_golden(lib, mlhip, curve):
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, _, _, gtb = mlhip.sizes(cid)
+    n = len(g["pairing"])
+    g1 = b"".join(_h(c["g1"]) for c in g["pairing"])
+    g2 = b"".join(_h(c["g2"]) for c in g["pairing"])
+    out = ctypes.create_string_buffer(gtb * n)
+    mlhip.check(lib.mlhip_pairing_batch(cid, g1, g2, n, out))
+    for i, c in enumerate(g["pairing"]):
+        assert out.raw[i * gtb : (i + 1) * gtb] == _h(c["fexp"]), (curve, i)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_miller_then_fexp_and_pairing2(lib, mlhip, curve):
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, _, _, gtb = mlhip.sizes(cid)
+    # Pairing then FExp == golden (raw Miller values are not canonical, only the FExp output is)
+    c = g["pairing"][1]
+    ml = ctypes.create_string_buffer(gtb)
+    fe = ctypes.create_string_buffer(gtb)
+    mlhip.check(lib.mlhip_miller_loop(cid, _h(c["g1"]), _h(c["g2"]), 1, 1, ml))
+    mlhip.check(lib.mlhip_final_exp(cid, ml.raw, 1, fe))
+    assert fe.raw == _h(c["fexp"])
+    # Pairing2: shared Miller loop over two pairs
+    p2 = g["pairing2"]
+    mlhip.check(lib.mlhip_miller_loop(cid, b"".join(_h(x) for x in p2["g1"]), b"".join(_h(x) for x in p2["g2"]), 2, 1, ml))
+    mlhip.check(lib.mlhip_final_exp(cid, ml.raw, 1, fe))
+    assert fe.raw == _h(p2["fexp"])
+    # FExp on the oracle's raw Miller value
+    io = g["fexp_io"]
+    mlhip.check(lib.mlhip_final_exp(cid, _h(io["input"]), 1, fe))
+    assert fe.raw == _h(io["output"])
+    # bilinearity vector: e([a]G1, [b]G2) == e(G1,G2)^(ab)
+    bl = g["bilinear"]
+    mlhip.check(lib.mlhip_pairing_batch(cid, _h(bl["g1"]), _h(bl["g2"]), 1, fe))
+    assert fe.raw == _h(bl["fexp"])
+    # a pair holding infinity contributes one
+    fpb, g1b, g2b, _ = mlhip.sizes(cid)
+    mlhip.check(lib.mlhip_miller_loop(cid, bytes(g1b), _h(c["g2"]), 1, 1, ml))
+    one = _h(g["fp_mul"][0]["a"])  # placeholder to get length
+    assert ml.raw[fpb:] == bytes(gtb - fpb) and any(ml.raw[:fpb])
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_gt_mul_matches_pairing2(lib, mlhip, curve):
+    """Pairing2 == Pairing * Pairing after FExp (math_test.go:436-446)."""
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, _, _, gtb = mlhip.sizes(cid)
+    a, b = g["pairing"][1], g["pairing"][2]
+    out = ctypes.create_string_buffer(gtb)
+    mlhip.check(lib.mlhip_gt_mul(cid, _h(a["fexp"]), _h(b["fexp"]), 1, out))
+    assert out.raw == _h(g["pairing2"]["fexp"])
+
+
+# ---------------------------------------------------------------------------------------------
+# mid-size parity against the C restatement (oracle/cref, itself pinned to the golden vectors)
+# ---------------------------------------------------------------------------------------------
+def _rand_scalars(n, seed, bits=254):
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    top = bits - 192
+    sc[:, 3] &= np.uint64((1 << top) - 1)
+    return sc
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("n,window_c", [(3000, 0), (1 << 14, 13), (1 << 14, 16)])
+def test_msm_g1_random_vs_cref(lib, mlhip, curve, n, window_c):
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, g1b, _, _ = mlhip.sizes(cid)
+    pts = cref.gen_points(cid, 1, 0x1234567 + n, 0x89ABCDEF01, n)
+    sc = _rand_scalars(n, n + cid, 252)
+    exp = cref.msm(cid, 1, pts, sc, n, False, 0, 8)
+    out = ctypes.create_string_buffer(g1b)
+    mlhip.check(lib.mlhip_msm_g1(cid, pts, sc.tobytes(), 0, n, window_c, out))
+    assert out.raw == exp
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_g2_random_vs_cref(lib, mlhip, curve):
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, _, g2b, _ = mlhip.sizes(cid)
+    n = 5000
+    pts = cref.gen_points(cid, 2, 77777, 31337, n)
+    sc = _rand_scalars(n, 99 + cid, 252)
+    exp = cref.msm(cid, 2, pts, sc, n, False, 0, 8)
+    out = ctypes.create_string_buffer(g2b)
+    mlhip.check(lib.mlhip_msm_g2(cid, pts, sc.tobytes(), 0, n, 12, out))
+    assert out.raw == exp
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_g1_skewed_distributions(lib, mlhip, curve):
+    """BASELINE.md section 3 extra distributions: small scalars, duplicated points, zero scalars, and one
+    hot bucket (all scalars equal) which exercises the workgroup-per-bucket path."""
+    import numpy as np
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, g1b, _, _ = mlhip.sizes(cid)
+    n = 6000
+    pts = bytearray(cref.gen_points(cid, 1, 424242, 1717, n))
+    for i in range(0, n, 100):  # 1 % duplicated points
+        pts[i * g1b : (i + 1) * g1b] = pts[:g1b]
+    for i in range(50, n, 1000):  # points at infinity
+        pts[i * g1b : (i + 1) * g1b] = bytes(g1b)
+    pts = bytes(pts)
+    cases = {}
+    sc = _rand_scalars(n, 5, 252)
+    sc[:, 1:] = 0
+    sc[:, 0] &= np.uint64(0xFFFFFFFF)
+    cases["lt_2_32"] = sc
+    sc = _rand_scalars(n, 6, 252)
+    sc[::7] = 0
+    cases["zeros"] = sc
+    sc = np.tile(_rand_scalars(1, 7, 252), (n, 1))
+    cases["all_equal"] = sc
+    for name, sc in cases.items():
+        exp = cref.msm(cid, 1, pts, sc, n, False, 0, 8)
+        for c in (8, 16):
+            out = ctypes.create_string_buffer(g1b)
+            mlhip.check(lib.mlhip_msm_g1(cid, pts, sc.tobytes(), 0, n, c, out))
+            assert out.raw == exp, (curve, name, c)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_pairing_batch_random_vs_cref(lib, mlhip, curve):
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    fpb, g1b, g2b, gtb = mlhip.sizes(cid)
+    n = 200
+    g1 = bytearray(cref.gen_points(cid, 1, 5555, 77, n))
+    g2 = bytearray(cref.gen_points(cid, 2, 6666, 99, n))
+    g1[3 * g1b : 4 * g1b] = bytes(g1b)  # pairs holding infinity -> 1
+    g2[9 * g2b : 10 * g2b] = bytes(g2b)
+    exp = cref.pairing_batch(cid, bytes(g1), bytes(g2), n, 8)
+    out = ctypes.create_string_buffer(gtb * n)
+    mlhip.check(lib.mlhip_pairing_batch(cid, bytes(g1), bytes(g2), n, out))
+    assert out.raw == exp
+    # Miller loop with 3 pairs per product, compared after FExp
+    ml = ctypes.create_string_buffer(gtb * 60)
+    mlhip.check(lib.mlhip_miller_loop(cid, bytes(g1[: 180 * g1b]), bytes(g2[: 180 * g2b]), 3, 60, ml))
+    fe = ctypes.create_string_buffer(gtb * 60)
+    mlhip.check(lib.mlhip_final_exp(cid, ml.raw, 60, fe))
+    assert fe.raw == cref.final_exp(cid, cref.miller_loop(cid, bytes(g1), bytes(g2), 3, 60, 8), 60, 8)
