@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its configs[1]: BLS12-381 2^20-point G1 MSM (Pippenger, c = 16)
+per MI355X, with the batched-pairing rate reported beside it.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one MSM over the rank's resident (point, scalar) shard: kernels, D2H of the window sums,
+host Horner tail, and for N > 1 the all-gather of the per-rank partial sums over RCCL plus the local
+EC addition.  Points and scalars are in HBM before the timed region starts.  Weak scaling: every rank
+holds 2^20 pairs, `value` = N * 2^20 * K / (max over ranks of the K-step time).
+
+Inputs are synthetic and produced by the product itself: P_i = [k_i]G from the batched scalar-mul
+kernel, k_i and the MSM scalars from torch's generator (seeded per rank).  The oracle (oracle/cref) is
+used ONLY for the `cpu_baseline` leg: the same workload timed on the host cores of rank 0 at N = 1.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mathlib_amd import _lib, dist as mdist  # noqa: E402
+from mathlib_amd.driver import Curve  # noqa: E402
+
+CURVE = _lib.CURVE_BLS12_381
+N_PER_GPU = 1 << 20
+WINDOW_C = 16
+N_PAIRINGS = 1 << 16
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MSM_BYTES_PER_UNIT = 128  # 96 B affine point + 32 B scalar
+PAIRING_BYTES_PER_UNIT = 864  # 96 + 192 in, 576 out
+INT_MAC_PEAK = 3.19e13  # measured v_mad_u64_u32 lane-ops/s, profiles/r01_ubench_int.txt
+MACS_PER_FP_MUL = 288  # 2 * 12^2 32x32->64 multiply-accumulates per 384-bit Montgomery product
+
+
+def rand_scalars(n: int, gen: torch.Generator, device) -> torch.Tensor:
+    """n x 32 bytes: uniform 256-bit integers (the device reduces them mod r, as fr.SetBigInt does)"""
+    lo = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, generator=gen, device=device)
+    return lo.view(torch.uint8).reshape(n, 32).contiguous()
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pairing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = _lib.load()
+    _lib.check(lib.mlhip_set_device(local_rank))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- synthetic inputs, resident in HBM
+    fpb, g1b, g2b, gtb = _lib.sizes(CURVE)
+    curve = Curve(CURVE)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x6D6C686970 + rank)
+    n = N_PER_GPU
+    k = rand_scalars(n, gen, dev)
+    base = torch.frombuffer(bytearray(curve.GenG1().raw), dtype=torch.uint8).to(dev)
+    points = torch.empty(n * g1b, dtype=torch.uint8, device=dev)
+    _lib.check(lib.mlhip_scalar_mul_device(CURVE, _lib.GROUP_G1, base.data_ptr(), 0, k.data_ptr(), 0, n, points.data_ptr(), stream))
+    scalars = rand_scalars(n, gen, dev)
+    torch.cuda.synchronize()
+
+    plan = _lib.MsmPlan(CURVE, _lib.GROUP_G1, n, WINDOW_C)
+    plan.set_profiling(True)
+
+    def step() -> bytes:
+        part = plan.run(points.data_ptr(), scalars.data_ptr(), n, False, stream)
+        return mdist.combine_partials(CURVE, _lib.GROUP_G1, part, dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    phase = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        for kname, v in plan.timings().items():
+            phase[kname] = phase.get(kname, 0.0) + v
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps = max(args.steps, 1)
+    phase = {kname: v / steps for kname, v in phase.items()}
+    value = world * n * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (k_accumulate): algorithmic bytes / its HIP-event duration
+    acc_ms = phase.get("accumulate", 0.0)
+    achieved = (MSM_BYTES_PER_UNIT * n) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm",
+        "kernel": "k_accumulate<FpField<Bls381>>",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "avg_kernel_ms": acc_ms,
+        "phase_ms": phase,
+        # the path is integer-ALU bound, not HBM bound: ~10 Fp multiplications per mixed addition,
+        # W = 16 additions per scalar => fraction of the measured v_mad_u64_u32 issue peak
+        "int_alu": {
+            "fp_mul_per_s": (n * 16 * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
+            "mac_frac_of_measured_peak": ((n * 16 * 10 * MACS_PER_FP_MUL) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
+        },
+    }
+
+    extra = {}
+    # ---- batched pairing (BASELINE configs[2]): 65 536 x (Miller loop + final exponentiation)
+    if not args.no_pairing:
+        npair = N_PAIRINGS
+        g2base = torch.frombuffer(bytearray(curve.GenG2().raw), dtype=torch.uint8).to(dev)
+        q = torch.empty(npair * g2b, dtype=torch.uint8, device=dev)
+        _lib.check(lib.mlhip_scalar_mul_device(CURVE, _lib.GROUP_G2, g2base.data_ptr(), 0, scalars.data_ptr(), 0, npair, q.data_ptr(), stream))
+        gt = torch.empty(npair * gtb, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = None
+        for _ in range(3):
+            ev0.record()
+            _lib.check(lib.mlhip_pairing_batch_device(CURVE, points.data_ptr(), q.data_ptr(), npair, gt.data_ptr(), stream))
+            ev1.record()
+            torch.cuda.synchronize()
+            ms = ev0.elapsed_time(ev1)
+            best = ms if best is None or ms < best else best
+        extra["pairings_per_s_per_gpu"] = npair / (best * 1e-3)
+        extra["pairing_batch"] = npair
+        extra["pairing_kernel_ms"] = best
+        extra["pairing_roofline"] = {
+            "bound": "hbm",
+            "achieved": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        }
+
+    # ---- CPU baseline: the oracle's C restatement on the same workload, host cores of this box
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cref  # checker / baseline only
+
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = max(1, min(cores, 64))
+        hp = points.cpu().numpy()
+        hs = scalars.cpu().numpy()
+        t1 = time.perf_counter()
+        ref = cref.msm(CURVE, 1, hp, hs, n, False, WINDOW_C, threads)
+        dt = time.perf_counter() - t1
+        cpu_baseline = {
+            "value": n / dt,
+            "unit": "scalar-muls/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": "the full 2^20-point workload (same points and scalars), oracle/cref Pippenger c=16, %d pthreads, %.2f s" % (threads, dt),
+            "matches_gpu_result": bool(ref == res),
+        }
+        if not args.no_pairing:
+            ns = 512
+            t1 = time.perf_counter()
+            cref.pairing_batch(CURVE, hp[: ns * g1b], q[: ns * g2b].cpu().numpy(), ns, threads)
+            dtp = time.perf_counter() - t1
+            cpu_baseline["pairings_per_s"] = ns / dtp
+            cpu_baseline["pairing_sample"] = "%d of the 65 536 pairs, %d pthreads, %.2f s" % (ns, threads, dtp)
+
+    if rank == 0:
+        line = {
+            "metric": "G1 scalar-muls/sec (BLS12-381 2^20-point MSM per GPU), pairings/sec reported in extra",
+            "value": value,
+            "unit": "scalar-muls/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BLS12-381 2^20-point G1 MSM per GPU, Pippenger c=16 (BASELINE configs[1]); inputs resident in HBM",
+                "curve": "BLS12-381",
+                "points_per_gpu": n,
+                "window_c": WINDOW_C,
+                "parallelism": "pairs sharded contiguously across ranks; one all-gather of 96-byte partial sums over RCCL + local EC add",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "extra": extra,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,15 @@ int mlhip_pairing_batch_device(int curve, const void* d_g1, const void* d_g2, si
                                void* stream);
 int mlhip_gt_mul_device(int curve, const void* d_a_gt, const void* d_b_gt, size_t n, void* d_out_gt, void* stream);
 
+/* out[i] = [scalars[i]] points[i * point_stride]: batched single-scalar multiplication (G1.Mul / G2.Mul,
+ * driver/gurvy/bls12381/bls12-381.go:238-247, :342-351).  point_stride = 0 multiplies one base point by
+ * every scalar (how the synthetic benchmark inputs [k_i]G are produced).  Device pointers. */
+int mlhip_scalar_mul_device(int curve, int group, const void* d_points, size_t point_stride, const void* d_scalars,
+                            int scalars_mont, size_t n, void* d_out_affine, void* stream);
+/* host-buffer form */
+int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stride, const void* scalars,
+                     int scalars_mont, size_t n, void* out_affine);
+
 /* ---- group helpers (host, O(n) tiny): combine per-GPU partial results after the RCCL all-gather */
 int mlhip_g1_sum(int curve, const void* affine_points, size_t n, void* out_affine);
 int mlhip_g2_sum(int curve, const void* affine_points, size_t n, void* out_affine);

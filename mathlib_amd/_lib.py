@@ -38,6 +38,8 @@ SYMBOLS = [
     "mlhip_final_exp_device",
     "mlhip_pairing_batch_device",
     "mlhip_gt_mul_device",
+    "mlhip_scalar_mul_device",
+    "mlhip_scalar_mul",
     "mlhip_g1_sum",
     "mlhip_g2_sum",
     "mlhip_fp_mul_device",
@@ -92,6 +94,8 @@ def load() -> ctypes.CDLL:
     lib.mlhip_final_exp_device.argtypes = [ci, vp, sz, vp, vp]
     lib.mlhip_pairing_batch_device.argtypes = [ci, vp, vp, sz, vp, vp]
     lib.mlhip_gt_mul_device.argtypes = [ci, vp, vp, sz, vp, vp]
+    lib.mlhip_scalar_mul_device.argtypes = [ci, ci, vp, sz, vp, ci, sz, vp, vp]
+    lib.mlhip_scalar_mul.argtypes = [ci, ci, vp, sz, vp, ci, sz, vp]
     lib.mlhip_g1_sum.argtypes = [ci, vp, sz, vp]
     lib.mlhip_g2_sum.argtypes = [ci, vp, sz, vp]
     lib.mlhip_fp_mul_device.argtypes = [ci, vp, vp, sz, ci, vp, vp]

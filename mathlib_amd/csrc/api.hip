@@ -346,6 +346,47 @@ int mlhip_gt_mul(int curve, const void* a, const void* b, size_t n, void* out) {
   return rc;
 }
 
+int mlhip_scalar_mul_device(int curve, int group, const void* d_points, size_t point_stride, const void* d_scalars,
+                            int mont, size_t n, void* d_out, void* stream) {
+  if (group != MLHIP_GROUP_G1 && group != MLHIP_GROUP_G2) return mlhip_rt::fail(MLHIP_EINVAL, "group must be 1 or 2");
+  if (point_stride > 1) return mlhip_rt::fail(MLHIP_EINVAL, "point_stride must be 0 or 1");
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (curve) {
+    case MLHIP_CURVE_BN254: return mlhip_tu_scalar_mul_Bn254(group, d_points, point_stride, d_scalars, mont, n, d_out, st);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_scalar_mul_Bls381(group, d_points, point_stride, d_scalars, mont, n, d_out, st);
+    case MLHIP_CURVE_BLS12_377: return mlhip_tu_scalar_mul_Bls377(group, d_points, point_stride, d_scalars, mont, n, d_out, st);
+    default: return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  }
+}
+
+int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stride, const void* scalars, int mont,
+                     size_t n, void* out) {
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (n == 0) return 0;
+  if (!points || !scalars || !out) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  int rc = ensure_device();
+  if (rc) return rc;
+  const size_t ptsz = group == MLHIP_GROUP_G1 ? sz.g1 : sz.g2;
+  const size_t npts = point_stride ? n : 1;
+  void *dp = nullptr, *ds = nullptr, *dout = nullptr;
+  do {
+    if (hipMalloc(&dp, npts * ptsz) != hipSuccess || hipMalloc(&ds, n * 32) != hipSuccess || hipMalloc(&dout, n * ptsz) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc failed"); break; }
+    if (hipMemcpy(dp, points, npts * ptsz, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(ds, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy H2D failed"); break; }
+    rc = mlhip_scalar_mul_device(curve, group, dp, point_stride, ds, mont, n, dout, nullptr);
+    if (rc) break;
+    hipError_t e = hipMemcpy(out, dout, n * ptsz, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e)); break; }
+  } while (0);
+  if (dp) (void)hipFree(dp);
+  if (ds) (void)hipFree(ds);
+  if (dout) (void)hipFree(dout);
+  return rc;
+}
+
 int mlhip_g1_sum(int curve, const void* pts, size_t n, void* out) {
   if (!out || (n && !pts)) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
   switch (curve) {

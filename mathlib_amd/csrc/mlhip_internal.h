@@ -41,7 +41,9 @@ struct mlhip_msm_plan {
   int mlhip_tu_pairing_##NAME(int what, const void* d_g1, const void* d_g2, size_t ppp, size_t n, const void* d_in, \
                               void* d_out, hipStream_t st);                                                         \
   int mlhip_tu_fp_mul_##NAME(const void* d_a, const void* d_b, size_t n, int repeat, void* d_out, hipStream_t st);   \
-  int mlhip_tu_gt_mul_##NAME(const void* d_a, const void* d_b, size_t n, void* d_out, hipStream_t st);
+  int mlhip_tu_gt_mul_##NAME(const void* d_a, const void* d_b, size_t n, void* d_out, hipStream_t st);             \
+  int mlhip_tu_scalar_mul_##NAME(int group, const void* d_points, size_t point_stride, const void* d_scalars,     \
+                                 int mont, size_t n, void* d_out, hipStream_t st);
 MLHIP_DECLARE_CURVE(Bn254)
 MLHIP_DECLARE_CURVE(Bls381)
 MLHIP_DECLARE_CURVE(Bls377)

@@ -10,3 +10,9 @@ int mlhip_tu_plan_run_Bls377(mlhip_msm_plan* p, const void* d_points, const void
     return plan_run<Bls377, FpField<Bls377>>(p, d_points, d_scalars, mont, n, st, out_affine, out_xyzz);
   return plan_run<Bls377, Fp2Field<Bls377>>(p, d_points, d_scalars, mont, n, st, out_affine, out_xyzz);
 }
+int mlhip_tu_scalar_mul_Bls377(int group, const void* d_points, size_t point_stride, const void* d_scalars, int mont,
+                              size_t n, void* d_out, hipStream_t st) {
+  if (group == MLHIP_GROUP_G1)
+    return scalar_mul_device<Bls377, FpField<Bls377>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
+  return scalar_mul_device<Bls377, Fp2Field<Bls377>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
+}

@@ -10,3 +10,9 @@ int mlhip_tu_plan_run_Bn254(mlhip_msm_plan* p, const void* d_points, const void*
     return plan_run<Bn254, FpField<Bn254>>(p, d_points, d_scalars, mont, n, st, out_affine, out_xyzz);
   return plan_run<Bn254, Fp2Field<Bn254>>(p, d_points, d_scalars, mont, n, st, out_affine, out_xyzz);
 }
+int mlhip_tu_scalar_mul_Bn254(int group, const void* d_points, size_t point_stride, const void* d_scalars, int mont,
+                              size_t n, void* d_out, hipStream_t st) {
+  if (group == MLHIP_GROUP_G1)
+    return scalar_mul_device<Bn254, FpField<Bn254>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
+  return scalar_mul_device<Bn254, Fp2Field<Bn254>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
+}
