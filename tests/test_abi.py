@@ -1,0 +1,117 @@
+"""The C-ABI library loads and exports every symbol include/mlhip.h declares; without a GPU every
+compute entry point fails loudly (no CPU fallback); host-only helpers work."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mlhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mlhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(mlhip):
+    lib = mlhip.load()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), "libmlhip.so does not export %s" % name
+    assert sorted(mlhip.SYMBOLS) == names, "mathlib_amd/_lib.py SYMBOLS out of sync with include/mlhip.h"
+    assert lib.mlhip_version() >= 100
+
+
+def test_sizes_follow_the_reference_layout(mlhip):
+    # Fp = [4]uint64 (BN254) / [6]uint64 (BLS12-381, -377): driver/kilic/custom.go:24, driver/gurvy/custom.go:24-40
+    assert mlhip.sizes(mlhip.CURVE_BN254) == (32, 64, 128, 384)
+    assert mlhip.sizes(mlhip.CURVE_BLS12_381) == (48, 96, 192, 576)
+    assert mlhip.sizes(mlhip.CURVE_BLS12_377) == (48, 96, 192, 576)
+    with pytest.raises(mlhip.MlhipError):
+        mlhip.sizes(7)
+
+
+def test_argument_errors_are_reported(mlhip):
+    lib = mlhip.load()
+    out = ctypes.create_string_buffer(96)
+    assert lib.mlhip_msm_g1(9, b"x", b"y", 0, 1, 0, out) == -1
+    assert b"curve" in lib.mlhip_last_error()
+    assert lib.mlhip_miller_loop(1, b"x", b"y", 9, 1, out) == -1
+    h = ctypes.c_void_p()
+    assert lib.mlhip_msm_plan_create(1, 3, 10, 0, ctypes.byref(h)) == -1
+    assert lib.mlhip_msm_plan_create(1, 1, 10, 40, ctypes.byref(h)) == -1
+    assert lib.mlhip_msm_plan_create(1, 1, 0, 0, ctypes.byref(h)) == -1
+
+
+def test_no_gpu_means_failure_not_fallback(mlhip):
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present; the no-device path cannot be exercised")
+    lib = mlhip.load()
+    g = load_golden("BLS12-381")
+    case = g["msm_g1"][0]
+    out = ctypes.create_string_buffer(96)
+    rc = lib.mlhip_msm_g1(1, bytes.fromhex(case["points"][0]), bytes.fromhex(case["scalars"][0]), 0, 1, 0, out)
+    assert rc == mlhip.ENODEVICE and b"no HIP device" in lib.mlhip_last_error()
+    gt = ctypes.create_string_buffer(576)
+    c = g["pairing"][0]
+    assert lib.mlhip_pairing_batch(1, bytes.fromhex(c["g1"]), bytes.fromhex(c["g2"]), 1, gt) == mlhip.ENODEVICE
+    assert lib.mlhip_final_exp(1, bytes(576), 1, gt) == mlhip.ENODEVICE
+    from mathlib_amd.driver import Curve
+
+    cv = Curve(mlhip.CURVE_BLS12_381)
+    with pytest.raises(mlhip.MlhipError):
+        cv.MultiScalarMul([cv.GenG1()], [cv.NewZrFromInt(5)])
+
+
+def test_host_group_helper_matches_oracle(mlhip):
+    """mlhip_g1_sum / mlhip_g2_sum (the post-all-gather combine) need no GPU"""
+    from oracle import pyref as R
+
+    lib = mlhip.load()
+    for name in ("BN254", "BLS12-381", "BLS12-377"):
+        cp = R.CURVES[name]
+        d = R.Drbg("abi/sum/" + name)
+        pts = [R.random_g1(cp, d) for _ in range(5)] + [None]
+        pts.append(R.g1_neg(cp, pts[0]))
+        exp = None
+        for p in pts:
+            exp = R.g1_add(cp, exp, p)
+        out = ctypes.create_string_buffer(2 * cp.fp_bytes)
+        mlhip.check(lib.mlhip_g1_sum(cp.curve_id, b"".join(R.g1_to_mont_bytes(cp, p) for p in pts), len(pts), out))
+        assert R.g1_from_mont_bytes(cp, out.raw) == exp
+        qs = [R.random_g2(cp, d) for _ in range(3)]
+        exp = None
+        for q in qs:
+            exp = R.g2_add(cp, exp, q)
+        out = ctypes.create_string_buffer(4 * cp.fp_bytes)
+        mlhip.check(lib.mlhip_g2_sum(cp.curve_id, b"".join(R.g2_to_mont_bytes(cp, q) for q in qs), len(qs), out))
+        assert R.g2_from_mont_bytes(cp, out.raw) == exp
+
+
+def test_driver_mirror_host_logic(mlhip):
+    """serialisation / Zr semantics of the host mirror (no GPU): generator strings of math_test.go:250-259"""
+    from mathlib_amd.driver import Curve
+    from oracle import pyref as R
+
+    for cid, name in ((0, "BN254"), (1, "BLS12-381"), (2, "BLS12-377")):
+        cv = Curve(cid)
+        cp = R.CURVES[name]
+        g = cv.GenG1()
+        assert g.String() == "(%d,%d)" % cp.g1
+        assert g.Bytes() == R.g1_wire_uncompressed(cp, cp.g1)
+        assert g.Compressed() == R.g1_wire_compressed(cp, cp.g1)
+        assert cv.NewG1().Compressed() == R.g1_wire_compressed(cp, None)
+        n = g.Copy()
+        n.Neg()
+        assert n.coords() == R.g1_neg(cp, cp.g1)
+        a = cv.NewZrFromInt(-5)
+        assert a.Bytes() == ((-5) % cp.r).to_bytes(32, "big")
+        assert a.le_bytes(True) == R.scalar_to_bytes(-5, cp, mont=True)
+        assert cv.GroupOrder.le_bytes() == bytes(32)  # r == 0 mod r
+        with pytest.raises(IndexError):
+            cv.MultiScalarMul([g, g], [a])

@@ -1,0 +1,101 @@
+"""Full-size checks at BASELINE.json's sizes through size-independent properties (plus, where the host has
+the cores for it, the C oracle on the whole input)."""
+import ctypes
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(mlhip, n, seed=1):
+    import torch
+
+    from mathlib_amd.driver import Curve
+
+    lib = mlhip.load()
+    cid = mlhip.CURVE_BLS12_381
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    k = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, generator=gen, device=dev).view(torch.uint8).reshape(n, 32)
+    s = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, generator=gen, device=dev).view(torch.uint8).reshape(n, 32)
+    base = torch.frombuffer(bytearray(Curve(cid).GenG1().raw), dtype=torch.uint8).to(dev)
+    pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    mlhip.check(lib.mlhip_scalar_mul_device(cid, 1, base.data_ptr(), 0, k.data_ptr(), 0, n, pts.data_ptr(), st))
+    torch.cuda.synchronize()
+    return lib, cid, pts, s, k, st
+
+
+def test_msm_2_20_c16_linearity_and_oracle(mlhip):
+    """BASELINE configs[1]: BLS12-381 2^20-point G1 MSM, c = 16.
+    (1) MSM(P, s) with P_i = [k_i]G equals [sum k_i s_i]G  (checked with one n=1 scalar mul);
+    (2) halves add up: MSM(P, s) == MSM(P[:h], s[:h]) + MSM(P[h:], s[h:]);
+    (3) the C oracle on the whole input (threads = host cores)."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from oracle import cref
+
+    n = 1 << 20
+    lib, cid, pts, s, k, st = _setup(mlhip, n)
+    plan = mlhip.MsmPlan(cid, 1, n, 16)
+    full = plan.run(pts.data_ptr(), s.data_ptr(), n, False, st)
+    h = n // 2 + 12345
+    a = plan.run(pts.data_ptr(), s.data_ptr(), h, False, st)
+    b = plan.run(pts.data_ptr() + h * 96, s.data_ptr() + h * 32, n - h, False, st)
+    out = ctypes.create_string_buffer(96)
+    mlhip.check(lib.mlhip_g1_sum(cid, a + b, 2, out))
+    assert out.raw == full
+    # (1): scalar sum over the integers mod r, then one scalar multiplication of the generator
+    r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    kk = k.cpu().numpy().view(np.uint64).reshape(n, 4)
+    ss = s.cpu().numpy().view(np.uint64).reshape(n, 4)
+    to_int = lambda row: int(row[0]) | int(row[1]) << 64 | int(row[2]) << 128 | int(row[3]) << 192  # noqa: E731
+    step = 4096  # exact big-int dot product in chunks
+    tot = 0
+    for lo in range(0, n, step):
+        tot += sum((to_int(kk[i]) % r) * (to_int(ss[i]) % r) for i in range(lo, min(n, lo + step)))
+    from mathlib_amd.driver import Curve
+
+    cv = Curve(cid)
+    assert cv.GenG1().Mul(cv.NewZrFromInt(tot % r)).raw == full
+    # (3)
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    assert cref.msm(cid, 1, pts.cpu().numpy(), ss, n, False, 16, threads) == full
+
+
+def test_pairing_batch_65536_properties(mlhip):
+    """BASELINE configs[2]: 65 536 pairings.  e([k]G1, Q)^1 checked through bilinearity on a strided sample
+    against the oracle, and the whole batch against a second run split in two (determinism / indexing)."""
+    import numpy as np
+    import torch
+
+    from oracle import cref
+
+    n = 1 << 16
+    lib, cid, pts, s, k, st = _setup(mlhip, n, seed=3)
+    from mathlib_amd.driver import Curve
+
+    g2 = torch.frombuffer(bytearray(Curve(cid).GenG2().raw), dtype=torch.uint8).cuda()
+    q = torch.empty(n * 192, dtype=torch.uint8, device="cuda")
+    mlhip.check(lib.mlhip_scalar_mul_device(cid, 2, g2.data_ptr(), 0, s.data_ptr(), 0, n, q.data_ptr(), st))
+    out = torch.empty(n * 576, dtype=torch.uint8, device="cuda")
+    mlhip.check(lib.mlhip_pairing_batch_device(cid, pts.data_ptr(), q.data_ptr(), n, out.data_ptr(), st))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    hp, hq = pts.cpu().numpy(), q.cpu().numpy()
+    idx = list(range(0, n, n // 32)) + [n - 1]
+    g1s = b"".join(hp[i * 96 : (i + 1) * 96].tobytes() for i in idx)
+    g2s = b"".join(hq[i * 192 : (i + 1) * 192].tobytes() for i in idx)
+    ref = cref.pairing_batch(cid, g1s, g2s, len(idx), 8)
+    for j, i in enumerate(idx):
+        assert o[i * 576 : (i + 1) * 576].tobytes() == ref[j * 576 : (j + 1) * 576], i
+    out2 = torch.empty_like(out)
+    h = n // 2 + 77
+    mlhip.check(lib.mlhip_pairing_batch_device(cid, pts.data_ptr(), q.data_ptr(), h, out2.data_ptr(), st))
+    mlhip.check(lib.mlhip_pairing_batch_device(cid, pts.data_ptr() + h * 96, q.data_ptr() + h * 192, n - h, out2.data_ptr() + h * 576, st))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)

@@ -1,0 +1,171 @@
+"""The kernels' __host__ __device__ math (mathlib_amd/csrc/*.h), compiled for the CPU with the 32-bit
+device code path forced (tests/hostmath), against oracle/pyref.py.  This is how the field / curve /
+pairing formulas and the per-thread MSM bodies are checked in the GPU-less container; the same
+functions then run inside the HIP kernels, which the -m gpu tests check through the C ABI."""
+import ctypes
+import random
+
+import pytest
+
+from oracle import pyref as R
+
+CURVES = ["BN254", "BLS12-381", "BLS12-377"]
+
+
+def fpb(cp, a):
+    return R.fp_to_mont_bytes(cp, a)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_fp_ops(hostmath, name):
+    cp = R.CURVES[name]
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("hm/fp/" + name)
+    pairs = [(d.below(cp.p), d.below(cp.p)) for _ in range(30)] + [(0, 0), (cp.p - 1, cp.p - 1), (0, cp.p - 1), (1, cp.p - 1), (2, (cp.p + 1) // 2)]
+    for a, b in pairs:
+        out = ctypes.create_string_buffer(n)
+        ops = [(0, a * b % cp.p), (1, (a + b) % cp.p), (2, (a - b) % cp.p), (3, (-a) % cp.p), (5, a * a % cp.p), (6, a * pow(2, -1, cp.p) % cp.p)]
+        if a:
+            ops.append((4, pow(a, -1, cp.p)))
+        for op, exp in ops:
+            assert L.hm_fp_op(cid, op, fpb(cp, a), fpb(cp, b), out) == 0
+            assert R.fp_from_mont_bytes(cp, out.raw) == exp, (name, op, a, b)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_fp12_tower(hostmath, name):
+    cp = R.CURVES[name]
+    T = R.tower(cp)
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("hm/f12/" + name)
+    rf = lambda: tuple((d.below(cp.p), d.below(cp.p)) for _ in range(6))  # noqa: E731
+    gb = lambda f: R.gt_to_mont_bytes(cp, f)  # noqa: E731
+    out = ctypes.create_string_buffer(12 * n)
+    for _ in range(2):
+        f, g = rf(), rf()
+        for op, exp in ((0, T.f12_mul(f, g)), (1, T.f12_sqr(f)), (2, T.f12_inv(f)), (3, T.f12_frob(f, 1)), (4, T.f12_frob(f, 2)), (5, T.f12_frob(f, 3)), (7, T.f12_conj(f))):
+            assert L.hm_fp12_op(cid, op, gb(f), gb(g), out) == 0
+            assert R.gt_from_mont_bytes(cp, out.raw) == exp, (name, op)
+        c = T.f12_mul(T.f12_conj(f), T.f12_inv(f))
+        c = T.f12_mul(T.f12_frob(c, 2), c)  # cyclotomic subgroup element
+        L.hm_fp12_op(cid, 6, gb(c), None, out)
+        assert R.gt_from_mont_bytes(cp, out.raw) == T.f12_sqr(c)
+        L.hm_fp12_op(cid, 8, gb(c), None, out)
+        assert R.gt_from_mont_bytes(cp, out.raw) == T.f12_pow(c, cp.x)
+        L.hm_fp12_op(cid, 9, gb(f), None, out)
+        assert R.gt_from_mont_bytes(cp, out.raw) == R.final_exp(cp, f)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_group_law_including_exceptional_cases(hostmath, name):
+    cp = R.CURVES[name]
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("hm/ec/" + name)
+    pts = [R.random_g1(cp, d) for _ in range(6)]
+    seq = pts + [None, pts[0], pts[1], R.g1_neg(cp, pts[1]), pts[0]]
+    buf = b"".join(R.g1_to_mont_bytes(cp, p) for p in seq)
+    out = ctypes.create_string_buffer(2 * n)
+    exp = None
+    for p in seq:
+        exp = R.g1_add(cp, exp, p)
+    L.hm_g1_sum(cid, buf, None, len(seq), out)
+    assert R.g1_from_mont_bytes(cp, out.raw) == exp
+    L.hm_g1_tree(cid, buf, len(seq), out)
+    assert R.g1_from_mont_bytes(cp, out.raw) == exp
+    neg = bytes(i & 1 for i in range(len(seq)))
+    exp = None
+    for i, p in enumerate(seq):
+        exp = R.g1_add(cp, exp, R.g1_neg(cp, p) if i & 1 else p)
+    L.hm_g1_sum(cid, buf, neg, len(seq), out)
+    assert R.g1_from_mont_bytes(cp, out.raw) == exp
+    two = R.g1_to_mont_bytes(cp, pts[0]) * 2
+    L.hm_g1_sum(cid, two, None, 2, out)
+    assert R.g1_from_mont_bytes(cp, out.raw) == R.g1_add(cp, pts[0], pts[0])
+    L.hm_g1_sum(cid, two, bytes([0, 1]), 2, out)
+    assert R.g1_from_mont_bytes(cp, out.raw) is None
+    L.hm_g1_tree(cid, two, 2, out)
+    assert R.g1_from_mont_bytes(cp, out.raw) == R.g1_add(cp, pts[0], pts[0])
+    qs = [R.random_g2(cp, d) for _ in range(3)]
+    seq2 = qs + [None, qs[0], R.g2_neg(cp, qs[1]), qs[1]]
+    buf = b"".join(R.g2_to_mont_bytes(cp, p) for p in seq2)
+    out2 = ctypes.create_string_buffer(4 * n)
+    exp = None
+    for p in seq2:
+        exp = R.g2_add(cp, exp, p)
+    L.hm_g2_sum(cid, buf, None, len(seq2), out2)
+    assert R.g2_from_mont_bytes(cp, out2.raw) == exp
+    L.hm_g2_tree(cid, buf, len(seq2), out2)
+    assert R.g2_from_mont_bytes(cp, out2.raw) == exp
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_miller_loop_and_final_exp(hostmath, name):
+    cp = R.CURVES[name]
+    T = R.tower(cp)
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("hm/pair/" + name)
+    P, P2 = R.random_g1(cp, d), R.random_g1(cp, d)
+    Q, Q2 = R.random_g2(cp, d), R.random_g2(cp, d)
+    ml = ctypes.create_string_buffer(12 * n)
+    fe = ctypes.create_string_buffer(12 * n)
+    L.hm_miller(cid, R.g1_to_mont_bytes(cp, P), R.g2_to_mont_bytes(cp, Q), 1, ml)
+    L.hm_fp12_op(cid, 9, ml.raw, None, fe)
+    assert R.gt_from_mont_bytes(cp, fe.raw) == R.pairing(cp, P, Q)
+    L.hm_miller(cid, R.g1_to_mont_bytes(cp, P) + R.g1_to_mont_bytes(cp, P2), R.g2_to_mont_bytes(cp, Q) + R.g2_to_mont_bytes(cp, Q2), 2, ml)
+    L.hm_fp12_op(cid, 9, ml.raw, None, fe)
+    assert R.gt_from_mont_bytes(cp, fe.raw) == T.f12_mul(R.pairing(cp, P, Q), R.pairing(cp, P2, Q2))
+    L.hm_miller(cid, R.g1_to_mont_bytes(cp, None), R.g2_to_mont_bytes(cp, Q), 1, ml)
+    assert R.gt_from_mont_bytes(cp, ml.raw) == T.f12_one
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_window_digits_reconstruct_the_scalar(hostmath, name):
+    """k_digits' body: sum_w d_w 2^(cw) == s mod r, |d_w| <= 2^(c-1), for plain and Montgomery inputs,
+    including the all-ones windows whose carry once produced a 'minus zero' digit."""
+    cp = R.CURVES[name]
+    L = hostmath
+    rnd = random.Random(1234)
+    for c in (4, 5, 7, 10, 12, 13, 16, 18, 20):
+        half = 1 << (c - 1)
+        cases = [0, 1, cp.r - 1, cp.r - 2, (1 << c) - 1, (1 << (2 * c)) - 1, (1 << 255) % cp.r, half, half + 1, 1 << c, ((1 << c) - 1) << c]
+        cases += [((1 << (c * k)) - 1) % cp.r for k in (3, 5, 9)] + [rnd.randrange(cp.r) for _ in range(100)]
+        for mont in (0, 1):
+            for s in cases:
+                enc = (s * (1 << 256) % cp.r) if mont else s
+                out = (ctypes.c_uint32 * 80)()
+                W = L.hm_digits(cp.curve_id, enc.to_bytes(32, "little"), mont, c, out, 80)
+                assert W == (cp.r.bit_length() + 1 + c - 1) // c
+                tot = 0
+                for w in range(W):
+                    dgt = out[w]
+                    if dgt:
+                        mag = dgt >> 1
+                        assert 1 <= mag <= half
+                        tot += (-mag if dgt & 1 else mag) << (c * w)
+                assert tot == s % cp.r, (name, c, s, mont)
+        for s in (cp.r, cp.r + 5, (1 << 256) - 1, 2 * cp.r + 3):  # BaseZr-style unreduced scalars
+            out = (ctypes.c_uint32 * 80)()
+            W = L.hm_digits(cp.curve_id, s.to_bytes(32, "little"), 0, c, out, 80)
+            assert sum(((-(out[w] >> 1) if out[w] & 1 else (out[w] >> 1)) << (c * w)) for w in range(W)) == s % cp.r
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_bucket_chunk_reduction_body(hostmath, name):
+    """k_chunks' body: A = sum of 8 buckets, W0 = sum_i i * bucket_i (with infinity buckets mixed in)"""
+    cp = R.CURVES[name]
+    L, n = hostmath, cp.fp_bytes
+    d = R.Drbg("hm/chunk/" + name)
+    nch = 3
+    pts = [R.random_g1(cp, d) if (i % 5) else None for i in range(8 * nch)]
+    pts[9] = pts[10]  # equal neighbours -> doubling branch
+    buf = b"".join(R.g1_to_mont_bytes(cp, p) for p in pts)
+    oa = ctypes.create_string_buffer(2 * n * nch)
+    ow = ctypes.create_string_buffer(2 * n * nch)
+    assert L.hm_chunks(cp.curve_id, buf, nch, oa, ow) == 0
+    for g in range(nch):
+        a = w = None
+        for i in range(8):
+            a = R.g1_add(cp, a, pts[8 * g + i])
+            w = R.g1_add(cp, w, R.g1_mul(cp, pts[8 * g + i], i) if pts[8 * g + i] is not None else None)
+        assert R.g1_from_mont_bytes(cp, oa.raw[g * 2 * n : (g + 1) * 2 * n]) == a
+        assert R.g1_from_mont_bytes(cp, ow.raw[g * 2 * n : (g + 1) * 2 * n]) == w
