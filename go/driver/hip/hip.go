@@ -1,0 +1,161 @@
+/*
+Package hip is the MI355X backend for the hot path of github.com/IBM/mathlib: it plugs in beside
+driver/amcl, driver/gurvy and driver/kilic behind the unchanged driver.Curve interface
+(driver/math.go:49-180) and overrides ONLY the data-parallel methods -- MultiScalarMul, Pairing,
+Pairing2, FExp -- with calls into libmlhip.so (C ABI: include/mlhip.h).  Everything else (the ~40
+remaining Curve methods, element arithmetic, serialization, hashing) is inherited bit-for-bit from the
+gurvy BLS12-381 driver by embedding, the way BBSCurve overrides four methods of Curve in
+driver/gurvy/bls12381/bls12-381.go:785-867.
+
+Memory is handed over with zero conversion: gnark-crypto's G1Affine / G2Affine / fr.Element / GT are
+plain arrays of little-endian uint64 limbs in Montgomery form, which is exactly the layout the kernels
+use (driver/gurvy/custom.go:24-40 proves the layout for fp.Element; init() below re-checks the sizes).
+
+NOTE: this file has never been compiled -- the build image has no Go toolchain (SURVEY.md, headline
+fact 3).  It is the binding a maintainer would add; INTEGRATION.md walks through it.  The same ABI is
+exercised by the Python mirror mathlib_amd/driver.py, which the test-suite runs on the GPU.
+
+Failure convention: like every reference driver this package panics on failure (there are no error
+returns in package driver; cf. driver/gurvy/bn254.go:249-251).  There is no CPU fallback: without a
+usable GPU the hot methods panic with the library's message; the inherited methods keep working, so
+registering the curve in math.Curves never needs a GPU (GenGt at package init uses the embedded
+driver: driver/gurvy/bls12381/bls12-381.go:490-497).
+*/
+package hip
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../../mathlib_amd -lmlhip -Wl,-rpath,${SRCDIR}/../../../mathlib_amd
+#include <stdlib.h>
+#include "mlhip.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"unsafe"
+
+	"github.com/IBM/mathlib/driver"
+	gurvy381 "github.com/IBM/mathlib/driver/gurvy/bls12381"
+	bls12381 "github.com/consensys/gnark-crypto/ecc/bls12-381"
+	"github.com/consensys/gnark-crypto/ecc/bls12-381/fr"
+)
+
+// WindowC is the Pippenger window (0 = chosen from n; BASELINE config 2 uses 16).
+var WindowC = 0
+
+func init() {
+	// the C ABI assumes gnark's in-memory layout; refuse to run if it ever changes
+	if unsafe.Sizeof(bls12381.G1Affine{}) != 96 || unsafe.Sizeof(bls12381.G2Affine{}) != 192 ||
+		unsafe.Sizeof(bls12381.GT{}) != 576 || unsafe.Sizeof(fr.Element{}) != 32 {
+		panic("hip: gnark-crypto element layout changed; libmlhip.so expects 96/192/576/32-byte elements")
+	}
+}
+
+func check(rc C.int) {
+	if rc != 0 {
+		panic(fmt.Sprintf("hip: libmlhip error %d: %s", int(rc), C.GoString(C.mlhip_last_error())))
+	}
+}
+
+// Curve is the gurvy BLS12-381 curve with its hot methods moved to the GPU.
+type Curve struct {
+	gurvy381.Curve
+}
+
+func NewCurve() *Curve { return &Curve{*gurvy381.NewCurve()} }
+
+// MultiScalarMul replaces driver/gurvy/bls12381/bls12-381.go:766-783 (gather + G1Jac.MultiExp +
+// FromJacobian).  The gather into contiguous arrays stays (the interface hands over boxed elements);
+// scalars are passed as fr.Element in Montgomery form, exactly what the gurvy driver feeds MultiExp.
+func (c *Curve) MultiScalarMul(a []driver.G1, b []driver.Zr) driver.G1 {
+	n := len(a)
+	points := make([]bls12381.G1Affine, n)
+	scalars := make([]fr.Element, len(b))
+	for i := range a {
+		points[i] = a[i].(*gurvy381.G1).G1Affine
+		scalars[i] = gurvy381.ZrValue(b[i]) // accessor for Zr.val (bls12-381.go:49-52); see INTEGRATION.md
+	}
+	out := &gurvy381.G1{}
+	if len(b) != n || n == 0 {
+		// gnark's MultiExp errors on a length mismatch and the driver drops the error: identity
+		return out
+	}
+	check(C.mlhip_msm_g1(C.MLHIP_CURVE_BLS12_381,
+		unsafe.Pointer(&points[0]), unsafe.Pointer(&scalars[0]), 1, C.size_t(n), C.int(WindowC),
+		unsafe.Pointer(&out.G1Affine)))
+	return out
+}
+
+// Pairing replaces bls12-381.go:448-455: Miller loop only, compare after FExp.
+func (c *Curve) Pairing(p2 driver.G2, p1 driver.G1) driver.Gt {
+	out := &gurvy381.Gt{}
+	check(C.mlhip_miller_loop(C.MLHIP_CURVE_BLS12_381,
+		unsafe.Pointer(&p1.(*gurvy381.G1).G1Affine), unsafe.Pointer(&p2.(*gurvy381.G2).G2Affine),
+		1, 1, unsafe.Pointer(&out.GT)))
+	return out
+}
+
+// Pairing2 replaces bls12-381.go:457-464 (one shared Miller loop over two pairs).
+func (c *Curve) Pairing2(p2a, p2b driver.G2, p1a, p1b driver.G1) driver.Gt {
+	g1 := [2]bls12381.G1Affine{p1a.(*gurvy381.G1).G1Affine, p1b.(*gurvy381.G1).G1Affine}
+	g2 := [2]bls12381.G2Affine{p2a.(*gurvy381.G2).G2Affine, p2b.(*gurvy381.G2).G2Affine}
+	out := &gurvy381.Gt{}
+	check(C.mlhip_miller_loop(C.MLHIP_CURVE_BLS12_381,
+		unsafe.Pointer(&g1[0]), unsafe.Pointer(&g2[0]), 2, 1, unsafe.Pointer(&out.GT)))
+	return out
+}
+
+// FExp replaces bls12-381.go:466-468.
+func (c *Curve) FExp(a driver.Gt) driver.Gt {
+	out := &gurvy381.Gt{}
+	check(C.mlhip_final_exp(C.MLHIP_CURVE_BLS12_381,
+		unsafe.Pointer(&a.(*gurvy381.Gt).GT), 1, unsafe.Pointer(&out.GT)))
+	return out
+}
+
+// ---- additive API (not in driver.Curve; needed by BASELINE configs 3 and 4) --------------------
+
+// MultiScalarMulG2 = sum of G2.Mul + Add (bls12-381.go:342-358) as one MSM.
+func (c *Curve) MultiScalarMulG2(a []driver.G2, b []driver.Zr) driver.G2 {
+	n := len(a)
+	points := make([]bls12381.G2Affine, n)
+	scalars := make([]fr.Element, len(b))
+	for i := range a {
+		points[i] = a[i].(*gurvy381.G2).G2Affine
+		scalars[i] = gurvy381.ZrValue(b[i])
+	}
+	out := &gurvy381.G2{}
+	if len(b) != n || n == 0 {
+		return out
+	}
+	check(C.mlhip_msm_g2(C.MLHIP_CURVE_BLS12_381,
+		unsafe.Pointer(&points[0]), unsafe.Pointer(&scalars[0]), 1, C.size_t(n), C.int(WindowC),
+		unsafe.Pointer(&out.G2Affine)))
+	return out
+}
+
+// PairingBatch returns FExp(Pairing(g2s[i], g1s[i])) for every i with one kernel launch.
+func (c *Curve) PairingBatch(g2s []driver.G2, g1s []driver.G1) []driver.Gt {
+	n := len(g1s)
+	if len(g2s) != n {
+		panic("hip: PairingBatch length mismatch")
+	}
+	if n == 0 {
+		return nil
+	}
+	p := make([]bls12381.G1Affine, n)
+	q := make([]bls12381.G2Affine, n)
+	for i := range g1s {
+		p[i] = g1s[i].(*gurvy381.G1).G1Affine
+		q[i] = g2s[i].(*gurvy381.G2).G2Affine
+	}
+	gts := make([]bls12381.GT, n)
+	check(C.mlhip_pairing_batch(C.MLHIP_CURVE_BLS12_381,
+		unsafe.Pointer(&p[0]), unsafe.Pointer(&q[0]), C.size_t(n), unsafe.Pointer(&gts[0])))
+	out := make([]driver.Gt, n)
+	for i := range gts {
+		out[i] = &gurvy381.Gt{GT: gts[i]}
+	}
+	return out
+}
