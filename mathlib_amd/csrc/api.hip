@@ -231,7 +231,8 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
 int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->device);
-  void* ptrs[] = {p->d_digits, p->d_sorted, p->d_zero, p->d_offsets, p->d_biglist, p->d_buckets, p->d_A, p->d_W0, p->d_out};
+  void* ptrs[] = {p->d_digits, p->d_sorted, p->d_zero, p->d_offsets, p->d_biglist, p->d_buckets, p->d_A, p->d_W0, p->d_out,
+                  p->d_order, p->d_hist, p->d_tilesums};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (p->h_out) (void)hipHostFree(p->h_out);

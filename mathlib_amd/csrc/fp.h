@@ -238,11 +238,27 @@ inline void fp_mul_host64(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
 }
 #endif
 
-// Out-of-line entry points: one copy of the ~1.2k-instruction multiply per kernel keeps the hot
-// loop inside the instruction cache (an inlined G1 mixed add would be >100 KB of code).
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 body: product-scanning Montgomery multiplication, one v_mad_u64_u32 + one v_addc_co_u32 per
+// limb product (generated: tools/gen_fp_comba.py).  Same result as fp_mul_inline, bit for bit
+// (checked on the GPU by tests/test_gpu_parity.py::test_fp_mul_kernel_* and everything built on it).
+#include "fp_mul_comba.inc"
+template <class C>
+__device__ __forceinline__ void fp_mul_device(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+  if constexpr (C::N == 12)
+    fp_mul_comba12<C>(r, a, b);
+  else
+    fp_mul_comba8<C>(r, a, b);
+}
+#endif
+
+// Out-of-line entry points: one copy of the multiply per kernel keeps the hot loop inside the
+// instruction cache (an inlined G1 mixed add would be >100 KB of code).
 template <class C>
 MLHIP_HD_NOINLINE void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
-#if defined(__HIP_DEVICE_COMPILE__) || defined(MLHIP_HOST_USE_DEVICE_PATH)
+#if defined(__HIP_DEVICE_COMPILE__)
+  fp_mul_device<C>(r, a, b);
+#elif defined(MLHIP_HOST_USE_DEVICE_PATH)
   fp_mul_inline<C>(r, a, b);
 #else
   fp_mul_host64<C>(r, a, b);
@@ -251,7 +267,9 @@ MLHIP_HD_NOINLINE void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
 
 template <class C>
 MLHIP_HD_NOINLINE void fp_sqr(Fp<C>& r, const Fp<C>& a) {
-#if defined(__HIP_DEVICE_COMPILE__) || defined(MLHIP_HOST_USE_DEVICE_PATH)
+#if defined(__HIP_DEVICE_COMPILE__)
+  fp_mul_device<C>(r, a, a);
+#elif defined(MLHIP_HOST_USE_DEVICE_PATH)
   fp_mul_inline<C>(r, a, a);
 #else
   fp_mul_host64<C>(r, a, a);

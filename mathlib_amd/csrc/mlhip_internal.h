@@ -23,6 +23,7 @@ struct mlhip_msm_plan {
   uint32_t M, T;
   size_t pt_size, xyzz_size;
   uint32_t *d_digits = nullptr, *d_sorted = nullptr, *d_zero = nullptr, *d_offsets = nullptr, *d_biglist = nullptr;
+  uint32_t *d_order = nullptr, *d_hist = nullptr, *d_tilesums = nullptr;
   uint32_t *d_counts = nullptr, *d_cursor = nullptr, *d_bigcount = nullptr;  // views into d_zero
   size_t zero_bytes = 0;
   void *d_buckets = nullptr, *d_A = nullptr, *d_W0 = nullptr, *d_out = nullptr;

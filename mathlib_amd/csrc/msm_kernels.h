@@ -11,6 +11,7 @@
 // Replaces gnark-crypto's MultiExp behind MultiScalarMul (reference
 // driver/gurvy/bls12381/bls12-381.go:766-783, driver/gurvy/bn254.go:232-245, driver/gurvy/bls12-377.go:229-242).
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <vector>
@@ -38,28 +39,107 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   }
 }
 
-static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                               size_t total) {
+// ---- exclusive scan of u32 counts: tile scan (1024 threads x 4) -> scan of tile sums -> add back
+constexpr int SCAN_TILE = 4096;
+
+static __global__ void __launch_bounds__(1024) k_scan_tile(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                            uint32_t* __restrict__ tile_sums, size_t total) {
   __shared__ uint32_t part[1024];
   const uint32_t tid = threadIdx.x;
-  size_t per = (total + 1023) / 1024;
-  size_t lo = (size_t)tid * per, hi = lo + per;
-  if (lo > total) lo = total;
-  if (hi > total) hi = total;
-  uint32_t s = 0;
-  for (size_t k = lo; k < hi; k++) s += counts[k];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)tid * 4;
+  uint32_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = base + k < total ? in[base + k] : 0u;
+  const uint32_t s = v[0] + v[1] + v[2] + v[3];
   part[tid] = s;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {
-    uint32_t v = tid >= off ? part[tid - off] : 0;
+    uint32_t x = tid >= off ? part[tid - off] : 0;
     __syncthreads();
-    part[tid] += v;
+    part[tid] += x;
     __syncthreads();
   }
-  uint32_t base = part[tid] - s;
+  uint32_t run = part[tid] - s;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (base + k < total) out[base + k] = run;
+    run += v[k];
+  }
+  if (tid == 1023) tile_sums[blockIdx.x] = part[1023];
+}
+
+// one block: exclusive scan of the tile sums in place (n_tiles <= a few thousand)
+static __global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* __restrict__ tile_sums, size_t n_tiles) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x;
+  size_t per = (n_tiles + 1023) / 1024;
+  size_t lo = (size_t)tid * per, hi = lo + per;
+  if (lo > n_tiles) lo = n_tiles;
+  if (hi > n_tiles) hi = n_tiles;
+  uint32_t s = 0;
+  for (size_t k = lo; k < hi; k++) s += tile_sums[k];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t x = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += x;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - s;
   for (size_t k = lo; k < hi; k++) {
-    offsets[k] = base;
-    base += counts[k];
+    uint32_t c = tile_sums[k];
+    tile_sums[k] = run;
+    run += c;
+  }
+}
+
+static __global__ void __launch_bounds__(1024) k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ tile_sums,
+                                                           size_t total) {
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 4;
+  const uint32_t add = tile_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (base + k < total) out[base + k] += add;
+}
+
+static inline void launch_scan(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, size_t total, hipStream_t st) {
+  const size_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;
+  k_scan_tile<<<dim3((unsigned)n_tiles), dim3(1024), 0, st>>>(in, out, tile_sums, total);
+  k_scan_sums<<<dim3(1), dim3(1024), 0, st>>>(tile_sums, n_tiles);
+  k_scan_add<<<dim3((unsigned)n_tiles), dim3(1024), 0, st>>>(out, tile_sums, total);
+}
+
+// ---- bucket ordering by population (largest first) so the 64 lanes of a wave own equally long buckets.
+// Counting sort on key = 255 - min(count, 255) without global atomics: per-block LDS histogram written
+// bin-major, scanned, then per-block placement with LDS cursors.
+constexpr int ORDER_BINS = 256;
+
+static __global__ void __launch_bounds__(256) k_order_hist(const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                            uint32_t* __restrict__ hist /* [ORDER_BINS][gridDim.x] */) {
+  __shared__ uint32_t h[ORDER_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (g < n_buckets) {
+    uint32_t c = counts[g];
+    atomicAdd(&h[255u - (c < 255u ? c : 255u)], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+static __global__ void __launch_bounds__(256) k_order_place(const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                             const uint32_t* __restrict__ hist_scanned,
+                                                             uint32_t* __restrict__ order) {
+  __shared__ uint32_t cur[ORDER_BINS];
+  cur[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+  __syncthreads();
+  size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (g < n_buckets) {
+    uint32_t c = counts[g];
+    uint32_t pos = atomicAdd(&cur[255u - (c < 255u ? c : 255u)], 1u);
+    order[pos] = (uint32_t)g;
   }
 }
 
@@ -84,10 +164,12 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
                                                     const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets,
                                                     const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                    const uint32_t* __restrict__ order,
                                                     uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
                                                     XYZZ<F>* __restrict__ buckets) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_buckets) return;
+  size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n_buckets) return;
+  const size_t g = order[tid];  // buckets sorted by population: a wave's lanes run equally long loops
   uint32_t cnt = counts[g];
   if (cnt > BIG_BUCKET) {
     uint32_t pos = atomicAdd(big_count, 1u);
@@ -239,6 +321,14 @@ int plan_alloc(mlhip_msm_plan* p) {
   p->d_bigcount = p->d_zero + 2 * nbuckets;
   HIPCHK(hipMalloc(&p->d_offsets, nbuckets * 4));
   HIPCHK(hipMalloc(&p->d_biglist, nbuckets * 4));
+  HIPCHK(hipMalloc(&p->d_order, nbuckets * 4));
+  {
+    const size_t nblk = (nbuckets + 255) / 256;
+    const size_t hist_n = (size_t)ORDER_BINS * nblk;
+    HIPCHK(hipMalloc(&p->d_hist, hist_n * 4));
+    const size_t tiles = (std::max(nbuckets, hist_n) + SCAN_TILE - 1) / SCAN_TILE;
+    HIPCHK(hipMalloc(&p->d_tilesums, (tiles + 1) * 4));
+  }
   HIPCHK(hipMalloc(&p->d_buckets, nbuckets * p->xyzz_size));
   HIPCHK(hipMalloc(&p->d_A, (size_t)p->W * p->T * p->xyzz_size));
   HIPCHK(hipMalloc(&p->d_W0, (size_t)p->W * p->T * p->xyzz_size));
@@ -296,7 +386,7 @@ int plan_run(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int
                                                                  p->d_digits, p->d_counts);
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
-    k_scan<<<dim3(1), dim3(1024), 0, st>>>(p->d_counts, p->d_offsets, nbuckets);
+    launch_scan(p->d_counts, p->d_offsets, p->d_tilesums, nbuckets, st);
     {
       size_t total_e = (size_t)p->W * n;
       size_t blocks = (total_e + 255) / 256;
@@ -304,10 +394,16 @@ int plan_run(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int
       k_scatter<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(p->d_digits, n, p->W, p->M, p->d_offsets, p->d_cursor,
                                                                p->d_sorted);
     }
+    {
+      const unsigned nblk = (unsigned)((nbuckets + 255) / 256);
+      k_order_hist<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist);
+      launch_scan(p->d_hist, p->d_hist, p->d_tilesums, (size_t)ORDER_BINS * nblk, st);
+      k_order_place<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist, p->d_order);
+    }
     if (prof) HIPCHK(hipEventRecord(p->ev[2], st));
     k_accumulate<F><<<dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st>>>(
-        (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_biglist, p->d_bigcount,
-        (X*)p->d_buckets);
+        (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, p->d_biglist,
+        p->d_bigcount, (X*)p->d_buckets);
     if (prof) HIPCHK(hipEventRecord(p->ev[3], st));
     {
       constexpr int BB = sizeof(X) <= 192 ? 256 : 128;  // 48 KB of LDS per block
