@@ -26,8 +26,8 @@ struct FpField {
   MLHIP_HD static void sub(T& r, const T& a, const T& b) { fp_sub<C>(r, a, b); }
   MLHIP_HD static void dbl(T& r, const T& a) { fp_dbl<C>(r, a); }
   MLHIP_HD static void neg(T& r, const T& a) { fp_neg<C>(r, a); }
-  MLHIP_HD static void mul(T& r, const T& a, const T& b) { fp_mul<C>(r, a, b); }
-  MLHIP_HD static void sqr(T& r, const T& a) { fp_sqr<C>(r, a); }
+  MLHIP_HD static void mul(T& r, const T& a, const T& b) { fp_mul_i<C>(r, a, b); }
+  MLHIP_HD static void sqr(T& r, const T& a) { fp_sqr_i<C>(r, a); }
   MLHIP_HD static void inv(T& r, const T& a) { fp_inv<C>(r, a); }
   MLHIP_HD static void select(T& r, bool c, const T& a, const T& b) { fp_select<C>(r, c, a, b); }
 };

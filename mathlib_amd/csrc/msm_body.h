@@ -99,9 +99,22 @@ MLHIP_HD void msm_digits_body(size_t i, size_t n, const uint32_t* scalars, bool 
 template <class F>
 MLHIP_HD void msm_accumulate_range(XYZZ<F>& acc, const Affine<F>* points, const uint32_t* sorted, size_t begin,
                                    size_t end, size_t stride) {
+  if (begin >= end) return;
+  // software prefetch: the next entry's index and point are loaded before the current mixed addition,
+  // so the two dependent gathers (index, then a random 96/192-byte row) overlap ~30k cycles of arithmetic
+  uint32_t e = sorted[begin];
+  Affine<F> p = points[e & 0x7fffffffu];
   for (size_t k = begin; k < end; k += stride) {
-    uint32_t e = sorted[k];
-    xyzz_madd<F>(acc, points[e & 0x7fffffffu], (e >> 31) != 0);
+    const size_t kn = k + stride;
+    uint32_t en = e;
+    Affine<F> pn = p;
+    if (kn < end) {
+      en = sorted[kn];
+      pn = points[en & 0x7fffffffu];
+    }
+    xyzz_madd<F>(acc, p, (e >> 31) != 0);
+    e = en;
+    p = pn;
   }
 }
 

@@ -259,6 +259,20 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums(const XYZZ<F>* __restrict
 // out[i] = [s_i] P_i: batched single-scalar multiplication (the reference's G1.Mul / G2.Mul,
 // driver/gurvy/bls12381/bls12-381.go:238-247, :342-351; double-and-add shape of :920-932), one lane per
 // product, 4-bit fixed windows: 15-entry table in scratch, 4 doublings + 1 addition per window.
+// out-of-line group operations for kernels that use several of them (bounds the code size)
+template <class F>
+__device__ __noinline__ void xyzz_madd_ool(XYZZ<F>& acc, const Affine<F>& q) {
+  xyzz_madd<F>(acc, q, false);
+}
+template <class F>
+__device__ __noinline__ void xyzz_add_ool(XYZZ<F>& acc, const XYZZ<F>& q) {
+  xyzz_add<F>(acc, q);
+}
+template <class F>
+__device__ __noinline__ void xyzz_dbl_ool(XYZZ<F>& r, const XYZZ<F>& p) {
+  xyzz_dbl<F>(r, p);
+}
+
 template <class C, class F>
 __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__ points, size_t point_stride,
                                                    const uint32_t* __restrict__ scalars, int mont, size_t n,
@@ -272,7 +286,7 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
   xyzz_from_affine<F>(tab[0], P);
   for (int k = 1; k < 15; k++) {
     tab[k] = tab[k - 1];
-    xyzz_madd<F>(tab[k], P, false);
+    xyzz_madd_ool<F>(tab[k], P);
   }
   XYZZ<F> acc;
   xyzz_set_inf<F>(acc);
@@ -281,13 +295,13 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
     if (started) {
       for (int d = 0; d < 4; d++) {
         XYZZ<F> t;
-        xyzz_dbl<F>(t, acc);
+        xyzz_dbl_ool<F>(t, acc);
         acc = t;
       }
     }
     uint32_t nib = (s[w >> 3] >> ((w & 7) * 4)) & 15u;
     if (nib) {
-      xyzz_add<F>(acc, tab[nib - 1]);
+      xyzz_add_ool<F>(acc, tab[nib - 1]);
       started = true;
     }
   }

@@ -94,14 +94,16 @@ MLHIP_HD void fp_mul_beta(Fp<C>& r, const Fp<C>& a) {
   }
 }
 
+// fp2_mul / fp2_sqr are the out-of-line units of the towers and of G2: three inlined Fp multiplies
+// each, operands loaded once into registers.
 template <class C>
-MLHIP_HD void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {
+MLHIP_HD_NOINLINE void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {
   Fp<C> t0, t1, t2, s0, s1;
-  fp_mul<C>(t0, a.c0, b.c0);
-  fp_mul<C>(t1, a.c1, b.c1);
+  fp_mul_i<C>(t0, a.c0, b.c0);
+  fp_mul_i<C>(t1, a.c1, b.c1);
   fp_add<C>(s0, a.c0, a.c1);
   fp_add<C>(s1, b.c0, b.c1);
-  fp_mul<C>(t2, s0, s1);
+  fp_mul_i<C>(t2, s0, s1);
   fp_sub<C>(t2, t2, t0);
   fp_sub<C>(r.c1, t2, t1);
   fp_mul_beta<C>(t1, t1);
@@ -109,19 +111,19 @@ MLHIP_HD void fp2_mul(Fp2<C>& r, const Fp2<C>& a, const Fp2<C>& b) {
 }
 
 template <class C>
-MLHIP_HD void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {
+MLHIP_HD_NOINLINE void fp2_sqr(Fp2<C>& r, const Fp2<C>& a) {
   if (C::BETA == -1) {
     Fp<C> s, d, m;
     fp_add<C>(s, a.c0, a.c1);
     fp_sub<C>(d, a.c0, a.c1);
-    fp_mul<C>(m, a.c0, a.c1);
-    fp_mul<C>(r.c0, s, d);
+    fp_mul_i<C>(m, a.c0, a.c1);
+    fp_mul_i<C>(r.c0, s, d);
     fp_dbl<C>(r.c1, m);
   } else {
     Fp<C> t0, t1, m;
-    fp_sqr<C>(t0, a.c0);
-    fp_sqr<C>(t1, a.c1);
-    fp_mul<C>(m, a.c0, a.c1);
+    fp_sqr_i<C>(t0, a.c0);
+    fp_sqr_i<C>(t1, a.c1);
+    fp_mul_i<C>(m, a.c0, a.c1);
     fp_mul_beta<C>(t1, t1);
     fp_add<C>(r.c0, t0, t1);
     fp_dbl<C>(r.c1, m);
