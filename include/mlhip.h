@@ -94,6 +94,13 @@ int mlhip_msm_plan_destroy(mlhip_msm_plan* plan);
  * the un-normalised partial sum (X,Y,ZZ,ZZZ) is written there too (multi-GPU combine). */
 int mlhip_msm_run(mlhip_msm_plan* plan, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
                   void* stream, void* out_affine, void* out_xyzz);
+/* The same in two halves, so consecutive MSMs pipeline: mlhip_msm_launch enqueues the kernels and the
+ * D2H of the window sums on `stream` and returns; mlhip_msm_finish waits for them and runs the O(1) host
+ * tail.  With two plans on two streams the sort of MSM k+1 overlaps the bucket accumulation of MSM k and
+ * the host tail of MSM k overlaps GPU work (a Groth16 prover issues 4-5 MSMs back to back). */
+int mlhip_msm_launch(mlhip_msm_plan* plan, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
+                     void* stream);
+int mlhip_msm_finish(mlhip_msm_plan* plan, void* out_affine, void* out_xyzz);
 /* Phase timings of the last run with profiling on (HIP events on the plan's stream), milliseconds:
  * [0] digits [1] sort (histogram scan + scatter) [2] bucket accumulation [3] bucket reduction
  * [4] device total [5] host tail.  Returns the number of values written. */

@@ -32,6 +32,8 @@ SYMBOLS = [
     "mlhip_msm_plan_create",
     "mlhip_msm_plan_destroy",
     "mlhip_msm_run",
+    "mlhip_msm_launch",
+    "mlhip_msm_finish",
     "mlhip_msm_plan_set_profiling",
     "mlhip_msm_plan_timings",
     "mlhip_miller_loop_device",
@@ -88,6 +90,8 @@ def load() -> ctypes.CDLL:
     lib.mlhip_msm_plan_create.argtypes = [ci, ci, sz, ci, POINTER(vp)]
     lib.mlhip_msm_plan_destroy.argtypes = [vp]
     lib.mlhip_msm_run.argtypes = [vp, vp, vp, ci, sz, vp, vp, vp]
+    lib.mlhip_msm_launch.argtypes = [vp, vp, vp, ci, sz, vp]
+    lib.mlhip_msm_finish.argtypes = [vp, vp, vp]
     lib.mlhip_msm_plan_set_profiling.argtypes = [vp, ci]
     lib.mlhip_msm_plan_timings.argtypes = [vp, POINTER(c_float), ci]
     lib.mlhip_miller_loop_device.argtypes = [ci, vp, vp, sz, sz, vp, vp]
@@ -152,6 +156,15 @@ class MsmPlan:
                 self._h, c_void_p(d_points), c_void_p(d_scalars), 1 if scalars_mont else 0, n, c_void_p(stream), out, xyzz
             )
         )
+        return (out.raw, xyzz.raw) if want_xyzz else out.raw
+
+    def launch(self, d_points: int, d_scalars: int, n: int, scalars_mont: bool, stream: int = 0) -> None:
+        check(load().mlhip_msm_launch(self._h, c_void_p(d_points), c_void_p(d_scalars), 1 if scalars_mont else 0, n, c_void_p(stream)))
+
+    def finish(self, want_xyzz: bool = False):
+        out = ctypes.create_string_buffer(self.point_bytes)
+        xyzz = ctypes.create_string_buffer(2 * self.point_bytes) if want_xyzz else None
+        check(load().mlhip_msm_finish(self._h, out, xyzz))
         return (out.raw, xyzz.raw) if want_xyzz else out.raw
 
     def close(self) -> None:

@@ -238,22 +238,42 @@ int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
   if (p->h_out) (void)hipHostFree(p->h_out);
   for (int i = 0; i < 5; i++)
     if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
+  if (p->done) (void)hipEventDestroy(p->done);
   delete p;
   return 0;
 }
 
-int mlhip_msm_run(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
-                  void* stream, void* out_affine, void* out_xyzz) {
-  if (!p || !out_affine) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+int mlhip_msm_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
+                     void* stream) {
+  if (!p) return mlhip_rt::fail(MLHIP_EINVAL, "null plan");
+  if (p->pending) return mlhip_rt::fail(MLHIP_EINVAL, "plan already has a pending launch; call mlhip_msm_finish first");
   if (n > p->max_n) return mlhip_rt::fail(MLHIP_EINVAL, "n exceeds the plan's max_n");
   if (n && (!d_points || !d_scalars)) return mlhip_rt::fail(MLHIP_EINVAL, "null device pointer");
   HIPCHK(hipSetDevice(p->device));
   hipStream_t st = (hipStream_t)stream;
   switch (p->curve) {
-    case MLHIP_CURVE_BN254: return mlhip_tu_plan_run_Bn254(p, d_points, d_scalars, scalars_mont, n, st, out_affine, out_xyzz);
-    case MLHIP_CURVE_BLS12_381: return mlhip_tu_plan_run_Bls381(p, d_points, d_scalars, scalars_mont, n, st, out_affine, out_xyzz);
-    default: return mlhip_tu_plan_run_Bls377(p, d_points, d_scalars, scalars_mont, n, st, out_affine, out_xyzz);
+    case MLHIP_CURVE_BN254: return mlhip_tu_plan_launch_Bn254(p, d_points, d_scalars, scalars_mont, n, st);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_plan_launch_Bls381(p, d_points, d_scalars, scalars_mont, n, st);
+    default: return mlhip_tu_plan_launch_Bls377(p, d_points, d_scalars, scalars_mont, n, st);
   }
+}
+
+int mlhip_msm_finish(mlhip_msm_plan* p, void* out_affine, void* out_xyzz) {
+  if (!p || !out_affine) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  HIPCHK(hipSetDevice(p->device));
+  switch (p->curve) {
+    case MLHIP_CURVE_BN254: return mlhip_tu_plan_finish_Bn254(p, out_affine, out_xyzz);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_plan_finish_Bls381(p, out_affine, out_xyzz);
+    default: return mlhip_tu_plan_finish_Bls377(p, out_affine, out_xyzz);
+  }
+}
+
+int mlhip_msm_run(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
+                  void* stream, void* out_affine, void* out_xyzz) {
+  if (!p || !out_affine) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  int rc = mlhip_msm_launch(p, d_points, d_scalars, scalars_mont, n, stream);
+  if (rc) return rc;
+  return mlhip_msm_finish(p, out_affine, out_xyzz);
 }
 
 int mlhip_msm_plan_set_profiling(mlhip_msm_plan* p, int on) {

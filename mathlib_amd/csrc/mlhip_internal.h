@@ -30,6 +30,9 @@ struct mlhip_msm_plan {
   void* h_out = nullptr;
   bool profiling = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t done = nullptr;
+  bool pending = false;
+  size_t pending_n = 0;
   float ms[6] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -37,8 +40,9 @@ struct mlhip_msm_plan {
 // per-curve entry points, defined in tu_msm_<curve>.hip / tu_pairing_<curve>.hip
 #define MLHIP_DECLARE_CURVE(NAME)                                                                                   \
   int mlhip_tu_plan_alloc_##NAME(mlhip_msm_plan* p);                                                                \
-  int mlhip_tu_plan_run_##NAME(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n,  \
-                               hipStream_t st, void* out_affine, void* out_xyzz);                                   \
+  int mlhip_tu_plan_launch_##NAME(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont,        \
+                                  size_t n, hipStream_t st);                                                       \
+  int mlhip_tu_plan_finish_##NAME(mlhip_msm_plan* p, void* out_affine, void* out_xyzz);                            \
   int mlhip_tu_pairing_##NAME(int what, const void* d_g1, const void* d_g2, size_t ppp, size_t n, const void* d_in, \
                               void* d_out, hipStream_t st);                                                         \
   int mlhip_tu_fp_mul_##NAME(const void* d_a, const void* d_b, size_t n, int repeat, void* d_out, hipStream_t st);   \

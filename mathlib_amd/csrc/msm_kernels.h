@@ -349,6 +349,7 @@ int plan_alloc(mlhip_msm_plan* p) {
   HIPCHK(hipMalloc(&p->d_out, (size_t)p->W * p->nsel * p->xyzz_size));
   HIPCHK(hipHostMalloc(&p->h_out, (size_t)p->W * p->nsel * p->xyzz_size, hipHostMallocDefault));
   for (int i = 0; i < 5; i++) HIPCHK(hipEventCreate(&p->ev[i]));
+  HIPCHK(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
   return 0;
 }
 
@@ -381,14 +382,12 @@ void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
 }
 
 template <class C, class F>
-int plan_run(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n, hipStream_t st,
-             void* out_affine, void* out_xyzz) {
+int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n, hipStream_t st) {
   typedef Affine<F> A;
   typedef XYZZ<F> X;
-  X total;
-  if (n == 0) {
-    xyzz_set_inf<F>(total);
-  } else {
+  p->pending_n = n;
+  p->pending = true;
+  if (n != 0) {
     const size_t nbuckets = (size_t)p->W * p->M;
     const bool prof = p->profiling;
     HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
@@ -436,19 +435,29 @@ int plan_run(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int
     if (prof) HIPCHK(hipEventRecord(p->ev[4], st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->W * p->nsel * sizeof(X), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventRecord(p->done, st));
+  }
+  return 0;
+}
+
+template <class C, class F>
+int plan_finish(mlhip_msm_plan* p, void* out_affine, void* out_xyzz) {
+  typedef Affine<F> A;
+  typedef XYZZ<F> X;
+  X total;
+  if (!p->pending) return mlhip_rt::fail(MLHIP_EINVAL, "mlhip_msm_finish without a pending mlhip_msm_launch");
+  p->pending = false;
+  if (p->pending_n == 0) {
+    xyzz_set_inf<F>(total);
+  } else {
+    HIPCHK(hipEventSynchronize(p->done));
     auto t0 = std::chrono::steady_clock::now();
     host_tail<F>(p, total);
-    A r;
-    xyzz_to_affine<F>(r, total);
-    memcpy(out_affine, &r, sizeof(A));
-    if (out_xyzz) memcpy(out_xyzz, &total, sizeof(X));
-    if (prof) {
+    if (p->profiling) {
       for (int i = 0; i < 4; i++) HIPCHK(hipEventElapsedTime(&p->ms[i], p->ev[i], p->ev[i + 1]));
       HIPCHK(hipEventElapsedTime(&p->ms[4], p->ev[0], p->ev[4]));
       p->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    return 0;
   }
   A r;
   xyzz_to_affine<F>(r, total);
@@ -456,6 +465,5 @@ int plan_run(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int
   if (out_xyzz) memcpy(out_xyzz, &total, sizeof(X));
   return 0;
 }
-
 
 }  // namespace mlhip

@@ -4,11 +4,14 @@ using namespace mlhip;
 int mlhip_tu_plan_alloc_Bn254(mlhip_msm_plan* p) {
   return p->group == MLHIP_GROUP_G1 ? plan_alloc<FpField<Bn254>>(p) : plan_alloc<Fp2Field<Bn254>>(p);
 }
-int mlhip_tu_plan_run_Bn254(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n,
-                         hipStream_t st, void* out_affine, void* out_xyzz) {
-  if (p->group == MLHIP_GROUP_G1)
-    return plan_run<Bn254, FpField<Bn254>>(p, d_points, d_scalars, mont, n, st, out_affine, out_xyzz);
-  return plan_run<Bn254, Fp2Field<Bn254>>(p, d_points, d_scalars, mont, n, st, out_affine, out_xyzz);
+int mlhip_tu_plan_launch_Bn254(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n,
+                            hipStream_t st) {
+  if (p->group == MLHIP_GROUP_G1) return plan_launch<Bn254, FpField<Bn254>>(p, d_points, d_scalars, mont, n, st);
+  return plan_launch<Bn254, Fp2Field<Bn254>>(p, d_points, d_scalars, mont, n, st);
+}
+int mlhip_tu_plan_finish_Bn254(mlhip_msm_plan* p, void* out_affine, void* out_xyzz) {
+  if (p->group == MLHIP_GROUP_G1) return plan_finish<Bn254, FpField<Bn254>>(p, out_affine, out_xyzz);
+  return plan_finish<Bn254, Fp2Field<Bn254>>(p, out_affine, out_xyzz);
 }
 int mlhip_tu_scalar_mul_Bn254(int group, const void* d_points, size_t point_stride, const void* d_scalars, int mont,
                               size_t n, void* d_out, hipStream_t st) {
