@@ -23,6 +23,9 @@ struct mlhip_msm_plan {
   uint32_t M, T;
   size_t pt_size, xyzz_size;
   uint32_t *d_digits = nullptr, *d_sorted = nullptr, *d_zero = nullptr, *d_offsets = nullptr, *d_biglist = nullptr;
+  int sort_low = 0, sort_idx_bits = 0;  // two-level sort: fine bits per coarse bin (0 = legacy path)
+  uint32_t sort_nb = 0;
+  uint32_t *d_coarse_count = nullptr, *d_coarse_cursor = nullptr, *d_coarse_off = nullptr;
   uint32_t *d_order = nullptr, *d_hist = nullptr, *d_tilesums = nullptr;
   uint32_t *d_counts = nullptr, *d_cursor = nullptr, *d_bigcount = nullptr;  // views into d_zero
   size_t zero_bytes = 0;

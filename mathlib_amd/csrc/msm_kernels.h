@@ -13,6 +13,7 @@
 #pragma once
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -108,6 +109,190 @@ static inline void launch_scan(const uint32_t* in, uint32_t* out, uint32_t* tile
   k_scan_tile<<<dim3((unsigned)n_tiles), dim3(1024), 0, st>>>(in, out, tile_sums, total);
   k_scan_sums<<<dim3(1), dim3(1024), 0, st>>>(tile_sums, n_tiles);
   k_scan_add<<<dim3((unsigned)n_tiles), dim3(1024), 0, st>>>(out, tile_sums, total);
+}
+
+// ---- two-level LDS counting sort of the (window, bucket) keys -------------------------------------------
+// Replaces k_digits + k_scatter (one global atomic per key, 2 x 16.7M at n = 2^20) by:
+//   k_coarse_hist     per block of 1024 scalars: digits -> LDS histogram over NB coarse bins
+//                     (bin = window * CB + bucket >> LOW), one global atomic per (block, bin)
+//   scan of the NB coarse counts
+//   k_coarse_scatter  same blocks: reserve a slice of every coarse bin per block (one global atomic per
+//                     (block, bin)), rank inside the block with LDS atomics, write packed entries
+//                     (fine bucket bits | sign | point index)
+//   k_fine_sort       one block per coarse bin: LDS histogram of the 2^LOW fine buckets -> counts/offsets
+//                     of the real buckets (coalesced), then LDS-ranked placement of the point indices
+constexpr int SORT_TILE = 1024;  // scalars per block in the coarse passes
+
+template <class C>
+__global__ void __launch_bounds__(256) k_coarse_hist(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
+                                                     int low, uint32_t NB, uint32_t* __restrict__ coarse_count) {
+  extern __shared__ uint32_t lds_u32[];
+  uint32_t* hist = lds_u32;
+  for (uint32_t b = threadIdx.x; b < NB; b += 256) hist[b] = 0;
+  __syncthreads();
+  const uint32_t cb_shift = (uint32_t)(c - 1 - low);  // coarse bins per window = 1 << cb_shift
+  for (int k = 0; k < SORT_TILE / 256; k++) {
+    size_t i = (size_t)blockIdx.x * SORT_TILE + (size_t)k * 256 + threadIdx.x;
+    if (i >= n) break;
+    // recompute the digit chain window by window (no per-lane array: keeps this in registers)
+    uint32_t s[8];
+    fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (c - 1);
+    for (int w = 0; w < W; w++) {
+      int bit = w * c;
+      uint32_t v = 0;
+      if (bit < 256) {
+        int word = bit >> 5, sh = bit & 31;
+        uint64_t two = s[word];
+        if (word + 1 < 8) two |= (uint64_t)s[word + 1] << 32;
+        v = (uint32_t)((two >> sh) & ((1u << c) - 1));
+      }
+      v += carry;
+      uint32_t mag;
+      if (v > half) {
+        mag = (1u << c) - v;
+        carry = 1;
+      } else {
+        mag = v;
+        carry = 0;
+      }
+      if (mag) atomicAdd(&hist[((uint32_t)w << cb_shift) + ((mag - 1) >> low)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < NB; b += 256) {
+    uint32_t h = hist[b];
+    if (h) atomicAdd(&coarse_count[b], h);
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_coarse_scatter(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
+                                                        int low, int idx_bits, uint32_t NB,
+                                                        const uint32_t* __restrict__ coarse_off,
+                                                        uint32_t* __restrict__ coarse_cursor, uint32_t* __restrict__ tmp) {
+  extern __shared__ uint32_t lds_u32[];
+  uint32_t* hist = lds_u32;       // per-block count, then running rank
+  uint32_t* base = lds_u32 + NB;  // global position of this block's slice of each bin
+  for (uint32_t b = threadIdx.x; b < NB; b += 256) hist[b] = 0;
+  __syncthreads();
+  const uint32_t cb_shift = (uint32_t)(c - 1 - low);
+  const uint32_t half = 1u << (c - 1);
+  // pass 1: count
+  for (int k = 0; k < SORT_TILE / 256; k++) {
+    size_t i = (size_t)blockIdx.x * SORT_TILE + (size_t)k * 256 + threadIdx.x;
+    if (i >= n) break;
+    uint32_t s[8];
+    fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+      int bit = w * c;
+      uint32_t v = 0;
+      if (bit < 256) {
+        int word = bit >> 5, sh = bit & 31;
+        uint64_t two = s[word];
+        if (word + 1 < 8) two |= (uint64_t)s[word + 1] << 32;
+        v = (uint32_t)((two >> sh) & ((1u << c) - 1));
+      }
+      v += carry;
+      uint32_t mag;
+      if (v > half) {
+        mag = (1u << c) - v;
+        carry = 1;
+      } else {
+        mag = v;
+        carry = 0;
+      }
+      if (mag) atomicAdd(&hist[((uint32_t)w << cb_shift) + ((mag - 1) >> low)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < NB; b += 256) {
+    uint32_t h = hist[b];
+    base[b] = h ? coarse_off[b] + atomicAdd(&coarse_cursor[b], h) : 0u;
+    hist[b] = 0;
+  }
+  __syncthreads();
+  // pass 2: place
+  const uint32_t low_mask = (1u << low) - 1u;
+  for (int k = 0; k < SORT_TILE / 256; k++) {
+    size_t i = (size_t)blockIdx.x * SORT_TILE + (size_t)k * 256 + threadIdx.x;
+    if (i >= n) break;
+    uint32_t s[8];
+    fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+      int bit = w * c;
+      uint32_t v = 0;
+      if (bit < 256) {
+        int word = bit >> 5, sh = bit & 31;
+        uint64_t two = s[word];
+        if (word + 1 < 8) two |= (uint64_t)s[word + 1] << 32;
+        v = (uint32_t)((two >> sh) & ((1u << c) - 1));
+      }
+      v += carry;
+      uint32_t mag, neg;
+      if (v > half) {
+        mag = (1u << c) - v;
+        neg = 1;
+        carry = 1;
+      } else {
+        mag = v;
+        neg = 0;
+        carry = 0;
+      }
+      if (mag) {
+        uint32_t bkt = mag - 1;
+        uint32_t bin = ((uint32_t)w << cb_shift) + (bkt >> low);
+        uint32_t pos = base[bin] + atomicAdd(&hist[bin], 1u);
+        tmp[pos] = ((bkt & low_mask) << (idx_bits + 1)) | (neg << idx_bits) | (uint32_t)i;
+      }
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(256) k_fine_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ coarse_off,
+                                                   const uint32_t* __restrict__ coarse_count, int c, int low, int idx_bits,
+                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                   uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t fo[256];
+  const uint32_t bin = blockIdx.x;
+  const uint32_t F = 1u << low;
+  const uint32_t begin = coarse_off[bin], cnt = coarse_count[bin];
+  const uint32_t idx_mask = (1u << idx_bits) - 1u;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < cnt; k += 256) atomicAdd(&hist[tmp[begin + k] >> (idx_bits + 1)], 1u);
+  __syncthreads();
+  // exclusive scan of the F <= 256 fine counts
+  uint32_t mine = threadIdx.x < F ? hist[threadIdx.x] : 0u;
+  fo[threadIdx.x] = mine;
+  __syncthreads();
+  for (uint32_t off = 1; off < 256; off <<= 1) {
+    uint32_t x = threadIdx.x >= off ? fo[threadIdx.x - off] : 0;
+    __syncthreads();
+    fo[threadIdx.x] += x;
+    __syncthreads();
+  }
+  const uint32_t excl = fo[threadIdx.x] - mine;
+  __syncthreads();
+  fo[threadIdx.x] = excl;
+  hist[threadIdx.x] = 0;  // becomes the running rank
+  // real bucket id of (bin, fine): window-major layout g = w*M + (cb << low) + fine = bin << low + fine
+  if (threadIdx.x < F) {
+    size_t g = ((size_t)bin << low) + threadIdx.x;
+    counts[g] = mine;
+    offsets[g] = begin + excl;
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < cnt; k += 256) {
+    uint32_t e = tmp[begin + k];
+    uint32_t f = e >> (idx_bits + 1);
+    uint32_t pos = begin + fo[f] + atomicAdd(&hist[f], 1u);
+    sorted[pos] = (e & idx_mask) | (((e >> idx_bits) & 1u) << 31);
+  }
 }
 
 // ---- bucket ordering by population (largest first) so the 64 lanes of a wave own equally long buckets.
@@ -328,11 +513,32 @@ int plan_alloc(mlhip_msm_plan* p) {
   p->xyzz_size = sizeof(XYZZ<F>);
   HIPCHK(hipMalloc(&p->d_digits, (size_t)p->W * p->max_n * 4));
   HIPCHK(hipMalloc(&p->d_sorted, (size_t)p->W * p->max_n * 4));
-  p->zero_bytes = (2 * nbuckets + 4) * 4;
+  {
+    // sort parameters: packed entry = fine bits | sign | index must fit 32 bits, coarse bins must fit LDS
+    int idx_bits = 1;
+    while (((size_t)1 << idx_bits) < p->max_n) idx_bits++;
+    int low = p->c - 1 < 8 ? p->c - 1 : 8;
+    if (low > 31 - idx_bits) low = 31 - idx_bits;
+    const char* legacy = getenv("MLHIP_LEGACY_SORT");
+    uint32_t nb = low >= 1 ? (uint32_t)p->W << (p->c - 1 - low) : 0;
+    if (low < 1 || nb > 4096 || (legacy && legacy[0] == '1')) {
+      p->sort_low = 0;
+      p->sort_nb = 0;
+    } else {
+      p->sort_low = low;
+      p->sort_nb = nb;
+    }
+    p->sort_idx_bits = idx_bits;
+  }
+  // zeroed every run: [counts | cursor | bigcount(4) | coarse_count | coarse_cursor]
+  p->zero_bytes = (2 * nbuckets + 4 + 2 * (size_t)p->sort_nb) * 4;
   HIPCHK(hipMalloc(&p->d_zero, p->zero_bytes));
   p->d_counts = p->d_zero;
   p->d_cursor = p->d_zero + nbuckets;
   p->d_bigcount = p->d_zero + 2 * nbuckets;
+  p->d_coarse_count = p->d_zero + 2 * nbuckets + 4;
+  p->d_coarse_cursor = p->d_coarse_count + p->sort_nb;
+  HIPCHK(hipMalloc(&p->d_coarse_off, ((size_t)p->sort_nb + 1) * 4));
   HIPCHK(hipMalloc(&p->d_offsets, nbuckets * 4));
   HIPCHK(hipMalloc(&p->d_biglist, nbuckets * 4));
   HIPCHK(hipMalloc(&p->d_order, nbuckets * 4));
@@ -392,20 +598,36 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     const bool prof = p->profiling;
     HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
     if (prof) HIPCHK(hipEventRecord(p->ev[0], st));
-    {
-      size_t blocks = (n + 255) / 256;
-      if (blocks > 65536) blocks = 65536;
-      k_digits<C><<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->M,
-                                                                 p->d_digits, p->d_counts);
-    }
-    if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
-    launch_scan(p->d_counts, p->d_offsets, p->d_tilesums, nbuckets, st);
-    {
-      size_t total_e = (size_t)p->W * n;
-      size_t blocks = (total_e + 255) / 256;
-      if (blocks > 262144) blocks = 262144;
-      k_scatter<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(p->d_digits, n, p->W, p->M, p->d_offsets, p->d_cursor,
-                                                               p->d_sorted);
+    if (p->sort_low > 0) {
+      // two-level LDS counting sort (no per-key global atomics)
+      const unsigned blocks = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+      const uint32_t NB = p->sort_nb;
+      k_coarse_hist<C><<<dim3(blocks), dim3(256), NB * 4, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low, NB,
+                                                              p->d_coarse_count);
+      if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
+      launch_scan(p->d_coarse_count, p->d_coarse_off, p->d_tilesums, NB, st);
+      k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low,
+                                                                 p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
+                                                                 p->d_digits);
+      k_fine_sort<<<dim3(NB), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->c, p->sort_low,
+                                                 p->sort_idx_bits, p->d_counts, p->d_offsets, p->d_sorted);
+    } else {
+      // legacy path (very large n or MLHIP_LEGACY_SORT=1): digits array + global-atomic histogram / scatter
+      {
+        size_t blocks = (n + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        k_digits<C><<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->M,
+                                                                   p->d_digits, p->d_counts);
+      }
+      if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
+      launch_scan(p->d_counts, p->d_offsets, p->d_tilesums, nbuckets, st);
+      {
+        size_t total_e = (size_t)p->W * n;
+        size_t blocks = (total_e + 255) / 256;
+        if (blocks > 262144) blocks = 262144;
+        k_scatter<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(p->d_digits, n, p->W, p->M, p->d_offsets, p->d_cursor,
+                                                                 p->d_sorted);
+      }
     }
     {
       const unsigned nblk = (unsigned)((nbuckets + 255) / 256);
