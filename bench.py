@@ -171,6 +171,17 @@ def main() -> None:
     # ---- roofline of the dominant kernel (k_accumulate): algorithmic bytes / its HIP-event duration
     acc_ms = phase.get("accumulate", 0.0)
     achieved = (MSM_BYTES_PER_UNIT * n) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json): the
+    # counters cannot be read from inside this process, so this is the per-launch figure of the same workload
+    traffic, traffic_note = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pm = json.load(f)
+        kk = next(v for k_, v in pm["kernels"].items() if k_.startswith("k_accumulate<") and "Fp2" not in k_)
+        traffic = (kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024.0
+        traffic_note = "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01_pmc_traffic.json, uncorrected (gather pattern, Infinity-Cache hits included): every point row is re-read once per window (16 x 96 MiB)"
+    except Exception:
+        pass
     roofline = {
         "bound": "hbm",
         "kernel": "k_accumulate<FpField<Bls381>>",
@@ -178,7 +189,8 @@ def main() -> None:
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_note": traffic_note,
         "avg_kernel_ms": acc_ms,
         "phase_ms": phase,
         # the path is integer-ALU bound, not HBM bound: ~10 Fp multiplications per mixed addition,
