@@ -84,6 +84,14 @@ int mlhip_pairing_batch(int curve, const void* g1, const void* g2, size_t n, voi
 /* out[i] = a[i] * b[i] in Gt (Gt.Mul, driver/gurvy/bls12381/bls12-381.go:417-419), element-wise over n */
 int mlhip_gt_mul(int curve, const void* a_gt, const void* b_gt, size_t n, void* out_gt);
 
+/* out[i] = in[i]^(scalars[i]) in Gt (Gt.Exp, driver/gurvy/bls12381/bls12-381.go:399-407), element-wise over n;
+ * valid for any Gt value.  Scalars as for the MSM entry points. */
+int mlhip_gt_exp(int curve, const void* in_gt, const void* scalars, int scalars_mont, size_t n, void* out_gt);
+/* out = FExp( prod_i MillerLoop(g1[i], g2[i]) ): a multi-pairing product with ONE shared final exponentiation
+ * (what a verifier computes before IsUnity: perf_test.go:254-259).  n Miller loops run one per lane, the
+ * product is a log-depth tree of Gt multiplications on the device. */
+int mlhip_pairing_product(int curve, const void* g1, const void* g2, size_t n, void* out_gt);
+
 /* ---- device-resident entry points (points / scalars already in HBM; resident SRS) ----------- */
 typedef struct mlhip_msm_plan mlhip_msm_plan;
 /* Workspace for MSMs of up to max_n points on the calling thread's device. */
@@ -113,6 +121,8 @@ int mlhip_final_exp_device(int curve, const void* d_in_gt, size_t n, void* d_out
 int mlhip_pairing_batch_device(int curve, const void* d_g1, const void* d_g2, size_t n, void* d_out_gt,
                                void* stream);
 int mlhip_gt_mul_device(int curve, const void* d_a_gt, const void* d_b_gt, size_t n, void* d_out_gt, void* stream);
+int mlhip_gt_exp_device(int curve, const void* d_in_gt, const void* d_scalars, int scalars_mont, size_t n,
+                        void* d_out_gt, void* stream);
 
 /* out[i] = [scalars[i]] points[i * point_stride]: batched single-scalar multiplication (G1.Mul / G2.Mul,
  * driver/gurvy/bls12381/bls12-381.go:238-247, :342-351).  point_stride = 0 multiplies one base point by

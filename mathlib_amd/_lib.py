@@ -29,6 +29,8 @@ SYMBOLS = [
     "mlhip_final_exp",
     "mlhip_pairing_batch",
     "mlhip_gt_mul",
+    "mlhip_gt_exp",
+    "mlhip_pairing_product",
     "mlhip_msm_plan_create",
     "mlhip_msm_plan_destroy",
     "mlhip_msm_run",
@@ -40,6 +42,7 @@ SYMBOLS = [
     "mlhip_final_exp_device",
     "mlhip_pairing_batch_device",
     "mlhip_gt_mul_device",
+    "mlhip_gt_exp_device",
     "mlhip_scalar_mul_device",
     "mlhip_scalar_mul",
     "mlhip_g1_sum",
@@ -87,6 +90,9 @@ def load() -> ctypes.CDLL:
     lib.mlhip_final_exp.argtypes = [ci, vp, sz, vp]
     lib.mlhip_pairing_batch.argtypes = [ci, vp, vp, sz, vp]
     lib.mlhip_gt_mul.argtypes = [ci, vp, vp, sz, vp]
+    lib.mlhip_gt_exp.argtypes = [ci, vp, vp, ci, sz, vp]
+    lib.mlhip_pairing_product.argtypes = [ci, vp, vp, sz, vp]
+    lib.mlhip_gt_exp_device.argtypes = [ci, vp, vp, ci, sz, vp, vp]
     lib.mlhip_msm_plan_create.argtypes = [ci, ci, sz, ci, POINTER(vp)]
     lib.mlhip_msm_plan_destroy.argtypes = [vp]
     lib.mlhip_msm_run.argtypes = [vp, vp, vp, ci, sz, vp, vp, vp]

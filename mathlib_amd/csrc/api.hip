@@ -408,6 +408,79 @@ int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stri
   return rc;
 }
 
+int mlhip_gt_exp_device(int curve, const void* d_in, const void* d_scalars, int mont, size_t n, void* d_out, void* stream) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (curve) {
+    case MLHIP_CURVE_BN254: return mlhip_tu_gt_exp_Bn254(d_in, d_scalars, mont, n, d_out, st);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_gt_exp_Bls381(d_in, d_scalars, mont, n, d_out, st);
+    case MLHIP_CURVE_BLS12_377: return mlhip_tu_gt_exp_Bls377(d_in, d_scalars, mont, n, d_out, st);
+    default: return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  }
+}
+
+int mlhip_gt_exp(int curve, const void* in, const void* scalars, int mont, size_t n, void* out) {
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (n == 0) return 0;
+  if (!in || !scalars || !out) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  int rc = ensure_device();
+  if (rc) return rc;
+  void *din = nullptr, *ds = nullptr, *dout = nullptr;
+  do {
+    if (hipMalloc(&din, n * sz.gt) != hipSuccess || hipMalloc(&ds, n * 32) != hipSuccess || hipMalloc(&dout, n * sz.gt) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc failed"); break; }
+    if (hipMemcpy(din, in, n * sz.gt, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(ds, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy H2D failed"); break; }
+    rc = mlhip_gt_exp_device(curve, din, ds, mont, n, dout, nullptr);
+    if (rc) break;
+    hipError_t e = hipMemcpy(out, dout, n * sz.gt, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e)); break; }
+  } while (0);
+  if (din) (void)hipFree(din);
+  if (ds) (void)hipFree(ds);
+  if (dout) (void)hipFree(dout);
+  return rc;
+}
+
+int mlhip_pairing_product(int curve, const void* g1, const void* g2, size_t n, void* out) {
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (!out) return mlhip_rt::fail(MLHIP_EINVAL, "null output pointer");
+  if (n && (!g1 || !g2)) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  int rc = ensure_device();
+  if (rc) return rc;
+  // n == 0: the empty product, FExp(1) = 1; run it through the same kernels with one infinity pair
+  const size_t m0 = n ? n : 1;
+  void *d1 = nullptr, *d2 = nullptr, *dgt = nullptr;
+  do {
+    if (hipMalloc(&d1, m0 * sz.g1) != hipSuccess || hipMalloc(&d2, m0 * sz.g2) != hipSuccess || hipMalloc(&dgt, m0 * sz.gt) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc failed"); break; }
+    if (n) {
+      if (hipMemcpy(d1, g1, n * sz.g1, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d2, g2, n * sz.g2, hipMemcpyHostToDevice) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy H2D failed"); break; }
+    } else {
+      if (hipMemset(d1, 0, sz.g1) != hipSuccess || hipMemset(d2, 0, sz.g2) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemset failed"); break; }
+    }
+    rc = tu_pairing(curve, 0, d1, d2, 1, m0, nullptr, dgt, nullptr);
+    if (rc) break;
+    // tree product: fold the upper part onto the lower part until one value is left
+    size_t m = m0;
+    while (m > 1 && rc == 0) {
+      size_t half = m / 2;
+      rc = mlhip_gt_mul_device(curve, dgt, (const char*)dgt + (m - half) * sz.gt, half, dgt, nullptr);
+      m -= half;
+    }
+    if (rc) break;
+    rc = tu_pairing(curve, 1, nullptr, nullptr, 1, 1, dgt, dgt, nullptr);
+    if (rc) break;
+    hipError_t e = hipMemcpy(out, dgt, sz.gt, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e)); break; }
+  } while (0);
+  if (d1) (void)hipFree(d1);
+  if (d2) (void)hipFree(d2);
+  if (dgt) (void)hipFree(dgt);
+  return rc;
+}
+
 int mlhip_g1_sum(int curve, const void* pts, size_t n, void* out) {
   if (!out || (n && !pts)) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
   switch (curve) {

@@ -3,6 +3,7 @@
 // Pairing, Pairing2 and FExp (driver/gurvy/bls12381/bls12-381.go:448-468, bn254.go:247-267, bls12-377.go:244-264).
 #pragma once
 #include "mlhip_internal.h"
+#include "msm_body.h"
 #include "pairing.h"
 
 namespace mlhip {
@@ -82,6 +83,41 @@ __global__ void __launch_bounds__(64) k_gt_mul(const Fp12<C>* __restrict__ a, co
   Fp12<C> x = a[i], y = b[i], r;
   fp12_mul<C>(r, x, y);
   out[i] = r;
+}
+
+// out[i] = in[i]^(scalars[i]) in Fp12 (Gt.Exp, reference driver/gurvy/bls12381/bls12-381.go:399-407): plain
+// square-and-multiply with the generic Fp12 squaring, so it is valid for ANY Gt value (raw Miller-loop
+// outputs included), like gnark's GT.Exp.
+template <class C>
+__global__ void __launch_bounds__(64) k_gt_exp(const Fp12<C>* __restrict__ in, const uint32_t* __restrict__ scalars, int mont,
+                                               size_t n, Fp12<C>* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+  fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  Fp12<C> base = in[i], acc;
+  fp12_one<C>(acc);
+  bool started = false;
+  for (int b = 255; b >= 0; b--) {
+    if (started) fp12_sqr<C>(acc, acc);
+    if ((s[b >> 5] >> (b & 31)) & 1u) {
+      if (started)
+        fp12_mul<C>(acc, acc, base);
+      else {
+        acc = base;
+        started = true;
+      }
+    }
+  }
+  out[i] = acc;
+}
+
+template <class C>
+int gt_exp_device(const void* d_in, const void* d_scalars, int mont, size_t n, void* d_out, hipStream_t st) {
+  k_gt_exp<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars, mont, n,
+                                                                 (Fp12<C>*)d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 template <class C>

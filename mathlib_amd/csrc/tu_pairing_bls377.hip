@@ -11,3 +11,6 @@ int mlhip_tu_fp_mul_Bls377(const void* d_a, const void* d_b, size_t n, int repea
 int mlhip_tu_gt_mul_Bls377(const void* d_a, const void* d_b, size_t n, void* d_out, hipStream_t st) {
   return gt_mul_device<Bls377>(d_a, d_b, n, d_out, st);
 }
+int mlhip_tu_gt_exp_Bls377(const void* d_in, const void* d_scalars, int mont, size_t n, void* d_out, hipStream_t st) {
+  return gt_exp_device<Bls377>(d_in, d_scalars, mont, n, d_out, st);
+}

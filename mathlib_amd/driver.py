@@ -10,7 +10,8 @@ names, argument order and error behaviour -- so the parity tests read like math_
     Curve.Pairing2(p2a, p2b G2, p1a, p1b G1) Gt  driver/math.go:54-55     -> mlhip_miller_loop (ppp=2)
     Curve.FExp(Gt) Gt                            driver/math.go:56-57     -> mlhip_final_exp
     G1.Mul / G2.Mul / Gt.Mul / G1.Add ...        driver/math.go:249-360   -> n=1 MSM, group helpers
-  additive: MultiScalarMulG2, PairingBatch.
+    Gt.Exp(Zr) Gt                                driver/math.go:358-359   -> mlhip_gt_exp
+  additive: MultiScalarMulG2, PairingBatch, PairingProduct.
 
 Only plumbing happens here (byte packing, Montgomery <-> integer conversion for printing and wire
 bytes).  All group / field arithmetic is done by libmlhip.so; nothing under oracle/ is imported.
@@ -235,6 +236,13 @@ class Gt(_Element):
         check(load().mlhip_gt_mul(self.curve.id, self.raw, o.raw, 1, out))
         self.raw = out.raw
 
+    def Exp(self, x: "Zr") -> "Gt":
+        """driver/math.go:358-359 / bls12-381.go:399-407"""
+        c = self.curve
+        out = ctypes.create_string_buffer(c.gt_bytes)
+        check(load().mlhip_gt_exp(c.id, self.raw, x.le_bytes(c.scalars_mont), 1 if c.scalars_mont else 0, 1, out))
+        return Gt(out.raw, c)
+
     def IsUnity(self) -> bool:
         return self.raw == self.curve._gt_one
 
@@ -361,6 +369,15 @@ class Curve:
         out = ctypes.create_string_buffer(self.gt_bytes * max(n, 1))
         check(load().mlhip_pairing_batch(self.id, b"".join(p.raw for p in g1s), b"".join(q.raw for q in g2s), n, out))
         return [Gt(out.raw[i * self.gt_bytes : (i + 1) * self.gt_bytes], self) for i in range(n)]
+
+
+    def PairingProduct(self, g2s: Sequence[G2], g1s: Sequence[G1]) -> Gt:
+        """FExp(prod_i Pairing(g2s[i], g1s[i])) with one shared final exponentiation (additive API)."""
+        if len(g2s) != len(g1s):
+            raise ValueError("PairingProduct: length mismatch")
+        out = ctypes.create_string_buffer(self.gt_bytes)
+        check(load().mlhip_pairing_product(self.id, b"".join(p.raw for p in g1s), b"".join(q.raw for q in g2s), len(g1s), out))
+        return Gt(out.raw, self)
 
 
 def NewCurve(name: str, **kw) -> Curve:

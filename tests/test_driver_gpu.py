@@ -134,3 +134,56 @@ def test_scalar_mul_batch_kernel(curve, mlhip):
     mlhip.check(lib.mlhip_scalar_mul(c.id, 1, out.raw[: 16 * c.g1_bytes], 1, sc[32 : 17 * 32], 0, 16, out3))
     for i in range(16):
         assert out3.raw[i * c.g1_bytes : (i + 1) * c.g1_bytes] == cref.point_mul(c.id, 1, out.raw[i * c.g1_bytes : (i + 1) * c.g1_bytes], ks[i + 1])
+
+
+def test_runPowTest_gt_exp(curve):
+    """math_test.go:390-421: e(g2, g1)^r == e(g2^r, g1) == e(g2, g1^r), through Gt.Exp"""
+    c = curve
+    r = c.NewRandomZr(c._rng)
+    g1, g2 = c.GenG1(), c._gen_g2
+    a = c.FExp(c.Pairing(g2, g1)).Exp(r)
+    b = c.FExp(c.Pairing(g2.Mul(r), g1))
+    d = c.FExp(c.Pairing(g2, g1.Mul(r)))
+    assert a.Equals(b) and a.Equals(d)
+    # Exp on a raw (not final-exponentiated) Miller value, then FExp: still the same element
+    raw = c.Pairing(g2, g1).Exp(r)
+    assert c.FExp(raw).Equals(a)
+    assert c.FExp(c.Pairing(g2, g1)).Exp(c.GroupOrder).IsUnity()
+    assert c.FExp(c.Pairing(g2, g1)).Exp(c.NewZrFromInt(0)).IsUnity()
+
+
+def test_gt_exp_batch_vs_oracle(curve, mlhip):
+    import ctypes
+
+    from oracle import pyref as R
+
+    c = curve
+    cp = R.CURVES_BY_ID[c.id]
+    T = R.tower(cp)
+    g = c._golden
+    f = R.gt_from_mont_bytes(cp, bytes.fromhex(g["pairing"][1]["fexp"]))
+    ks = [0, 1, 2, cp.r - 1, c._rng(cp.r), c._rng(1 << 64)]
+    out = ctypes.create_string_buffer(c.gt_bytes * len(ks))
+    mlhip.check(mlhip.load().mlhip_gt_exp(c.id, bytes.fromhex(g["pairing"][1]["fexp"]) * len(ks), b"".join(k.to_bytes(32, "little") for k in ks), 0, len(ks), out))
+    for i, k in enumerate(ks):
+        assert out.raw[i * c.gt_bytes : (i + 1) * c.gt_bytes] == R.gt_to_mont_bytes(cp, T.f12_pow(f, k)), k
+
+
+def test_PairingProduct_shared_final_exp(curve):
+    """prod_i e(P_i, Q_i) with one FExp == product of the individually exponentiated pairings (17 pairs:
+    exercises the odd-sized tree), the empty product is one, and e(P,Q) e(-P,Q) == 1."""
+    c = curve
+    g1s = [c.GenG1().Mul(c.NewRandomZr(c._rng)) for _ in range(17)]
+    g2s = [c._gen_g2.Mul(c.NewRandomZr(c._rng)) for _ in range(17)]
+    prod = c.PairingProduct(g2s, g1s)
+    acc = None
+    for gt in c.PairingBatch(g2s, g1s):
+        if acc is None:
+            acc = gt
+        else:
+            acc.Mul(gt)
+    assert prod.Equals(acc)
+    assert c.PairingProduct([], []).IsUnity()
+    n = g1s[0].Copy()
+    n.Neg()
+    assert c.PairingProduct([g2s[0], g2s[0]], [g1s[0], n]).IsUnity()
