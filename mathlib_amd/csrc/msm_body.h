@@ -120,17 +120,19 @@ MLHIP_HD void msm_accumulate_range(XYZZ<F>& acc, const Affine<F>* points, const 
 
 // ---- bucket reduction, level 1 ---------------------------------------------------------------
 // Thread t of window w owns buckets [t*L, (t+1)*L): A = sum B_b ; W0 = sum_i i * B_{tL+i}.
-template <class F, int L>
-MLHIP_HD void msm_chunk_body(size_t g, const XYZZ<F>* buckets, XYZZ<F>* A, XYZZ<F>* W0, int l_eff) {
+// `add(acc, q)` is the group addition to use: the kernels pass an out-of-line copy (one ~90 KB body per
+// kernel instead of three inlined ones), the host test passes xyzz_add itself.
+template <class F, class AddFn>
+MLHIP_HD void msm_chunk_body(size_t g, const XYZZ<F>* buckets, XYZZ<F>* A, XYZZ<F>* W0, int l_eff, AddFn add) {
   const XYZZ<F>* b = buckets + g * (size_t)l_eff;
   XYZZ<F> acc, w0;
   xyzz_set_inf<F>(acc);
   xyzz_set_inf<F>(w0);
   for (int i = l_eff - 1; i >= 1; i--) {
-    xyzz_add<F>(acc, b[i]);
-    xyzz_add<F>(w0, acc);
+    add(acc, b[i]);
+    add(w0, acc);
   }
-  xyzz_add<F>(acc, b[0]);
+  add(acc, b[0]);
   A[g] = acc;
   W0[g] = w0;
 }

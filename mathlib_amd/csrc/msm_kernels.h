@@ -22,7 +22,7 @@
 
 namespace mlhip {
 
-constexpr uint32_t BIG_BUCKET = 256;  // entries above which a bucket is summed by a whole workgroup
+constexpr uint32_t BIG_BUCKET_MIN = 256;  // a bucket is summed by a whole workgroup above max(this, 8 x the mean length)
 constexpr int CHUNK_L = 8;            // buckets per level-1 reduction thread
 
 // ------------------------------------------------------------------------------------ kernels
@@ -349,14 +349,14 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
                                                     const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets,
                                                     const uint32_t* __restrict__ counts, size_t n_buckets,
-                                                    const uint32_t* __restrict__ order,
+                                                    const uint32_t* __restrict__ order, uint32_t big_threshold,
                                                     uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
                                                     XYZZ<F>* __restrict__ buckets) {
   size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n_buckets) return;
   const size_t g = order[tid];  // buckets sorted by population: a wave's lanes run equally long loops
   uint32_t cnt = counts[g];
-  if (cnt > BIG_BUCKET) {
+  if (cnt > big_threshold) {
     uint32_t pos = atomicAdd(big_count, 1u);
     big_list[pos] = (uint32_t)g;
     return;
@@ -368,6 +368,20 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
   buckets[g] = acc;
 }
 
+// out-of-line group operations for kernels that use several of them (bounds the code size)
+template <class F>
+__device__ __noinline__ void xyzz_madd_ool(XYZZ<F>& acc, const Affine<F>& q) {
+  xyzz_madd<F>(acc, q, false);
+}
+template <class F>
+__device__ __noinline__ void xyzz_add_ool(XYZZ<F>& acc, const XYZZ<F>& q) {
+  xyzz_add<F>(acc, q);
+}
+template <class F>
+__device__ __noinline__ void xyzz_dbl_ool(XYZZ<F>& r, const XYZZ<F>& p) {
+  xyzz_dbl<F>(r, p);
+}
+
 // LDS tree sum of one XYZZ per thread; result valid in sh[0] after return (all threads must call)
 template <class F, int BLOCK>
 __device__ void block_tree_sum(XYZZ<F>* sh, const XYZZ<F>& mine) {
@@ -377,7 +391,7 @@ __device__ void block_tree_sum(XYZZ<F>* sh, const XYZZ<F>& mine) {
   for (int s = BLOCK / 2; s > 0; s >>= 1) {
     if (tid < s) {
       XYZZ<F> a = sh[tid];
-      xyzz_add<F>(a, sh[tid + s]);
+      xyzz_add_ool<F>(a, sh[tid + s]);
       sh[tid] = a;
     }
     __syncthreads();
@@ -413,7 +427,7 @@ __global__ void __launch_bounds__(256) k_chunks(const XYZZ<F>* __restrict__ buck
                                                 XYZZ<F>* __restrict__ A, XYZZ<F>* __restrict__ W0) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_chunks) return;
-  msm_chunk_body<F, CHUNK_L>(g, buckets, A, W0, l_eff);
+  msm_chunk_body<F>(g, buckets, A, W0, l_eff, [](XYZZ<F>& a, const XYZZ<F>& q) { xyzz_add_ool<F>(a, q); });
 }
 
 // block (w, sel): sel 0 -> sum_t W0[w][t]; sel 1 -> sum_t A[w][t]; sel 2+k -> sum over t with bit k set of A[w][t]
@@ -428,13 +442,13 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums(const XYZZ<F>* __restrict
   XYZZ<F> acc;
   xyzz_set_inf<F>(acc);
   if (sel < 2) {
-    for (uint32_t t = threadIdx.x; t < T; t += BLOCK) xyzz_add<F>(acc, src[t]);
+    for (uint32_t t = threadIdx.x; t < T; t += BLOCK) xyzz_add_ool<F>(acc, src[t]);
   } else {
     const int k = sel - 2;
     const uint32_t lowmask = (1u << k) - 1u;
     for (uint32_t j = threadIdx.x; j < T / 2; j += BLOCK) {
       uint32_t t = ((j >> k) << (k + 1)) | (1u << k) | (j & lowmask);
-      xyzz_add<F>(acc, src[t]);
+      xyzz_add_ool<F>(acc, src[t]);
     }
   }
   block_tree_sum<F, BLOCK>(sh, acc);
@@ -444,20 +458,6 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums(const XYZZ<F>* __restrict
 // out[i] = [s_i] P_i: batched single-scalar multiplication (the reference's G1.Mul / G2.Mul,
 // driver/gurvy/bls12381/bls12-381.go:238-247, :342-351; double-and-add shape of :920-932), one lane per
 // product, 4-bit fixed windows: 15-entry table in scratch, 4 doublings + 1 addition per window.
-// out-of-line group operations for kernels that use several of them (bounds the code size)
-template <class F>
-__device__ __noinline__ void xyzz_madd_ool(XYZZ<F>& acc, const Affine<F>& q) {
-  xyzz_madd<F>(acc, q, false);
-}
-template <class F>
-__device__ __noinline__ void xyzz_add_ool(XYZZ<F>& acc, const XYZZ<F>& q) {
-  xyzz_add<F>(acc, q);
-}
-template <class F>
-__device__ __noinline__ void xyzz_dbl_ool(XYZZ<F>& r, const XYZZ<F>& p) {
-  xyzz_dbl<F>(r, p);
-}
-
 template <class C, class F>
 __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__ points, size_t point_stride,
                                                    const uint32_t* __restrict__ scalars, int mont, size_t n,
@@ -596,6 +596,11 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
   if (n != 0) {
     const size_t nbuckets = (size_t)p->W * p->M;
     const bool prof = p->profiling;
+    // Buckets far longer than the mean (degenerate inputs: equal scalars, tiny scalars) are handed to a whole
+    // workgroup each; the threshold scales with the mean length n / 2^(c-1) so that large n, and the sparser top
+    // window (2-4x the mean for these group orders), stay on the one-thread-per-bucket path.
+    uint32_t big_threshold = (uint32_t)std::min<size_t>((n >> (p->c - 1)) * 8, 1u << 30);
+    if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
     HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
     if (prof) HIPCHK(hipEventRecord(p->ev[0], st));
     if (p->sort_low > 0) {
@@ -637,7 +642,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[2], st));
     k_accumulate<F><<<dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st>>>(
-        (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, p->d_biglist,
+        (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
         p->d_bigcount, (X*)p->d_buckets);
     if (prof) HIPCHK(hipEventRecord(p->ev[3], st));
     {

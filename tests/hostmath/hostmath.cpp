@@ -143,7 +143,8 @@ struct Ops {
     const A1* p = (const A1*)pts;
     std::vector<X1> b(n_chunks * 8), A(n_chunks), W0(n_chunks);
     for (int i = 0; i < n_chunks * 8; i++) xyzz_from_affine<FpField<C>>(b[i], p[i]);
-    for (int g = 0; g < n_chunks; g++) msm_chunk_body<FpField<C>, 8>(g, b.data(), A.data(), W0.data(), 8);
+    for (int g = 0; g < n_chunks; g++) msm_chunk_body<FpField<C>>(g, b.data(), A.data(), W0.data(), 8,
+                                                                  [](X1& a, const X1& q) { xyzz_add<FpField<C>>(a, q); });
     for (int g = 0; g < n_chunks; g++) {
       A1 r;
       xyzz_to_affine<FpField<C>>(r, A[g]);
