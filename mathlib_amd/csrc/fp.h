@@ -67,17 +67,42 @@ MLHIP_HD bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
   return o == 0;
 }
 
+// Carry-chain primitives.  clang's __builtin_addc / __builtin_subc lower to v_addc_co_u32 / v_subb_co_u32
+// chains on gfx950 (hipcc pads their VCC hazards itself); other compilers (the g++ host-test build) get
+// the portable 64-bit form.
+#if defined(__clang__)
+MLHIP_HD uint32_t mlhip_addc(uint32_t a, uint32_t b, uint32_t& c) {
+  unsigned co;
+  uint32_t r = __builtin_addc(a, b, c, &co);
+  c = co;
+  return r;
+}
+MLHIP_HD uint32_t mlhip_subb(uint32_t a, uint32_t b, uint32_t& br) {
+  unsigned bo;
+  uint32_t r = __builtin_subc(a, b, br, &bo);
+  br = bo;
+  return r;
+}
+#else
+MLHIP_HD uint32_t mlhip_addc(uint32_t a, uint32_t b, uint32_t& c) {
+  uint64_t s = (uint64_t)a + b + c;
+  c = (uint32_t)(s >> 32);
+  return (uint32_t)s;
+}
+MLHIP_HD uint32_t mlhip_subb(uint32_t a, uint32_t b, uint32_t& br) {
+  uint64_t s = (uint64_t)a - b - br;
+  br = (uint32_t)((s >> 32) & 1);
+  return (uint32_t)s;
+}
+#endif
+
 // r = t - p if t >= p else t   (t < 2p)
 template <class C>
 MLHIP_HD void fp_reduce_once(Fp<C>& r, const uint32_t (&t)[C::N]) {
   uint32_t d[C::N];
-  uint64_t br = 0;
+  uint32_t br = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; i++) {
-    uint64_t s = (uint64_t)t[i] - C::P[i] - br;
-    d[i] = (uint32_t)s;
-    br = (s >> 32) & 1;
-  }
+  for (int i = 0; i < C::N; i++) d[i] = mlhip_subb(t[i], C::P[i], br);
 #pragma unroll
   for (int i = 0; i < C::N; i++) r.l[i] = br ? t[i] : d[i];
 }
@@ -85,13 +110,9 @@ MLHIP_HD void fp_reduce_once(Fp<C>& r, const uint32_t (&t)[C::N]) {
 template <class C>
 MLHIP_HD void fp_add(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
   uint32_t t[C::N];
-  uint64_t c = 0;
+  uint32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; i++) {
-    uint64_t s = (uint64_t)a.l[i] + b.l[i] + c;
-    t[i] = (uint32_t)s;
-    c = s >> 32;
-  }
+  for (int i = 0; i < C::N; i++) t[i] = mlhip_addc(a.l[i], b.l[i], c);
   // p < 2^(32N-1) for all three curves, so a + b < 2p never carries out of N limbs
   fp_reduce_once<C>(r, t);
 }
@@ -104,22 +125,14 @@ MLHIP_HD void fp_dbl(Fp<C>& r, const Fp<C>& a) {
 template <class C>
 MLHIP_HD void fp_sub(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
   uint32_t d[C::N];
-  uint64_t br = 0;
+  uint32_t br = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; i++) {
-    uint64_t s = (uint64_t)a.l[i] - b.l[i] - br;
-    d[i] = (uint32_t)s;
-    br = (s >> 32) & 1;
-  }
+  for (int i = 0; i < C::N; i++) d[i] = mlhip_subb(a.l[i], b.l[i], br);
   // add p back when the subtraction borrowed
-  uint32_t mask = (uint32_t)0 - (uint32_t)br;
-  uint64_t c = 0;
+  uint32_t mask = (uint32_t)0 - br;
+  uint32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; i++) {
-    uint64_t s = (uint64_t)d[i] + (C::P[i] & mask) + c;
-    r.l[i] = (uint32_t)s;
-    c = s >> 32;
-  }
+  for (int i = 0; i < C::N; i++) r.l[i] = mlhip_addc(d[i], C::P[i] & mask, c);
 }
 
 template <class C>
@@ -129,13 +142,9 @@ MLHIP_HD void fp_neg(Fp<C>& r, const Fp<C>& a) {
 #pragma unroll
   for (int i = 0; i < C::N; i++) nz |= a.l[i];
   uint32_t mask = nz ? 0xffffffffu : 0u;
-  uint64_t br = 0;
+  uint32_t br = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; i++) {
-    uint64_t s = (uint64_t)(C::P[i] & mask) - a.l[i] - br;
-    r.l[i] = (uint32_t)s;
-    br = (s >> 32) & 1;
-  }
+  for (int i = 0; i < C::N; i++) r.l[i] = mlhip_subb(C::P[i] & mask, a.l[i], br);
 }
 
 // r = c ? a : b
