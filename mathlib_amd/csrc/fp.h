@@ -259,6 +259,14 @@ __device__ __forceinline__ void fp_mul_device(Fp<C>& r, const Fp<C>& a, const Fp
   else
     fp_mul_comba8<C>(r, a, b);
 }
+// r = (a*b + c*d) R^-1 mod p with one shared Montgomery reduction (fp2_lanes.h)
+template <class C>
+__device__ __forceinline__ void fp_mul2_device(Fp<C>& r, const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) {
+  if constexpr (C::N == 12)
+    fp_mul2_comba12<C>(r, a, b, c, d);
+  else
+    fp_mul2_comba8<C>(r, a, b, c, d);
+}
 #endif
 
 // Inlined entry points: used where the caller keeps its operands in registers (the G1 bucket

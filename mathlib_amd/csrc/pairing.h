@@ -18,14 +18,14 @@
 
 namespace mlhip {
 
-template <class C>
+template <class C, class E2 = Fp2<C>>
 struct G2Proj {
-  Fp2<C> x, y, z;
+  E2 x, y, z;
 };
 
-template <class C>
+template <class C, class E2 = Fp2<C>>
 struct Line {
-  Fp2<C> r0, r1, r2;  // r0 pairs with yP, r1 with xP, r2 is the constant coefficient
+  E2 r0, r1, r2;  // r0 pairs with yP, r1 with xP, r2 is the constant coefficient
 };
 
 template <class C>
@@ -52,9 +52,9 @@ MLHIP_HD void fp2_halve(Fp2<C>& r, const Fp2<C>& a) {
 }
 
 // T <- 2T, line through T,T
-template <class C>
-MLHIP_HD_NOINLINE void g2_double_step(G2Proj<C>& T, Line<C>& l) {
-  Fp2<C> A, B, Cc, E, F, G, H, I, J, EE, t, b3;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void g2_double_step(G2Proj<C, E2>& T, Line<C, E2>& l) {
+  E2 A, B, Cc, E, F, G, H, I, J, EE, t, b3;
   fp2_mul<C>(A, T.x, T.y);
   fp2_halve<C>(A, A);
   fp2_sqr<C>(B, T.y);
@@ -87,9 +87,9 @@ MLHIP_HD_NOINLINE void g2_double_step(G2Proj<C>& T, Line<C>& l) {
 }
 
 // T <- T + Q (Q affine), line through T,Q
-template <class C>
-MLHIP_HD_NOINLINE void g2_add_step(G2Proj<C>& T, const Fp2<C>& qx, const Fp2<C>& qy, Line<C>& l) {
-  Fp2<C> O, L, Cc, D, E, F, G, H, t, t2;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void g2_add_step(G2Proj<C, E2>& T, const E2& qx, const E2& qy, Line<C, E2>& l) {
+  E2 O, L, Cc, D, E, F, G, H, t, t2;
   fp2_mul<C>(t, qy, T.z);
   fp2_sub<C>(O, T.y, t);
   fp2_mul<C>(t, qx, T.z);
@@ -116,9 +116,9 @@ MLHIP_HD_NOINLINE void g2_add_step(G2Proj<C>& T, const Fp2<C>& qx, const Fp2<C>&
   fp2_neg<C>(l.r1, O);
 }
 
-template <class C>
-MLHIP_HD void mul_by_line(Fp12<C>& f, const Line<C>& l, const Fp<C>& px, const Fp<C>& py) {
-  Fp2<C> a, b;
+template <class C, class E2>
+MLHIP_HD void mul_by_line(Fp12<C, E2>& f, const Line<C, E2>& l, const Fp<C>& px, const Fp<C>& py) {
+  E2 a, b;
   fp2_mul_fp<C>(a, l.r0, py);
   fp2_mul_fp<C>(b, l.r1, px);
   if (C::MTWIST)
@@ -128,23 +128,22 @@ MLHIP_HD void mul_by_line(Fp12<C>& f, const Line<C>& l, const Fp<C>& px, const F
 }
 
 // f = prod_k f_{loop,Q_k}(P_k) over n_pairs pairs (shared squaring chain: the reference's Pairing2,
-// driver/gurvy/bls12381/bls12-381.go:457-464).  Pairs containing infinity are skipped, as gnark does.
-// MAXP bounds n_pairs (state is kept per pair).
-template <class C, int MAXP>
-MLHIP_HD void miller_loop(Fp12<C>& f, const Affine<FpField<C>>* P, const Affine<Fp2Field<C>>* Q, int n_pairs) {
-  G2Proj<C> T[MAXP];
-  bool live[MAXP];
+// driver/gurvy/bls12381/bls12-381.go:457-464).  Pairs flagged not live (one side at infinity) are skipped, as
+// gnark does.  MAXP bounds n_pairs (state is kept per pair).  Coordinates: px/py in Fp, qx/qy in E2.
+template <class C, int MAXP, class E2>
+MLHIP_HD void miller_loop_core(Fp12<C, E2>& f, const Fp<C>* px, const Fp<C>* py, const E2* qx, const E2* qy,
+                               const bool* live, int n_pairs) {
+  G2Proj<C, E2> T[MAXP];
   int any = 0;
   for (int k = 0; k < n_pairs && k < MAXP; k++) {
-    live[k] = !(affine_is_inf<FpField<C>>(P[k]) | affine_is_inf<Fp2Field<C>>(Q[k]));
-    T[k].x = Q[k].x;
-    T[k].y = Q[k].y;
+    T[k].x = qx[k];
+    T[k].y = qy[k];
     fp2_one<C>(T[k].z);
     any |= live[k];
   }
   fp12_one<C>(f);
   if (!any) return;
-  Line<C> l;
+  Line<C, E2> l;
   bool first = true;
   for (int i = C::ATE_BITS - 2; i >= 0; i--) {
     if (!first) fp12_sqr<C>(f, f);
@@ -153,10 +152,10 @@ MLHIP_HD void miller_loop(Fp12<C>& f, const Affine<FpField<C>>* P, const Affine<
     for (int k = 0; k < n_pairs && k < MAXP; k++) {
       if (!live[k]) continue;
       g2_double_step<C>(T[k], l);
-      mul_by_line<C>(f, l, P[k].x, P[k].y);
+      mul_by_line<C>(f, l, px[k], py[k]);
       if (bit) {
-        g2_add_step<C>(T[k], Q[k].x, Q[k].y, l);
-        mul_by_line<C>(f, l, P[k].x, P[k].y);
+        g2_add_step<C>(T[k], qx[k], qy[k], l);
+        mul_by_line<C>(f, l, px[k], py[k]);
       }
     }
   }
@@ -164,31 +163,45 @@ MLHIP_HD void miller_loop(Fp12<C>& f, const Affine<FpField<C>>* P, const Affine<
     // lines through pi(Q) and -pi^2(Q)
     for (int k = 0; k < n_pairs && k < MAXP; k++) {
       if (!live[k]) continue;
-      Fp2<C> x1, y1, x2, y2, g;
-      fp2_conj<C>(x1, Q[k].x);
+      E2 x1, y1, x2, y2, g;
+      fp2_conj<C>(x1, qx[k]);
       fp2_from_const<C>(g, C::GAMMA1[2]);
       fp2_mul<C>(x1, x1, g);
-      fp2_conj<C>(y1, Q[k].y);
+      fp2_conj<C>(y1, qy[k]);
       fp2_from_const<C>(g, C::GAMMA1[3]);
       fp2_mul<C>(y1, y1, g);
-      fp2_from_const<C>(g, C::GAMMA2[2]);
-      fp2_mul<C>(x2, Q[k].x, g);
-      fp2_from_const<C>(g, C::GAMMA2[3]);
-      fp2_mul<C>(y2, Q[k].y, g);
+      fp2_mul_by_real_const<C>(x2, qx[k], C::GAMMA2[2]);
+      fp2_mul_by_real_const<C>(y2, qy[k], C::GAMMA2[3]);
       fp2_neg<C>(y2, y2);
       g2_add_step<C>(T[k], x1, y1, l);
-      mul_by_line<C>(f, l, P[k].x, P[k].y);
+      mul_by_line<C>(f, l, px[k], py[k]);
       g2_add_step<C>(T[k], x2, y2, l);
-      mul_by_line<C>(f, l, P[k].x, P[k].y);
+      mul_by_line<C>(f, l, px[k], py[k]);
     }
   }
   if (C::X_NEG) fp12_conj<C>(f, f);
 }
 
+// one-element-per-lane entry point over the C-ABI point types
+template <class C, int MAXP>
+MLHIP_HD void miller_loop(Fp12<C>& f, const Affine<FpField<C>>* P, const Affine<Fp2Field<C>>* Q, int n_pairs) {
+  Fp<C> px[MAXP], py[MAXP];
+  Fp2<C> qx[MAXP], qy[MAXP];
+  bool live[MAXP];
+  for (int k = 0; k < n_pairs && k < MAXP; k++) {
+    live[k] = !(affine_is_inf<FpField<C>>(P[k]) | affine_is_inf<Fp2Field<C>>(Q[k]));
+    px[k] = P[k].x;
+    py[k] = P[k].y;
+    qx[k] = Q[k].x;
+    qy[k] = Q[k].y;
+  }
+  miller_loop_core<C, MAXP, Fp2<C>>(f, px, py, qx, qy, live, n_pairs);
+}
+
 // z^|x| by cyclotomic squarings (z in the cyclotomic subgroup), conjugated when the seed is negative
-template <class C>
-MLHIP_HD_NOINLINE void fp12_expt(Fp12<C>& r, const Fp12<C>& z) {
-  Fp12<C> acc = z;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_expt(Fp12<C, E2>& r, const Fp12<C, E2>& z) {
+  Fp12<C, E2> acc = z;
   int top = 63;
   while (!((C::X_ABS >> top) & 1)) top--;
   for (int i = top - 1; i >= 0; i--) {
@@ -200,9 +213,9 @@ MLHIP_HD_NOINLINE void fp12_expt(Fp12<C>& r, const Fp12<C>& z) {
 }
 
 // r = f^(k (p^12 - 1)/r_order): the reference's FExp (bls12-381.go:466-468 etc.)
-template <class C>
-MLHIP_HD void final_exp(Fp12<C>& out, const Fp12<C>& f) {
-  Fp12<C> r, t0, t1, t2;
+template <class C, class E2>
+MLHIP_HD void final_exp(Fp12<C, E2>& out, const Fp12<C, E2>& f) {
+  Fp12<C, E2> r, t0, t1, t2;
   // easy part: f^((p^6-1)(p^2+1))
   fp12_conj<C>(t0, f);
   fp12_inv<C>(t1, f);
@@ -232,7 +245,7 @@ MLHIP_HD void final_exp(Fp12<C>& out, const Fp12<C>& f) {
   } else {
     // hard part, exponent l0 + l1 p + l2 p^2 + l3 p^3 = 2x(6x^2+3x+1) (p^4-p^2+1)/r
     //   a = 12x^3+6x^2+6x ; b = a - 2x ; l0 = a + 6x^2 + 1 ; l1 = b ; l2 = a ; l3 = b - 1
-    Fp12<C> fx, f2x, f6x, f6x2, f12x3, a, b;
+    Fp12<C, E2> fx, f2x, f6x, f6x2, f12x3, a, b;
     fp12_expt<C>(fx, r);
     fp12_cyclo_sqr<C>(f2x, fx);
     fp12_cyclo_sqr<C>(t0, f2x);  // 4x

@@ -2,8 +2,11 @@
 // Included by tu_pairing_<curve>.hip.  Replaces MillerLoop / FinalExponentiation behind the reference's
 // Pairing, Pairing2 and FExp (driver/gurvy/bls12381/bls12-381.go:448-468, bn254.go:247-267, bls12-377.go:244-264).
 #pragma once
+#include <cstdlib>
+
 #include "mlhip_internal.h"
 #include "msm_body.h"
+#include "fp2_lanes.h"
 #include "pairing.h"
 
 namespace mlhip {
@@ -40,6 +43,73 @@ __global__ void __launch_bounds__(64) k_pairing(const Affine<FpField<C>>* __rest
   out[i] = r;
 }
 
+// ---- lane-pair kernels: two adjacent lanes per pairing, one Fp2 component each (fp2_lanes.h) ----------
+template <class C>
+MLHIP_HD void fp2_halve(Fp2L<C>& r, const Fp2L<C>& a) {
+  fp_halve<C>(r.v, a.v);
+}
+
+template <class C>
+__device__ __forceinline__ void lp_store_gt(Fp12<C>* out, size_t i, const Fp12<C, Fp2L<C>>& f) {
+  // Fp12 memory order: c0.c0 c0.c1 c0.c2 c1.c0 c1.c1 c1.c2, each {c0, c1}; this lane owns component hi
+  Fp<C>* o = reinterpret_cast<Fp<C>*>(out + i) + (lane_is_hi() ? 1 : 0);
+  o[0] = f.c0.c0.v;
+  o[2] = f.c0.c1.v;
+  o[4] = f.c0.c2.v;
+  o[6] = f.c1.c0.v;
+  o[8] = f.c1.c1.v;
+  o[10] = f.c1.c2.v;
+}
+template <class C>
+__device__ __forceinline__ void lp_load_gt(Fp12<C, Fp2L<C>>& f, const Fp12<C>* in, size_t i) {
+  const Fp<C>* o = reinterpret_cast<const Fp<C>*>(in + i) + (lane_is_hi() ? 1 : 0);
+  f.c0.c0.v = o[0];
+  f.c0.c1.v = o[2];
+  f.c0.c2.v = o[4];
+  f.c1.c0.v = o[6];
+  f.c1.c1.v = o[8];
+  f.c1.c2.v = o[10];
+}
+
+// what: 0 = Miller loop of ppp pairs per product, 1 = final exponentiation, 2 = Miller (1 pair) + final exp
+template <class C, int WHAT>
+__global__ void __launch_bounds__(64) k_pairing_lp(const Affine<FpField<C>>* __restrict__ g1,
+                                                   const Affine<Fp2Field<C>>* __restrict__ g2, int ppp, size_t n,
+                                                   const Fp12<C>* __restrict__ in, Fp12<C>* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = t >> 1;  // both lanes of a pair share i, so this exit is pair-uniform
+  if (i >= n) return;
+  typedef Fp2L<C> E2;
+  Fp12<C, E2> f, r;
+  if (WHAT == 1) {
+    lp_load_gt<C>(f, in, i);
+  } else {
+    Fp<C> px[4], py[4];
+    E2 qx[4], qy[4];
+    bool live[4];
+    const int hi = lane_is_hi() ? 1 : 0;
+    for (int k = 0; k < ppp && k < 4; k++) {
+      const Affine<FpField<C>> P = g1[i * ppp + k];
+      const Fp<C>* q = reinterpret_cast<const Fp<C>*>(g2 + i * ppp + k);
+      px[k] = P.x;
+      py[k] = P.y;
+      qx[k].v = q[hi];
+      qy[k].v = q[2 + hi];
+      // Q is the point at infinity iff all four of its Fp components are zero
+      uint32_t zq = (fp_is_zero<C>(qx[k].v) & fp_is_zero<C>(qy[k].v)) ? 1u : 0u;
+      zq &= pair_xchg_u32(zq);
+      live[k] = !(affine_is_inf<FpField<C>>(P) | (zq != 0));
+    }
+    miller_loop_core<C, 4, E2>(f, px, py, qx, qy, live, ppp);
+  }
+  if (WHAT == 0) {
+    lp_store_gt<C>(out, i, f);
+  } else {
+    final_exp<C>(r, f);
+    lp_store_gt<C>(out, i, r);
+  }
+}
+
 template <class C>
 __global__ void __launch_bounds__(256) k_fp_mul(const Fp<C>* __restrict__ a, const Fp<C>* __restrict__ b, size_t n,
                                                 int repeat, Fp<C>* __restrict__ out) {
@@ -51,28 +121,51 @@ __global__ void __launch_bounds__(256) k_fp_mul(const Fp<C>* __restrict__ a, con
   out[i] = r;
 }
 
+// The batched entry points run the lane-pair kernels (two lanes per pairing); the one-lane-per-pairing
+// kernels above stay as the reference shape (MLHIP_PAIRING_ONE_LANE=1 selects them; the tests run both).
 template <class C>
 int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, size_t n, const void* d_in, void* d_out,
                    hipStream_t st) {
   if (n == 0) return 0;
-  unsigned blocks = (unsigned)((n + 63) / 64);
   typedef Affine<FpField<C>> A1;
   typedef Affine<Fp2Field<C>> A2;
-  switch (what) {
-    case 0:
-      k_miller<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, (Fp12<C>*)d_out);
-      break;
-    case 1:
-      k_final_exp<C><<<dim3(blocks), dim3(64), 0, st>>>((const Fp12<C>*)d_in, n, (Fp12<C>*)d_out);
-      break;
-    default:
-      k_pairing<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, (Fp12<C>*)d_out);
-      break;
+  static const bool one_lane = [] {
+    const char* e = getenv("MLHIP_PAIRING_ONE_LANE");
+    return e && e[0] == '1';
+  }();
+  if (one_lane) {
+    unsigned blocks = (unsigned)((n + 63) / 64);
+    switch (what) {
+      case 0:
+        k_miller<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, (Fp12<C>*)d_out);
+        break;
+      case 1:
+        k_final_exp<C><<<dim3(blocks), dim3(64), 0, st>>>((const Fp12<C>*)d_in, n, (Fp12<C>*)d_out);
+        break;
+      default:
+        k_pairing<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, (Fp12<C>*)d_out);
+        break;
+    }
+  } else {
+    unsigned blocks = (unsigned)((2 * n + 63) / 64);
+    switch (what) {
+      case 0:
+        k_pairing_lp<C, 0><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, nullptr,
+                                                             (Fp12<C>*)d_out);
+        break;
+      case 1:
+        k_pairing_lp<C, 1><<<dim3(blocks), dim3(64), 0, st>>>(nullptr, nullptr, 1, n, (const Fp12<C>*)d_in,
+                                                             (Fp12<C>*)d_out);
+        break;
+      default:
+        k_pairing_lp<C, 2><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr,
+                                                             (Fp12<C>*)d_out);
+        break;
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;
 }
-
 
 // out[i] = a[i] * b[i] in Fp12 (Gt.Mul, reference driver/gurvy/bls12381/bls12-381.go:417-419)
 template <class C>

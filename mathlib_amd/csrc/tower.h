@@ -23,13 +23,15 @@ template <class C>
 struct Fp2 {
   Fp<C> c0, c1;
 };
-template <class C>
+// E2 is the Fp2 element type: Fp2<C> (one element per lane) or Fp2L<C> (fp2_lanes.h: one component per
+// lane, an element per lane pair).  Everything from Fp6 up is written against the fp2_* overload set.
+template <class C, class E2 = Fp2<C>>
 struct Fp6 {
-  Fp2<C> c0, c1, c2;
+  E2 c0, c1, c2;
 };
-template <class C>
+template <class C, class E2 = Fp2<C>>
 struct Fp12 {
-  Fp6<C> c0, c1;
+  Fp6<C, E2> c0, c1;
 };
 
 // ------------------------------------------------------------------ Fp2
@@ -184,50 +186,58 @@ MLHIP_HD void fp2_from_const(Fp2<C>& r, const uint32_t (&k)[2][C::N]) {
   fp_from_const<C>(r.c1, k[1]);
 }
 
-// ------------------------------------------------------------------ Fp6
+// r = a * Re(k) for a constant k whose imaginary part is zero (Frobenius^2 coefficients)
 template <class C>
-MLHIP_HD void fp6_zero(Fp6<C>& r) {
+MLHIP_HD void fp2_mul_by_real_const(Fp2<C>& r, const Fp2<C>& a, const uint32_t (&k)[2][C::N]) {
+  Fp<C> kr;
+  fp_from_const<C>(kr, k[0]);
+  fp2_mul_fp<C>(r, a, kr);
+}
+
+// ------------------------------------------------------------------ Fp6
+template <class C, class E2>
+MLHIP_HD void fp6_zero(Fp6<C, E2>& r) {
   fp2_zero<C>(r.c0);
   fp2_zero<C>(r.c1);
   fp2_zero<C>(r.c2);
 }
-template <class C>
-MLHIP_HD void fp6_add(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {
+template <class C, class E2>
+MLHIP_HD void fp6_add(Fp6<C, E2>& r, const Fp6<C, E2>& a, const Fp6<C, E2>& b) {
   fp2_add<C>(r.c0, a.c0, b.c0);
   fp2_add<C>(r.c1, a.c1, b.c1);
   fp2_add<C>(r.c2, a.c2, b.c2);
 }
-template <class C>
-MLHIP_HD void fp6_sub(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {
+template <class C, class E2>
+MLHIP_HD void fp6_sub(Fp6<C, E2>& r, const Fp6<C, E2>& a, const Fp6<C, E2>& b) {
   fp2_sub<C>(r.c0, a.c0, b.c0);
   fp2_sub<C>(r.c1, a.c1, b.c1);
   fp2_sub<C>(r.c2, a.c2, b.c2);
 }
-template <class C>
-MLHIP_HD void fp6_neg(Fp6<C>& r, const Fp6<C>& a) {
+template <class C, class E2>
+MLHIP_HD void fp6_neg(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
   fp2_neg<C>(r.c0, a.c0);
   fp2_neg<C>(r.c1, a.c1);
   fp2_neg<C>(r.c2, a.c2);
 }
-template <class C>
-MLHIP_HD void fp6_dbl(Fp6<C>& r, const Fp6<C>& a) {
+template <class C, class E2>
+MLHIP_HD void fp6_dbl(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
   fp2_dbl<C>(r.c0, a.c0);
   fp2_dbl<C>(r.c1, a.c1);
   fp2_dbl<C>(r.c2, a.c2);
 }
 // r = v * a
-template <class C>
-MLHIP_HD void fp6_mul_v(Fp6<C>& r, const Fp6<C>& a) {
-  Fp2<C> t;
+template <class C, class E2>
+MLHIP_HD void fp6_mul_v(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
+  E2 t;
   fp2_mul_xi<C>(t, a.c2);
   r.c2 = a.c1;
   r.c1 = a.c0;
   r.c0 = t;
 }
 
-template <class C>
-MLHIP_HD_NOINLINE void fp6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {
-  Fp2<C> t0, t1, t2, s0, s1, x0, x1, x2;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp6_mul(Fp6<C, E2>& r, const Fp6<C, E2>& a, const Fp6<C, E2>& b) {
+  E2 t0, t1, t2, s0, s1, x0, x1, x2;
   fp2_mul<C>(t0, a.c0, b.c0);
   fp2_mul<C>(t1, a.c1, b.c1);
   fp2_mul<C>(t2, a.c2, b.c2);
@@ -259,10 +269,10 @@ MLHIP_HD_NOINLINE void fp6_mul(Fp6<C>& r, const Fp6<C>& a, const Fp6<C>& b) {
   r.c2 = x2;
 }
 
-template <class C>
-MLHIP_HD_NOINLINE void fp6_sqr(Fp6<C>& r, const Fp6<C>& a) {
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp6_sqr(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
   // Chung-Hasan SQR2
-  Fp2<C> s0, s1, s2, s3, s4, t;
+  E2 s0, s1, s2, s3, s4, t;
   fp2_sqr<C>(s0, a.c0);
   fp2_mul<C>(s1, a.c0, a.c1);
   fp2_dbl<C>(s1, s1);
@@ -284,9 +294,9 @@ MLHIP_HD_NOINLINE void fp6_sqr(Fp6<C>& r, const Fp6<C>& a) {
 }
 
 // r = a * (b0 + b1 v)
-template <class C>
-MLHIP_HD_NOINLINE void fp6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0, const Fp2<C>& b1) {
-  Fp2<C> t0, t1, t2, x0, x1, x2, s0, s1;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp6_mul_by_01(Fp6<C, E2>& r, const Fp6<C, E2>& a, const E2& b0, const E2& b1) {
+  E2 t0, t1, t2, x0, x1, x2, s0, s1;
   fp2_mul<C>(t0, a.c0, b0);
   fp2_mul<C>(t1, a.c1, b1);
   // c0 = a0 b0 + xi a2 b1
@@ -308,9 +318,9 @@ MLHIP_HD_NOINLINE void fp6_mul_by_01(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b
 }
 
 // r = a * (b1 v)
-template <class C>
-MLHIP_HD void fp6_mul_by_1(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b1) {
-  Fp2<C> x0, x1, x2;
+template <class C, class E2>
+MLHIP_HD void fp6_mul_by_1(Fp6<C, E2>& r, const Fp6<C, E2>& a, const E2& b1) {
+  E2 x0, x1, x2;
   fp2_mul<C>(x0, a.c2, b1);
   fp2_mul_xi<C>(x0, x0);
   fp2_mul<C>(x1, a.c0, b1);
@@ -321,16 +331,16 @@ MLHIP_HD void fp6_mul_by_1(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b1) {
 }
 
 // r = a * b0  (b0 in Fp2)
-template <class C>
-MLHIP_HD void fp6_mul_by_0(Fp6<C>& r, const Fp6<C>& a, const Fp2<C>& b0) {
+template <class C, class E2>
+MLHIP_HD void fp6_mul_by_0(Fp6<C, E2>& r, const Fp6<C, E2>& a, const E2& b0) {
   fp2_mul<C>(r.c0, a.c0, b0);
   fp2_mul<C>(r.c1, a.c1, b0);
   fp2_mul<C>(r.c2, a.c2, b0);
 }
 
-template <class C>
-MLHIP_HD_NOINLINE void fp6_inv(Fp6<C>& r, const Fp6<C>& a) {
-  Fp2<C> c0, c1, c2, t, u;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp6_inv(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
+  E2 c0, c1, c2, t, u;
   // c0 = a0^2 - xi a1 a2 ; c1 = xi a2^2 - a0 a1 ; c2 = a1^2 - a0 a2
   fp2_sqr<C>(c0, a.c0);
   fp2_mul<C>(t, a.c1, a.c2);
@@ -357,26 +367,26 @@ MLHIP_HD_NOINLINE void fp6_inv(Fp6<C>& r, const Fp6<C>& a) {
 }
 
 // ------------------------------------------------------------------ Fp12
-template <class C>
-MLHIP_HD void fp12_one(Fp12<C>& r) {
+template <class C, class E2>
+MLHIP_HD void fp12_one(Fp12<C, E2>& r) {
   fp6_zero<C>(r.c0);
   fp6_zero<C>(r.c1);
-  fp_one<C>(r.c0.c0.c0);
+  fp2_one<C>(r.c0.c0);
 }
-template <class C>
-MLHIP_HD bool fp12_eq(const Fp12<C>& a, const Fp12<C>& b) {
+template <class C, class E2>
+MLHIP_HD bool fp12_eq(const Fp12<C, E2>& a, const Fp12<C, E2>& b) {
   return fp2_eq<C>(a.c0.c0, b.c0.c0) & fp2_eq<C>(a.c0.c1, b.c0.c1) & fp2_eq<C>(a.c0.c2, b.c0.c2) &
          fp2_eq<C>(a.c1.c0, b.c1.c0) & fp2_eq<C>(a.c1.c1, b.c1.c1) & fp2_eq<C>(a.c1.c2, b.c1.c2);
 }
-template <class C>
-MLHIP_HD void fp12_conj(Fp12<C>& r, const Fp12<C>& a) {
+template <class C, class E2>
+MLHIP_HD void fp12_conj(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   r.c0 = a.c0;
   fp6_neg<C>(r.c1, a.c1);
 }
 
-template <class C>
-MLHIP_HD_NOINLINE void fp12_mul(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) {
-  Fp6<C> t0, t1, s0, s1, x;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_mul(Fp12<C, E2>& r, const Fp12<C, E2>& a, const Fp12<C, E2>& b) {
+  Fp6<C, E2> t0, t1, s0, s1, x;
   fp6_mul<C>(t0, a.c0, b.c0);
   fp6_mul<C>(t1, a.c1, b.c1);
   fp6_add<C>(s0, a.c0, a.c1);
@@ -388,10 +398,10 @@ MLHIP_HD_NOINLINE void fp12_mul(Fp12<C>& r, const Fp12<C>& a, const Fp12<C>& b) 
   fp6_add<C>(r.c0, t0, t1);
 }
 
-template <class C>
-MLHIP_HD_NOINLINE void fp12_sqr(Fp12<C>& r, const Fp12<C>& a) {
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   // complex squaring: c0 = (a0+a1)(a0+v a1) - ab - v ab ; c1 = 2ab
-  Fp6<C> ab, s0, s1, t;
+  Fp6<C, E2> ab, s0, s1, t;
   fp6_mul<C>(ab, a.c0, a.c1);
   fp6_add<C>(s0, a.c0, a.c1);
   fp6_mul_v<C>(t, a.c1);
@@ -403,9 +413,9 @@ MLHIP_HD_NOINLINE void fp12_sqr(Fp12<C>& r, const Fp12<C>& a) {
   fp6_dbl<C>(r.c1, ab);
 }
 
-template <class C>
-MLHIP_HD_NOINLINE void fp12_inv(Fp12<C>& r, const Fp12<C>& a) {
-  Fp6<C> t0, t1;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_inv(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
+  Fp6<C, E2> t0, t1;
   fp6_sqr<C>(t0, a.c0);
   fp6_sqr<C>(t1, a.c1);
   fp6_mul_v<C>(t1, t1);
@@ -418,13 +428,13 @@ MLHIP_HD_NOINLINE void fp12_inv(Fp12<C>& r, const Fp12<C>& a) {
 
 // Frobenius f -> f^(p^K), K = 1, 2, 3.  Coefficient of w^i gets multiplied by GAMMAK[i]
 // (after conjugation for odd K).  w-basis positions: g0=c0.c0 g1=c1.c0 g2=c0.c1 g3=c1.c1 g4=c0.c2 g5=c1.c2
-template <class C, int K>
-MLHIP_HD_NOINLINE void fp12_frob(Fp12<C>& r, const Fp12<C>& a) {
-  const Fp2<C>* src[6] = {&a.c0.c0, &a.c1.c0, &a.c0.c1, &a.c1.c1, &a.c0.c2, &a.c1.c2};
-  Fp2<C>* dst[6] = {&r.c0.c0, &r.c1.c0, &r.c0.c1, &r.c1.c1, &r.c0.c2, &r.c1.c2};
+template <class C, int K, class E2>
+MLHIP_HD_NOINLINE void fp12_frob(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
+  const E2* src[6] = {&a.c0.c0, &a.c1.c0, &a.c0.c1, &a.c1.c1, &a.c0.c2, &a.c1.c2};
+  E2* dst[6] = {&r.c0.c0, &r.c1.c0, &r.c0.c1, &r.c1.c1, &r.c0.c2, &r.c1.c2};
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    Fp2<C> x, g;
+    E2 x, g;
     if (K & 1)
       fp2_conj<C>(x, *src[i]);
     else
@@ -432,13 +442,12 @@ MLHIP_HD_NOINLINE void fp12_frob(Fp12<C>& r, const Fp12<C>& a) {
     if (i == 0) {
       *dst[i] = x;
     } else {
-      if (K == 1) fp2_from_const<C>(g, C::GAMMA1[i]);
-      if (K == 2) fp2_from_const<C>(g, C::GAMMA2[i]);
-      if (K == 3) fp2_from_const<C>(g, C::GAMMA3[i]);
       if (K == 2) {
         // gamma2[i] is a 6th root of unity in Fp (imaginary part is zero)
-        fp2_mul_fp<C>(*dst[i], x, g.c0);
+        fp2_mul_by_real_const<C>(*dst[i], x, C::GAMMA2[i]);
       } else {
+        if (K == 1) fp2_from_const<C>(g, C::GAMMA1[i]);
+        if (K == 3) fp2_from_const<C>(g, C::GAMMA3[i]);
         fp2_mul<C>(*dst[i], x, g);
       }
     }
@@ -446,9 +455,9 @@ MLHIP_HD_NOINLINE void fp12_frob(Fp12<C>& r, const Fp12<C>& a) {
 }
 
 // Granger-Scott squaring, valid for f in the cyclotomic subgroup (after the easy part of FExp).
-template <class C>
-MLHIP_HD_NOINLINE void fp12_cyclo_sqr(Fp12<C>& r, const Fp12<C>& a) {
-  Fp2<C> t0, t1, t2, t3, t4, t5, t6, t7, t8, s;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_cyclo_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
+  E2 t0, t1, t2, t3, t4, t5, t6, t7, t8, s;
   fp2_sqr<C>(t0, a.c1.c1);
   fp2_sqr<C>(t1, a.c0.c0);
   fp2_add<C>(s, a.c1.c1, a.c0.c0);
@@ -474,7 +483,7 @@ MLHIP_HD_NOINLINE void fp12_cyclo_sqr(Fp12<C>& r, const Fp12<C>& a) {
   fp2_add<C>(t2, t2, t3);  // xi a.c0.c2^2 + a.c1.c0^2
   fp2_mul_xi<C>(t4, t4);
   fp2_add<C>(t4, t4, t5);  // xi a.c1.c2^2 + a.c0.c1^2
-  Fp12<C> o;
+  Fp12<C, E2> o;
   // z = 3 t - 2 a (c0 part), 3 t + 2 a (c1 part)
   fp2_sub<C>(s, t0, a.c0.c0);
   fp2_dbl<C>(s, s);
@@ -498,10 +507,10 @@ MLHIP_HD_NOINLINE void fp12_cyclo_sqr(Fp12<C>& r, const Fp12<C>& a) {
 }
 
 // f *= (c0 + c1 v + c4 v w)   -- line of an M-twist curve (BLS12-381)
-template <class C>
-MLHIP_HD_NOINLINE void fp12_mul_by_014(Fp12<C>& f, const Fp2<C>& c0, const Fp2<C>& c1, const Fp2<C>& c4) {
-  Fp6<C> t0, t1, s, x;
-  Fp2<C> d;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_mul_by_014(Fp12<C, E2>& f, const E2& c0, const E2& c1, const E2& c4) {
+  Fp6<C, E2> t0, t1, s, x;
+  E2 d;
   fp6_mul_by_01<C>(t0, f.c0, c0, c1);
   fp6_mul_by_1<C>(t1, f.c1, c4);
   fp6_add<C>(s, f.c0, f.c1);
@@ -514,10 +523,10 @@ MLHIP_HD_NOINLINE void fp12_mul_by_014(Fp12<C>& f, const Fp2<C>& c0, const Fp2<C
 }
 
 // f *= (c0 + c3 w + c4 v w)   -- line of a D-twist curve (BN254, BLS12-377)
-template <class C>
-MLHIP_HD_NOINLINE void fp12_mul_by_034(Fp12<C>& f, const Fp2<C>& c0, const Fp2<C>& c3, const Fp2<C>& c4) {
-  Fp6<C> t0, t1, s, x;
-  Fp2<C> d;
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_mul_by_034(Fp12<C, E2>& f, const E2& c0, const E2& c3, const E2& c4) {
+  Fp6<C, E2> t0, t1, s, x;
+  E2 d;
   fp6_mul_by_0<C>(t0, f.c0, c0);
   fp6_mul_by_01<C>(t1, f.c1, c3, c4);
   fp6_add<C>(s, f.c0, f.c1);
