@@ -112,7 +112,7 @@ MLHIP_HD void fp2_halve(Fp2L<C>& r, const Fp2L<C>& a);  // defined after pairing
 //   lane c0: own a=a0, b=b0, partner a'=a1, b'=b1  ->  a*b  + a'*(BETA b')
 //   lane c1: own a=a1, b=b1, partner a'=a0, b'=b0  ->  a*b' + a'*b
 template <class C>
-MLHIP_HD_NOINLINE void fp2_mul(Fp2L<C>& r, const Fp2L<C>& a, const Fp2L<C>& b) {
+MLHIP_HD void fp2_mul(Fp2L<C>& r, const Fp2L<C>& a, const Fp2L<C>& b) {
   const bool hi = lane_is_hi();
   Fp<C> ax, bx, nb, y1, y2;
   fp_pair_xchg<C>(ax, a.v);
@@ -124,7 +124,7 @@ MLHIP_HD_NOINLINE void fp2_mul(Fp2L<C>& r, const Fp2L<C>& a, const Fp2L<C>& b) {
 }
 
 template <class C>
-MLHIP_HD_NOINLINE void fp2_sqr(Fp2L<C>& r, const Fp2L<C>& a) {
+MLHIP_HD void fp2_sqr(Fp2L<C>& r, const Fp2L<C>& a) {
   const bool hi = lane_is_hi();
   Fp<C> ax;
   fp_pair_xchg<C>(ax, a.v);
