@@ -214,7 +214,7 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
   p->lgL = 3;
   p->T = p->M / p->L;
   p->nb = ilog2(p->T);
-  p->nsel = 2 + p->nb;
+  p->nsel = 4 + p->nb;  // two half-sums of W0, two of A, nb bit-masked sums
   switch (curve) {
     case MLHIP_CURVE_BN254: rc = mlhip_tu_plan_alloc_Bn254(p); break;
     case MLHIP_CURVE_BLS12_381: rc = mlhip_tu_plan_alloc_Bls381(p); break;

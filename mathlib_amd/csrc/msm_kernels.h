@@ -430,7 +430,8 @@ __global__ void __launch_bounds__(256) k_chunks(const XYZZ<F>* __restrict__ buck
   msm_chunk_body<F>(g, buckets, A, W0, l_eff, [](XYZZ<F>& a, const XYZZ<F>& q) { xyzz_add_ool<F>(a, q); });
 }
 
-// block (w, sel): sel 0 -> sum_t W0[w][t]; sel 1 -> sum_t A[w][t]; sel 2+k -> sum over t with bit k set of A[w][t]
+// block (w, sel): sel 0,1 -> the two halves of sum_t W0[w][t]; sel 2,3 -> the two halves of sum_t A[w][t];
+// sel 4+k -> sum over t with bit k set of A[w][t].  Every block therefore sums T/2 elements (equal depth).
 template <class F, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_masked_sums(const XYZZ<F>* __restrict__ A, const XYZZ<F>* __restrict__ W0,
                                                        uint32_t T, int nsel, XYZZ<F>* __restrict__ out) {
@@ -438,13 +439,15 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums(const XYZZ<F>* __restrict
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
   const uint32_t w = blockIdx.x / nsel;
   const int sel = blockIdx.x % nsel;
-  const XYZZ<F>* src = (sel == 0 ? W0 : A) + (size_t)w * T;
+  const XYZZ<F>* src = (sel < 2 ? W0 : A) + (size_t)w * T;
   XYZZ<F> acc;
   xyzz_set_inf<F>(acc);
-  if (sel < 2) {
-    for (uint32_t t = threadIdx.x; t < T; t += BLOCK) xyzz_add_ool<F>(acc, src[t]);
+  if (sel < 4) {
+    const uint32_t half = (T + 1) / 2;
+    const uint32_t lo = (sel & 1) ? half : 0u, hi = (sel & 1) ? T : half;
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += BLOCK) xyzz_add_ool<F>(acc, src[t]);
   } else {
-    const int k = sel - 2;
+    const int k = sel - 4;
     const uint32_t lowmask = (1u << k) - 1u;
     for (uint32_t j = threadIdx.x; j < T / 2; j += BLOCK) {
       uint32_t t = ((j >> k) << (k + 1)) | (1u << k) | (j & lowmask);
@@ -559,7 +562,7 @@ int plan_alloc(mlhip_msm_plan* p) {
   return 0;
 }
 
-// Horner over bit positions: total = sum_w 2^(cw) [ out[w][0] + out[w][1] + L * sum_k 2^k out[w][2+k] ]
+// Horner over bit positions: total = sum_w 2^(cw) [ out[w][0..3] summed + L * sum_k 2^k out[w][4+k] ]
 template <class F>
 void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
   const XYZZ<F>* o = reinterpret_cast<const XYZZ<F>*>(p->h_out);
@@ -568,9 +571,9 @@ void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
   for (int i = 0; i < npos; i++) xyzz_set_inf<F>(slot[i]);
   for (int w = 0; w < p->W; w++) {
     XYZZ<F> s = o[w * p->nsel + 0];
-    xyzz_add<F>(s, o[w * p->nsel + 1]);
+    for (int h = 1; h < 4; h++) xyzz_add<F>(s, o[w * p->nsel + h]);
     slot[w * p->c] = s;
-    for (int k = 0; k < p->nb; k++) slot[w * p->c + p->lgL + k] = o[w * p->nsel + 2 + k];
+    for (int k = 0; k < p->nb; k++) slot[w * p->c + p->lgL + k] = o[w * p->nsel + 4 + k];
   }
   xyzz_set_inf<F>(total);
   bool started = false;
