@@ -17,6 +17,9 @@
 #include <cstring>
 #include <vector>
 
+#include <type_traits>
+
+#include "fp2_lanes.h"
 #include "mlhip_internal.h"
 #include "msm_body.h"
 
@@ -509,6 +512,169 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
   return 0;
 }
 
+// ---- G2 over lane pairs -----------------------------------------------------------------------------
+// A G2 bucket is owned by two adjacent lanes, one Fp2 component each (fp2_lanes.h): the XYZZ accumulator is
+// 4 x 12 words per lane -- the G1 footprint -- so the mixed addition stays in registers (one Fp2 element per
+// lane needs ~340 live words and spills), and every Fp2 product is one fused dual Montgomery product.
+template <class C>
+struct Fp2LField {
+  using Curve = C;
+  using T = Fp2L<C>;
+  MLHIP_HD static void zero(T& r) { fp2_zero<C>(r); }
+  MLHIP_HD static void one(T& r) { fp2_one<C>(r); }
+  MLHIP_HD static bool is_zero(const T& a) { return fp2_is_zero<C>(a); }
+  MLHIP_HD static bool eq(const T& a, const T& b) { return fp2_eq<C>(a, b); }
+  MLHIP_HD static void add(T& r, const T& a, const T& b) { fp2_add<C>(r, a, b); }
+  MLHIP_HD static void sub(T& r, const T& a, const T& b) { fp2_sub<C>(r, a, b); }
+  MLHIP_HD static void dbl(T& r, const T& a) { fp2_dbl<C>(r, a); }
+  MLHIP_HD static void neg(T& r, const T& a) { fp2_neg<C>(r, a); }
+  MLHIP_HD static void mul(T& r, const T& a, const T& b) { fp2_mul<C>(r, a, b); }
+  MLHIP_HD static void sqr(T& r, const T& a) { fp2_sqr<C>(r, a); }
+  MLHIP_HD static void inv(T& r, const T& a) { fp2_inv<C>(r, a); }
+  MLHIP_HD static void select(T& r, bool c, const T& a, const T& b) { fp2_select<C>(r, c, a, b); }
+};
+
+// component loads / stores between the AoS Fp2 layout in memory and the lane-pair registers
+template <class C>
+__device__ __forceinline__ void lp_load_affine(Affine<Fp2LField<C>>& p, const Affine<Fp2Field<C>>* pts, size_t idx, int hi) {
+  const Fp<C>* q = reinterpret_cast<const Fp<C>*>(pts + idx);
+  p.x.v = q[hi];
+  p.y.v = q[2 + hi];
+}
+template <class C>
+__device__ __forceinline__ void lp_load_xyzz(XYZZ<Fp2LField<C>>& r, const XYZZ<Fp2Field<C>>* src, size_t idx, int hi) {
+  const Fp<C>* q = reinterpret_cast<const Fp<C>*>(src + idx);
+  r.x.v = q[hi];
+  r.y.v = q[2 + hi];
+  r.zz.v = q[4 + hi];
+  r.zzz.v = q[6 + hi];
+}
+template <class C>
+__device__ __forceinline__ void lp_store_xyzz(XYZZ<Fp2Field<C>>* dst, size_t idx, const XYZZ<Fp2LField<C>>& r, int hi) {
+  Fp<C>* q = reinterpret_cast<Fp<C>*>(dst + idx);
+  q[hi] = r.x.v;
+  q[2 + hi] = r.y.v;
+  q[4 + hi] = r.zz.v;
+  q[6 + hi] = r.zzz.v;
+}
+template <class C>
+__device__ __noinline__ void xyzz_add_lp_ool(XYZZ<Fp2LField<C>>& acc, const XYZZ<Fp2LField<C>>& q) {
+  xyzz_add<Fp2LField<C>>(acc, q);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_accumulate_lp(const Affine<Fp2Field<C>>* __restrict__ points,
+                                                       const uint32_t* __restrict__ sorted,
+                                                       const uint32_t* __restrict__ offsets,
+                                                       const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                       const uint32_t* __restrict__ order, uint32_t big_threshold,
+                                                       uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
+                                                       XYZZ<Fp2Field<C>>* __restrict__ buckets) {
+  typedef Fp2LField<C> FL;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t pair = t >> 1;  // both lanes of a pair share the bucket: every branch below is pair-uniform
+  if (pair >= n_buckets) return;
+  const int hi = lane_is_hi() ? 1 : 0;
+  const size_t g = order[pair];
+  const uint32_t cnt = counts[g];
+  if (cnt > big_threshold) {
+    if (!hi) {
+      uint32_t pos = atomicAdd(big_count, 1u);
+      big_list[pos] = (uint32_t)g;
+    }
+    return;
+  }
+  XYZZ<FL> acc;
+  xyzz_set_inf<FL>(acc);
+  const size_t begin = offsets[g], end = begin + cnt;
+  if (begin < end) {
+    uint32_t e = sorted[begin];
+    Affine<FL> p;
+    lp_load_affine<C>(p, points, e & 0x7fffffffu, hi);
+    for (size_t k = begin; k < end; k++) {
+      uint32_t en = e;
+      Affine<FL> pn = p;
+      if (k + 1 < end) {
+        en = sorted[k + 1];
+        lp_load_affine<C>(pn, points, en & 0x7fffffffu, hi);
+      }
+      xyzz_madd<FL>(acc, p, (e >> 31) != 0);
+      e = en;
+      p = pn;
+    }
+  }
+  lp_store_xyzz<C>(buckets, g, acc, hi);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_chunks_lp(const XYZZ<Fp2Field<C>>* __restrict__ buckets, size_t n_chunks, int l_eff,
+                                                   XYZZ<Fp2Field<C>>* __restrict__ A, XYZZ<Fp2Field<C>>* __restrict__ W0) {
+  typedef Fp2LField<C> FL;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t g = t >> 1;
+  if (g >= n_chunks) return;
+  const int hi = lane_is_hi() ? 1 : 0;
+  XYZZ<FL> acc, w0, b;
+  xyzz_set_inf<FL>(acc);
+  xyzz_set_inf<FL>(w0);
+  for (int i = l_eff - 1; i >= 1; i--) {
+    lp_load_xyzz<C>(b, buckets, g * (size_t)l_eff + i, hi);
+    xyzz_add_lp_ool<C>(acc, b);
+    xyzz_add_lp_ool<C>(w0, acc);
+  }
+  lp_load_xyzz<C>(b, buckets, g * (size_t)l_eff, hi);
+  xyzz_add_lp_ool<C>(acc, b);
+  lp_store_xyzz<C>(A, g, acc, hi);
+  lp_store_xyzz<C>(W0, g, w0, hi);
+}
+
+// same selection scheme as k_masked_sums; BLOCK threads = BLOCK/2 lane pairs, LDS tree over pairs
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_masked_sums_lp(const XYZZ<Fp2Field<C>>* __restrict__ A,
+                                                          const XYZZ<Fp2Field<C>>* __restrict__ W0, uint32_t T, int nsel,
+                                                          XYZZ<Fp2Field<C>>* __restrict__ out) {
+  typedef Fp2LField<C> FL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<Fp2Field<C>>* sh = reinterpret_cast<XYZZ<Fp2Field<C>>*>(smem);
+  constexpr uint32_t PAIRS = BLOCK / 2;
+  const uint32_t pid = threadIdx.x >> 1;
+  const int hi = lane_is_hi() ? 1 : 0;
+  const uint32_t w = blockIdx.x / nsel;
+  const int sel = blockIdx.x % nsel;
+  const XYZZ<Fp2Field<C>>* src = (sel < 2 ? W0 : A) + (size_t)w * T;
+  XYZZ<FL> acc, b;
+  xyzz_set_inf<FL>(acc);
+  if (sel < 4) {
+    const uint32_t half = (T + 1) / 2;
+    const uint32_t lo = (sel & 1) ? half : 0u, hi_t = (sel & 1) ? T : half;
+    for (uint32_t t = lo + pid; t < hi_t; t += PAIRS) {
+      lp_load_xyzz<C>(b, src, t, hi);
+      xyzz_add_lp_ool<C>(acc, b);
+    }
+  } else {
+    const int k = sel - 4;
+    const uint32_t lowmask = (1u << k) - 1u;
+    for (uint32_t j = pid; j < T / 2; j += PAIRS) {
+      uint32_t t = ((j >> k) << (k + 1)) | (1u << k) | (j & lowmask);
+      lp_load_xyzz<C>(b, src, t, hi);
+      xyzz_add_lp_ool<C>(acc, b);
+    }
+  }
+  lp_store_xyzz<C>(sh, pid, acc, hi);
+  __syncthreads();
+  for (uint32_t s = PAIRS / 2; s > 0; s >>= 1) {
+    if (pid < s) {  // pair-uniform
+      XYZZ<FL> a;
+      lp_load_xyzz<C>(a, sh, pid, hi);
+      lp_load_xyzz<C>(b, sh, pid + s, hi);
+      xyzz_add_lp_ool<C>(a, b);
+      lp_store_xyzz<C>(sh, pid, a, hi);
+    }
+    __syncthreads();
+  }
+  if (pid == 0) lp_store_xyzz<C>(out, blockIdx.x, [&] { XYZZ<FL> a; lp_load_xyzz<C>(a, sh, 0, hi); return a; }(), hi);
+}
+
 template <class F>
 int plan_alloc(mlhip_msm_plan* p) {
   const size_t nbuckets = (size_t)p->W * p->M;
@@ -644,9 +810,16 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
       k_order_place<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist, p->d_order);
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[2], st));
-    k_accumulate<F><<<dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st>>>(
-        (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
-        p->d_bigcount, (X*)p->d_buckets);
+    constexpr bool kLanePairs = std::is_same<F, Fp2Field<C>>::value;  // G2: two lanes per bucket
+    if constexpr (kLanePairs) {
+      k_accumulate_lp<C><<<dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+          (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
+          p->d_bigcount, (X*)p->d_buckets);
+    } else {
+      k_accumulate<F><<<dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+          (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
+          p->d_bigcount, (X*)p->d_buckets);
+    }
     if (prof) HIPCHK(hipEventRecord(p->ev[3], st));
     {
       constexpr int BB = sizeof(X) <= 192 ? 256 : 128;  // 48 KB of LDS per block
@@ -656,11 +829,19 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     }
     {
       size_t n_chunks = (size_t)p->W * p->T;
-      k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
-                                                                                   p->L, (X*)p->d_A, (X*)p->d_W0);
-      constexpr int RB = sizeof(X) <= 192 ? 256 : 128;  // 48 KB of LDS per block
-      k_masked_sums<F, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), RB * sizeof(X), st>>>(
-          (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      if constexpr (kLanePairs) {
+        k_chunks_lp<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                          p->L, (X*)p->d_A, (X*)p->d_W0);
+        constexpr int RB = 256;  // 128 lane pairs x 384 B = 48 KB of LDS per block
+        k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 2) * sizeof(X), st>>>(
+            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      } else {
+        k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                     p->L, (X*)p->d_A, (X*)p->d_W0);
+        constexpr int RB = 256;  // 48 KB of LDS per block
+        k_masked_sums<F, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), RB * sizeof(X), st>>>(
+            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      }
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[4], st));
     HIPCHK(hipGetLastError());
