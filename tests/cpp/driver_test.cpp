@@ -1,0 +1,175 @@
+// tests/cpp/driver_test.cpp -- the reference's acceptance tests for a driver (TestCurves, math_test.go:852-877),
+// restated in C++ against the HIP backend through include/mlhip_driver.hpp (the compiled-language mirror of
+// driver/math.go).  Helper names follow math_test.go.  Modes:
+//   driver_test host         host-only logic (no GPU needed): Zr arithmetic, serialisation, loud failure without a device
+//   driver_test gpu          the property tests on every curve; prints hex lines the pytest wrapper checks
+//                            against the oracle / golden vectors
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "mlhip_driver.hpp"
+
+using namespace mlhip_driver;
+
+static int g_fail = 0;
+#define EXPECT(cond)                                                        \
+  do {                                                                      \
+    if (!(cond)) {                                                          \
+      printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);                \
+      g_fail++;                                                             \
+    }                                                                       \
+  } while (0)
+
+static std::string hex(const Bytes& b) {
+  static const char* d = "0123456789abcdef";
+  std::string s;
+  for (uint8_t x : b) {
+    s.push_back(d[x >> 4]);
+    s.push_back(d[x & 15]);
+  }
+  return s;
+}
+
+static const char* kNames[3] = {"BN254", "BLS12-381", "BLS12-377"};
+
+// math_test.go:132-248 (runZrTest), 591-649: scalar arithmetic mod r, on the host
+static void runZrTest(const Curve& c) {
+  uint64_t st = 42 + c.id;
+  Zr a = c.NewRandomZr(st), b = c.NewRandomZr(st);
+  EXPECT(a.Plus(b).Minus(b).Equals(a));
+  EXPECT(a.Mul(b).Equals(b.Mul(a)));
+  EXPECT(a.Plus(a.Neg()).Equals(c.NewZrFromInt(0)));
+  EXPECT(c.NewZrFromInt(-1).Plus(c.NewZrFromInt(1)).Equals(c.NewZrFromInt(0)));
+  EXPECT(c.NewZrFromInt(6).Equals(c.NewZrFromInt(2).Mul(c.NewZrFromInt(3))));
+  EXPECT(a.ToBytes().size() == 32);  // c.ScalarByteSize
+  EXPECT(c.GroupOrder.Equals(c.NewZrFromInt(0)));
+}
+
+// math_test.go:272-321: generator string / byte round trips need no GPU
+static void runG1HostTest(const Curve& c) {
+  G1 g = c.GenG1();
+  printf("%s gen_g1_compressed %s\n", kNames[c.id], hex(g.Compressed()).c_str());
+  printf("%s gen_g1_bytes %s\n", kNames[c.id], hex(g.ToBytes()).c_str());
+  G1 n = g.Copy();
+  n.Neg();
+  n.Neg();
+  EXPECT(n.Equals(g));
+  EXPECT(c.NewG1().IsInfinity());
+  printf("%s inf_g1_compressed %s\n", kNames[c.id], hex(c.NewG1().Compressed()).c_str());
+}
+
+// without a GPU every hot method must throw (no CPU fallback); with one this is skipped by the caller
+static void runNoDeviceTest(const Curve& c) {
+  bool threw = false;
+  try {
+    c.MultiScalarMul({c.GenG1()}, {c.NewZrFromInt(5)});
+  } catch (const std::runtime_error& e) {
+    threw = std::string(e.what()).find("no HIP device") != std::string::npos;
+  }
+  EXPECT(threw);
+  bool threw2 = false;
+  try {
+    c.MultiScalarMul({c.GenG1(), c.GenG1()}, {c.NewZrFromInt(5)});
+  } catch (const std::out_of_range&) {
+    threw2 = true;  // math.go:963-966 panics with index out of range
+  }
+  EXPECT(threw2);
+}
+
+// math_test.go:323-346
+static void runMultiScalarMul(const Curve& c, uint64_t& st) {
+  std::vector<G1> g1s;
+  std::vector<Zr> zrs;
+  for (int i = 0; i < 10; i++) {
+    g1s.push_back(c.GenG1().Mul(c.NewRandomZr(st)));
+    zrs.push_back(c.NewRandomZr(st));
+  }
+  G1 msm = c.MultiScalarMul(g1s, zrs);
+  G1 acc = c.NewG1();
+  for (int i = 0; i < 10; i++) acc.Add(g1s[i].Mul(zrs[i]));
+  EXPECT(msm.Equals(acc));
+  EXPECT(msm.Compressed() == acc.Compressed());
+  EXPECT(c.MultiScalarMul({}, {}).IsInfinity());
+  EXPECT(c.MultiScalarMul({g1s[0]}, {zrs[0], zrs[1]}).IsInfinity());  // dropped MultiExp error
+  // a fixed instance for the oracle cross-check: sum_{i<4} [i+2] * [i+1]G = [sum (i+1)(i+2)]G = [40]G
+  std::vector<G1> ps;
+  std::vector<Zr> ss;
+  for (int i = 0; i < 4; i++) {
+    ps.push_back(c.GenG1().Mul(c.NewZrFromInt(i + 1)));
+    ss.push_back(c.NewZrFromInt(i + 2));
+  }
+  G1 fixed = c.MultiScalarMul(ps, ss);
+  EXPECT(fixed.Equals(c.GenG1().Mul(c.NewZrFromInt(40))));
+  printf("%s msm_40G_compressed %s\n", kNames[c.id], hex(fixed.Compressed()).c_str());
+}
+
+// math_test.go:272-321 on the GPU path
+static void runG1Test(const Curve& c, uint64_t& st) {
+  Zr a = c.NewRandomZr(st), b = c.NewRandomZr(st);
+  G1 g = c.GenG1();
+  G1 s = g.Mul(a);
+  s.Add(g.Mul(b));
+  EXPECT(s.Equals(g.Mul(a.Plus(b))));
+  EXPECT(g.Mul2(a, g.Mul(b), b).Equals(g.Mul(a.Plus(b.Mul(b)))));
+  G1 d = g.Mul(a);
+  d.Sub(g.Mul(a));
+  EXPECT(d.IsInfinity());
+  EXPECT(g.Mul(c.GroupOrder).IsInfinity());
+  EXPECT(g.Mul(c.NewZrFromInt(-1)).Equals([&] { G1 n = g.Copy(); n.Neg(); return n; }()));
+}
+
+// math_test.go:423-455, 457-470, 390-421
+static void runPairingTest(const Curve& c, const G2& g2, uint64_t& st) {
+  Zr r1 = c.NewRandomZr(st), r2 = c.NewRandomZr(st);
+  G1 g1 = c.GenG1();
+  Gt a = c.FExp(c.Pairing(g2.Mul(r1), g1.Mul(r2)));
+  Gt b = c.FExp(c.Pairing(g2.Mul(r1.Mul(r2)), g1));
+  EXPECT(a.Equals(b));
+  Gt p = c.FExp(c.Pairing(g2.Mul(r1), g1.Mul(r2)));
+  p.Mul(c.FExp(c.Pairing(g2.Mul(r2), g1.Mul(r1))));
+  Gt p2 = c.FExp(c.Pairing2(g2.Mul(r1), g2.Mul(r2), g1.Mul(r2), g1.Mul(r1)));
+  EXPECT(p2.Equals(p));
+  Gt gengt = c.FExp(c.Pairing(g2, g1));
+  EXPECT(!gengt.IsUnity());
+  EXPECT(gengt.Exp(c.GroupOrder).IsUnity());
+  EXPECT(gengt.Exp(r1).Equals(c.FExp(c.Pairing(g2.Mul(r1), g1))));
+  EXPECT(c.FExp(c.Pairing(g2, c.NewG1())).IsUnity());
+  printf("%s gen_gt_bytes %s\n", kNames[c.id], hex(gengt.ToBytes()).c_str());
+  // additive API
+  std::vector<G1> ps = {g1.Mul(r1), g1.Mul(r2), g1};
+  std::vector<G2> qs = {g2.Mul(r2), g2, g2.Mul(r1)};
+  std::vector<Gt> batch = c.PairingBatch(qs, ps);
+  Gt prod = batch[0];
+  prod.Mul(batch[1]);
+  prod.Mul(batch[2]);
+  EXPECT(c.PairingProduct(qs, ps).Equals(prod));
+  G2 sum = g2.Mul(r1);
+  sum.Add(g2.Mul(r2));
+  EXPECT(c.MultiScalarMulG2({g2, g2}, {r1, r2}).Equals(sum));
+}
+
+int main(int argc, char** argv) {
+  std::string mode = argc > 1 ? argv[1] : "host";
+  int ndev = 0;
+  mlhip_device_count(&ndev);
+  for (int id = 0; id < 3; id++) {
+    Curve c(id);
+    runZrTest(c);
+    runG1HostTest(c);
+    if (mode == "host") {
+      if (ndev == 0) runNoDeviceTest(c);
+      continue;
+    }
+    uint64_t st = 20251003 + id;
+    runMultiScalarMul(c, st);
+    runG1Test(c, st);
+    if (id != MLHIP_CURVE_BLS12_377) {
+      runPairingTest(c, c.GenG2(), st);
+    } else if (argc > 5) {  // the G2 generator of BLS12-377 comes from the golden file (decimal coordinates)
+      runPairingTest(c, c.NewG2FromCoords(argv[2], argv[3], argv[4], argv[5]), st);
+    }
+  }
+  printf(g_fail ? "RESULT FAIL %d\n" : "RESULT OK\n", g_fail);
+  return g_fail ? 1 : 0;
+}
