@@ -133,6 +133,20 @@ int mlhip_scalar_mul_device(int curve, int group, const void* d_points, size_t p
 int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stride, const void* scalars,
                      int scalars_mont, size_t n, void* out_affine);
 
+/* ---- wire format (bulk NewG1FromBytes / NewG1FromCompressed and G1.Bytes / G1.Compressed,
+ * driver/gurvy/bls12381/bls12-381.go:531-569, :286-296) --------------------------------------------------
+ * Decode n points of gnark's wire format (BLS12 curves: zcash 3-bit header; BN254: 2-bit header), all of the
+ * same form: compressed (fp bytes each) or uncompressed (2 x fp bytes).  Every point gets a status byte:
+ * 0 ok | 1 malformed (flags, coordinate >= p, bad infinity) | 2 not on the curve | 3 not in the r-torsion
+ * subgroup; out_affine[i] is (0,0) unless status[i] == 0.  subgroup_check = 0 skips the [r]P test (gnark's
+ * SetBytes always does it; its cost is ~6x the decompression itself). */
+int mlhip_g1_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out_affine,
+                        unsigned char* status);
+int mlhip_g1_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire);
+int mlhip_g1_from_bytes_device(int curve, const void* d_wire, size_t n, int compressed, int subgroup_check,
+                               void* d_out_affine, unsigned char* d_status, void* stream);
+int mlhip_g1_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream);
+
 /* ---- group helpers (host, O(n) tiny): combine per-GPU partial results after the RCCL all-gather */
 int mlhip_g1_sum(int curve, const void* affine_points, size_t n, void* out_affine);
 int mlhip_g2_sum(int curve, const void* affine_points, size_t n, void* out_affine);

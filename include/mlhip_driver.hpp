@@ -316,6 +316,18 @@ class Curve {
     g.raw.assign(g1_bytes, 0);
     return g;
   }
+  // NewG1FromBytes / NewG1FromCompressed (driver/gurvy/bls12381/bls12-381.go:531-559): decoded, curve- and
+  // subgroup-checked on the device; the reference panics on bad input ("set bytes failed [...]") -> throws here.
+  G1 g1_from_wire(const Bytes& b, bool compressed) const {
+    if (b.size() != (size_t)(compressed ? 1 : 2) * fp_bytes) throw std::invalid_argument("set bytes failed [invalid length]");
+    G1 g = NewG1();
+    unsigned char st = 0;
+    check(mlhip_g1_from_bytes(id, b.data(), 1, compressed ? 1 : 0, 1, g.raw.data(), &st));
+    if (st) throw std::invalid_argument(std::string("set bytes failed [status ") + std::to_string((int)st) + "]");
+    return g;
+  }
+  G1 NewG1FromBytes(const Bytes& b) const { return g1_from_wire(b, false); }
+  G1 NewG1FromCompressed(const Bytes& b) const { return g1_from_wire(b, true); }
   G2 NewG2() const {
     G2 g;
     g.curve = this;

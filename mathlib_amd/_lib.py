@@ -45,6 +45,10 @@ SYMBOLS = [
     "mlhip_gt_exp_device",
     "mlhip_scalar_mul_device",
     "mlhip_scalar_mul",
+    "mlhip_g1_from_bytes",
+    "mlhip_g1_to_bytes",
+    "mlhip_g1_from_bytes_device",
+    "mlhip_g1_to_bytes_device",
     "mlhip_g1_sum",
     "mlhip_g2_sum",
     "mlhip_fp_mul_device",
@@ -106,6 +110,10 @@ def load() -> ctypes.CDLL:
     lib.mlhip_gt_mul_device.argtypes = [ci, vp, vp, sz, vp, vp]
     lib.mlhip_scalar_mul_device.argtypes = [ci, ci, vp, sz, vp, ci, sz, vp, vp]
     lib.mlhip_scalar_mul.argtypes = [ci, ci, vp, sz, vp, ci, sz, vp]
+    lib.mlhip_g1_from_bytes.argtypes = [ci, vp, sz, ci, ci, vp, vp]
+    lib.mlhip_g1_to_bytes.argtypes = [ci, vp, sz, ci, vp]
+    lib.mlhip_g1_from_bytes_device.argtypes = [ci, vp, sz, ci, ci, vp, vp, vp]
+    lib.mlhip_g1_to_bytes_device.argtypes = [ci, vp, sz, ci, vp, vp]
     lib.mlhip_g1_sum.argtypes = [ci, vp, sz, vp]
     lib.mlhip_g2_sum.argtypes = [ci, vp, sz, vp]
     lib.mlhip_fp_mul_device.argtypes = [ci, vp, vp, sz, ci, vp, vp]

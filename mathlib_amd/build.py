@@ -24,6 +24,9 @@ UNITS = [
     "tu_pairing_bn254.hip",
     "tu_pairing_bls381.hip",
     "tu_pairing_bls377.hip",
+    "tu_codec_bn254.hip",
+    "tu_codec_bls381.hip",
+    "tu_codec_bls377.hip",
 ]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fno-gpu-rdc"]
 

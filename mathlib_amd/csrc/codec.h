@@ -1,0 +1,222 @@
+// codec.h -- gnark / zcash wire format of G1 points: bulk decode (SetBytes) and encode (Bytes / RawBytes), gfx950.
+//
+// Replaces, in bulk, what the reference's NewG1FromBytes / NewG1FromCompressed and G1.Bytes / G1.Compressed do
+// one point at a time through gnark-crypto (driver/gurvy/bls12381/bls12-381.go:531-569, :286-296; sizes
+// :499-517; same for bn254.go / bls12-377.go).  Decoding = flag parsing, big-endian coordinates (rejected when
+// >= p), y recovered as a square root of x^3 + b for compressed points (the sign bit says "y is the
+// lexicographically largest of +-y"), curve-equation check for uncompressed points, and the r-torsion subgroup
+// check ([r]P = infinity; skipped for BN254 whose G1 is the whole curve).  Header bits (gnark-crypto marshal.go,
+// restated from the public format -- not in the reference tree): BLS12 curves use the zcash 3-bit header
+// (0x80 compressed, 0x40 infinity, 0x20 y-is-largest); BN254 uses 2 bits (0x80 / 0xC0 compressed smallest /
+// largest, 0x40 infinity, 0x00 uncompressed).
+// status: 0 ok | 1 malformed encoding | 2 not on the curve | 3 not in the subgroup.
+#pragma once
+#include "ec.h"
+
+namespace mlhip {
+
+enum { CODEC_OK = 0, CODEC_MALFORMED = 1, CODEC_NOT_ON_CURVE = 2, CODEC_NOT_IN_SUBGROUP = 3 };
+
+// r = a^e, e given as N little-endian 32-bit words
+template <class C>
+MLHIP_HD void fp_pow_words(Fp<C>& r, const Fp<C>& a, const uint32_t (&e)[C::N]) {
+  Fp<C> acc;
+  fp_one<C>(acc);
+  bool started = false;
+  for (int i = C::N * 32 - 1; i >= 0; i--) {
+    if (started) fp_sqr<C>(acc, acc);
+    if ((e[i >> 5] >> (i & 31)) & 1u) {
+      if (started)
+        fp_mul<C>(acc, acc, a);
+      else {
+        acc = a;
+        started = true;
+      }
+    }
+  }
+  r = acc;
+}
+
+// square root in Fp; false when a is a non-residue.  p = 3 mod 4: a^((p+1)/4); else Tonelli-Shanks.
+template <class C>
+MLHIP_HD bool fp_sqrt(Fp<C>& r, const Fp<C>& a) {
+  if (fp_is_zero<C>(a)) {
+    fp_zero<C>(r);
+    return true;
+  }
+  Fp<C> one;
+  fp_one<C>(one);
+  if (C::SQRT_S == 1) {
+    Fp<C> y, y2;
+    fp_pow_words<C>(y, a, C::SQRT_EXP);
+    fp_sqr<C>(y2, y);
+    if (!fp_eq<C>(y2, a)) return false;
+    r = y;
+    return true;
+  }
+  // p - 1 = 2^S q:  w = a^((q-1)/2), x = a w, b = x w = a^q
+  Fp<C> w, x, b, z, t;
+  fp_pow_words<C>(w, a, C::SQRT_EXP);
+  fp_mul<C>(x, a, w);
+  fp_mul<C>(b, x, w);
+  fp_from_const<C>(z, C::SQRT_Z);
+  int rr = C::SQRT_S;
+  // a is a residue iff b^(2^(S-1)) = 1
+  t = b;
+  for (int i = 0; i < C::SQRT_S - 1; i++) fp_sqr<C>(t, t);
+  if (!fp_eq<C>(t, one)) return false;
+  while (!fp_eq<C>(b, one)) {
+    int m = 0;
+    t = b;
+    while (!fp_eq<C>(t, one)) {
+      fp_sqr<C>(t, t);
+      m++;
+    }
+    t = z;
+    for (int i = 0; i < rr - m - 1; i++) fp_sqr<C>(t, t);
+    fp_sqr<C>(z, t);
+    fp_mul<C>(b, b, z);
+    fp_mul<C>(x, x, t);
+    rr = m;
+  }
+  r = x;
+  return true;
+}
+
+// canonical (non-Montgomery) value of a > (p-1)/2 ?
+template <class C>
+MLHIP_HD bool fp_is_largest(const Fp<C>& a_mont) {
+  Fp<C> a;
+  fp_from_mont<C>(a, a_mont);
+  uint32_t br = 0;
+#pragma unroll
+  for (int i = 0; i < C::N; i++) (void)mlhip_subb(C::HALF_P[i], a.l[i], br);  // HALF_P - a borrows <=> a > HALF_P
+  return br != 0;
+}
+
+// big-endian bytes -> limbs (plain integer); false when the value is >= p.  `top_mask` clears the header bits.
+template <class C>
+MLHIP_HD bool fp_from_be(Fp<C>& r, const uint8_t* b, uint8_t top_mask) {
+  constexpr int N = C::N;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const uint8_t* q = b + 4 * (N - 1 - i);
+    uint32_t b0 = q[0];
+    if (i == N - 1) b0 &= top_mask;
+    r.l[i] = (b0 << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+  }
+  uint32_t br = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) (void)mlhip_subb(r.l[i], C::P[i], br);
+  return br != 0;  // r < p
+}
+
+template <class C>
+MLHIP_HD void fp_to_be(uint8_t* b, const Fp<C>& a_plain) {
+  constexpr int N = C::N;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    uint8_t* q = b + 4 * (N - 1 - i);
+    uint32_t v = a_plain.l[i];
+    q[0] = (uint8_t)(v >> 24);
+    q[1] = (uint8_t)(v >> 16);
+    q[2] = (uint8_t)(v >> 8);
+    q[3] = (uint8_t)v;
+  }
+}
+
+// [r]P == infinity ?
+template <class C>
+MLHIP_HD bool g1_in_subgroup(const Affine<FpField<C>>& P) {
+  typedef FpField<C> F;
+  XYZZ<F> acc;
+  xyzz_set_inf<F>(acc);
+  for (int i = C::FR_BITS - 1; i >= 0; i--) {
+    XYZZ<F> d;
+    xyzz_dbl<F>(d, acc);
+    acc = d;
+    if ((C::FR[i >> 5] >> (i & 31)) & 1u) xyzz_madd<F>(acc, P, false);
+  }
+  return xyzz_is_inf<F>(acc);
+}
+
+template <class C>
+MLHIP_HD int g1_decode(Affine<FpField<C>>& out, const uint8_t* w, bool compressed, bool subgroup_check) {
+  typedef FpField<C> F;
+  constexpr int NB = C::N * 4;
+  fp_zero<C>(out.x);
+  fp_zero<C>(out.y);
+  const uint8_t flags = w[0];
+  bool f_comp, f_inf, f_largest;
+  uint8_t mask;
+  if (C::ZCASH_FLAGS) {
+    f_comp = (flags & 0x80) != 0;
+    f_inf = (flags & 0x40) != 0;
+    f_largest = (flags & 0x20) != 0;
+    mask = 0x1F;
+    if (!f_comp && f_largest) return CODEC_MALFORMED;
+    if (f_inf && f_largest) return CODEC_MALFORMED;
+  } else {
+    const uint8_t hdr = flags & 0xC0;
+    f_inf = hdr == 0x40;
+    f_comp = (hdr & 0x80) != 0 || (f_inf && compressed);
+    f_largest = hdr == 0xC0;
+    mask = 0x3F;
+  }
+  if (f_comp != compressed) return CODEC_MALFORMED;
+  const int len = compressed ? NB : 2 * NB;
+  if (f_inf) {
+    uint32_t o = flags & mask;
+    for (int i = 1; i < len; i++) o |= w[i];
+    return o ? CODEC_MALFORMED : CODEC_OK;  // (0,0) = infinity
+  }
+  Fp<C> x, y;
+  if (!fp_from_be<C>(x, w, mask)) return CODEC_MALFORMED;
+  fp_to_mont<C>(x, x);
+  Fp<C> rhs, t, bcoef;
+  fp_sqr<C>(t, x);
+  fp_mul<C>(rhs, t, x);
+  fp_from_const<C>(bcoef, C::B_G1);
+  fp_add<C>(rhs, rhs, bcoef);
+  if (compressed) {
+    if (!fp_sqrt<C>(y, rhs)) return CODEC_NOT_ON_CURVE;
+    if (fp_is_largest<C>(y) != f_largest) fp_neg<C>(y, y);
+  } else {
+    if (!fp_from_be<C>(y, w + NB, 0xFF)) return CODEC_MALFORMED;
+    fp_to_mont<C>(y, y);
+    fp_sqr<C>(t, y);
+    if (!fp_eq<C>(t, rhs)) return CODEC_NOT_ON_CURVE;
+  }
+  Affine<F> P;
+  P.x = x;
+  P.y = y;
+  if (subgroup_check && !C::G1_COFACTOR_ONE && !g1_in_subgroup<C>(P)) return CODEC_NOT_IN_SUBGROUP;
+  out = P;
+  return CODEC_OK;
+}
+
+template <class C>
+MLHIP_HD void g1_encode(uint8_t* w, const Affine<FpField<C>>& P, bool compressed) {
+  constexpr int NB = C::N * 4;
+  const int len = compressed ? NB : 2 * NB;
+  if (affine_is_inf<FpField<C>>(P)) {
+    for (int i = 0; i < len; i++) w[i] = 0;
+    w[0] = C::ZCASH_FLAGS ? (compressed ? 0xC0 : 0x40) : 0x40;
+    return;
+  }
+  Fp<C> x, y;
+  fp_from_mont<C>(x, P.x);
+  fp_to_be<C>(w, x);
+  if (compressed) {
+    const bool largest = fp_is_largest<C>(P.y);
+    if (C::ZCASH_FLAGS)
+      w[0] |= 0x80 | (largest ? 0x20 : 0x00);
+    else
+      w[0] |= largest ? 0xC0 : 0x80;
+  } else {
+    fp_from_mont<C>(y, P.y);
+    fp_to_be<C>(w + NB, y);
+  }
+}
+
+}  // namespace mlhip

@@ -288,6 +288,27 @@ class Curve:
     def NewG2FromCoords(self, x, y) -> G2:
         return G2(b"".join(self._to_mont(v) for v in (x[0], x[1], y[0], y[1])), self)
 
+    _CODEC_ERRORS = {1: "invalid point encoding", 2: "invalid point: not on the curve", 3: "invalid point: subgroup check failed"}
+
+    def _g1_from_wire(self, b: bytes, compressed: bool) -> G1:
+        out = ctypes.create_string_buffer(self.g1_bytes)
+        st = ctypes.create_string_buffer(1)
+        if len(b) != (self.fp_bytes if compressed else 2 * self.fp_bytes):
+            raise ValueError("set bytes failed [invalid length]")
+        check(load().mlhip_g1_from_bytes(self.id, bytes(b), 1, 1 if compressed else 0, 1, out, st))
+        if st.raw[0]:
+            # the reference panics ("set bytes failed [...]"), the facade turns it into an error (math.go:761-832)
+            raise ValueError("set bytes failed [%s]" % self._CODEC_ERRORS[st.raw[0]])
+        return G1(out.raw, self)
+
+    def NewG1FromBytes(self, b: bytes) -> G1:
+        """uncompressed wire form, subgroup-checked (driver/gurvy/bls12381/bls12-381.go:531-539)"""
+        return self._g1_from_wire(b, False)
+
+    def NewG1FromCompressed(self, b: bytes) -> G1:
+        """compressed wire form (bls12-381.go:551-559)"""
+        return self._g1_from_wire(b, True)
+
     def NewG1(self) -> G1:
         return G1(bytes(self.g1_bytes), self)
 

@@ -856,6 +856,55 @@ def g1_wire_compressed(cp: CurveParams, P) -> bytes:
     return bytes(out)
 
 
+def g1_from_wire(cp: CurveParams, b: bytes, subgroup_check: bool = True):
+    """gnark G1Affine.SetBytes semantics (the reference's NewG1FromBytes / NewG1FromCompressed,
+    driver/gurvy/bls12381/bls12-381.go:531-569): returns (point, status) with status 0 ok, 1 malformed
+    encoding, 2 not on the curve (or x^3 + b is a non-residue), 3 not in the r-torsion subgroup.
+    The format (compressed / uncompressed) follows from the flag bits; len(b) must match it."""
+    n = cp.fp_bytes
+    if len(b) not in (n, 2 * n):
+        return None, 1
+    flags = b[0]
+    if cp.family == "BLS12":
+        hdr, mask = flags & 0xE0, 0x1F
+        compressed = bool(hdr & 0x80)
+        infinity = bool(hdr & 0x40)
+        largest = bool(hdr & 0x20)
+        if not compressed and largest:
+            return None, 1
+    else:
+        hdr, mask = flags & 0xC0, 0x3F
+        compressed = hdr in (0x80, 0xC0) or (hdr == 0x40 and len(b) == n)
+        infinity = hdr == 0x40
+        largest = hdr == 0xC0
+    if len(b) != (n if compressed else 2 * n):
+        return None, 1
+    body = bytes([b[0] & mask]) + b[1:]
+    if infinity:
+        if cp.family == "BLS12" and largest:
+            return None, 1
+        return (None, 0) if not any(body) else (None, 1)
+    x = int.from_bytes(body[:n], "big")
+    if x >= cp.p:
+        return None, 1
+    if compressed:
+        y = fp_sqrt((x * x * x + cp.b) % cp.p, cp.p)
+        if y is None:
+            return None, 2
+        if (y > (cp.p - 1) // 2) != largest:
+            y = (-y) % cp.p
+    else:
+        y = int.from_bytes(body[n:], "big")
+        if y >= cp.p:
+            return None, 1
+        if (y * y - x * x * x - cp.b) % cp.p:
+            return None, 2
+    P = (x, y)
+    if subgroup_check and g1_mul_unreduced(cp, P, cp.r) is not None:
+        return None, 3
+    return P, 0
+
+
 # --------------------------------------------------------------------------------------
 # Deterministic inputs (BASELINE.md section 3: SHA-256 counter DRBG, seed "mlhip-vec-1")
 # --------------------------------------------------------------------------------------

@@ -117,6 +117,19 @@ static void runG1Test(const Curve& c, uint64_t& st) {
   EXPECT(d.IsInfinity());
   EXPECT(g.Mul(c.GroupOrder).IsInfinity());
   EXPECT(g.Mul(c.NewZrFromInt(-1)).Equals([&] { G1 n = g.Copy(); n.Neg(); return n; }()));
+  // runToFroBytesTest / runToFroCompressedTest (math_test.go:511-589)
+  EXPECT(c.NewG1FromBytes(s.ToBytes()).Equals(s));
+  EXPECT(c.NewG1FromCompressed(s.Compressed()).Equals(s));
+  EXPECT(c.NewG1FromCompressed(c.NewG1().Compressed()).IsInfinity());
+  Bytes bad = s.ToBytes();
+  bad.back() ^= 1;
+  bool threw = false;
+  try {
+    c.NewG1FromBytes(bad);
+  } catch (const std::invalid_argument&) {
+    threw = true;
+  }
+  EXPECT(threw);
 }
 
 // math_test.go:423-455, 457-470, 390-421

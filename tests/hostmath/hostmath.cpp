@@ -7,6 +7,7 @@
 #include <vector>
 #include "../../mathlib_amd/csrc/pairing.h"
 #include "../../mathlib_amd/csrc/msm_body.h"
+#include "../../mathlib_amd/csrc/codec.h"
 
 using namespace mlhip;
 
@@ -154,6 +155,18 @@ struct Ops {
     }
     return 0;
   }
+  static int g1dec(const uint8_t* w, int compressed, int subgroup, void* out) {
+    A1 p;
+    int st = g1_decode<C>(p, w, compressed != 0, subgroup != 0);
+    memcpy(out, &p, sizeof(A1));
+    return st;
+  }
+  static int g1enc(const void* pt, int compressed, uint8_t* w) {
+    A1 p;
+    memcpy(&p, pt, sizeof(A1));
+    g1_encode<C>(w, p, compressed != 0);
+    return 0;
+  }
   static int miller(const void* g1s, const void* g2s, int n_pairs, void* out) {
     F12 f;
     miller_loop<C, 4>(f, (const A1*)g1s, (const A2*)g2s, n_pairs);
@@ -180,5 +193,7 @@ int hm_g1_tree(int curve, const void* pts, int n, void* out) { DISPATCH(curve, g
 int hm_g2_tree(int curve, const void* pts, int n, void* out) { DISPATCH(curve, g2_tree(pts, n, out)) }
 int hm_digits(int curve, const void* scalar, int mont, int c, uint32_t* out, int cap) { DISPATCH(curve, digits(scalar, mont, c, out, cap)) }
 int hm_chunks(int curve, const void* pts, int n_chunks, void* outA, void* outW0) { DISPATCH(curve, chunks(pts, n_chunks, outA, outW0)) }
+int hm_g1_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g1dec(w, compressed, subgroup, out)) }
+int hm_g1_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g1enc(pt, compressed, w)) }
 int hm_miller(int curve, const void* g1s, const void* g2s, int n_pairs, void* out) { DISPATCH(curve, miller(g1s, g2s, n_pairs, out)) }
 }

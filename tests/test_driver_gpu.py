@@ -187,3 +187,18 @@ def test_PairingProduct_shared_final_exp(curve):
     n = g1s[0].Copy()
     n.Neg()
     assert c.PairingProduct([g2s[0], g2s[0]], [g1s[0], n]).IsUnity()
+
+
+def test_runToFroBytesTest_and_compressed(curve):
+    """math_test.go:511-589: Bytes()/Compressed() -> NewG1FromBytes/NewG1FromCompressed round trips; bad bytes raise"""
+    c = curve
+    p = c.GenG1().Mul(c.NewRandomZr(c._rng))
+    assert c.NewG1FromBytes(p.Bytes()).Equals(p)
+    assert c.NewG1FromCompressed(p.Compressed()).Equals(p)
+    assert c.NewG1FromCompressed(c.NewG1().Compressed()).IsInfinity()
+    bad = bytearray(p.Bytes())
+    bad[-1] ^= 1
+    with pytest.raises(ValueError):
+        c.NewG1FromBytes(bytes(bad))
+    with pytest.raises(ValueError):
+        c.NewG1FromCompressed(p.Compressed()[:-1])

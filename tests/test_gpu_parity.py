@@ -267,3 +267,61 @@ def test_pairing_batch_random_vs_cref(lib, mlhip, curve):
     fe = ctypes.create_string_buffer(gtb * 60)
     mlhip.check(lib.mlhip_final_exp(cid, ml.raw, 60, fe))
     assert fe.raw == cref.final_exp(cid, cref.miller_loop(cid, bytes(g1), bytes(g2), 3, 60, 8), 60, 8)
+
+
+# ---------------------------------------------------------------------------------------------
+# wire format: bulk NewG1FromBytes / NewG1FromCompressed and Bytes / Compressed
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("curve", CURVES)
+def test_g1_wire_codec_vs_oracle(lib, mlhip, curve):
+    from oracle import pyref as R
+
+    cp = R.CURVES[curve]
+    cid = cp.curve_id
+    n = cp.fp_bytes
+    d = R.Drbg("gpu/codec/" + curve)
+    pts = [R.random_g1(cp, d) for _ in range(40)] + [None, cp.g1, R.g1_neg(cp, cp.g1)]
+    for comp, enc in ((1, R.g1_wire_compressed), (0, R.g1_wire_uncompressed)):
+        wire = b"".join(enc(cp, p) for p in pts)
+        out = ctypes.create_string_buffer(2 * n * len(pts))
+        st = ctypes.create_string_buffer(len(pts))
+        mlhip.check(lib.mlhip_g1_from_bytes(cid, wire, len(pts), comp, 1, out, st))
+        assert st.raw == bytes(len(pts))
+        assert out.raw == b"".join(R.g1_to_mont_bytes(cp, p) for p in pts)
+        back = ctypes.create_string_buffer(len(wire))
+        mlhip.check(lib.mlhip_g1_to_bytes(cid, out.raw, len(pts), comp, back))
+        assert back.raw == wire  # runToFroBytesTest / runToFroCompressedTest (math_test.go:511-589)
+    # invalid encodings: every status must agree with the oracle's SetBytes restatement
+    bad = []
+    x = 1
+    while len(bad) < 4:  # x^3 + b a non-residue
+        x += 1
+        if R.fp_sqrt((x**3 + cp.b) % cp.p, cp.p) is None:
+            w = bytearray(x.to_bytes(n, "big"))
+            w[0] |= 0x80
+            bad.append(bytes(w))
+    w = bytearray(cp.p.to_bytes(n, "big"))  # coordinate >= p
+    w[0] |= 0x80
+    bad.append(bytes(w))
+    w = bytearray(R.g1_wire_compressed(cp, None))  # infinity with stray bits
+    w[7] = 3
+    bad.append(bytes(w))
+    if cp.family == "BLS12":  # on the curve but outside the r-torsion subgroup
+        x = 2
+        while True:
+            y = R.fp_sqrt((x**3 + cp.b) % cp.p, cp.p)
+            if y is not None and R.g1_mul_unreduced(cp, (x, y), cp.r) is not None:
+                break
+            x += 1
+        bad.append(R.g1_wire_compressed(cp, (x, y)))
+    bad.append(R.g1_wire_compressed(cp, pts[0]))  # a good one in between
+    st = ctypes.create_string_buffer(len(bad))
+    out = ctypes.create_string_buffer(2 * n * len(bad))
+    mlhip.check(lib.mlhip_g1_from_bytes(cid, b"".join(bad), len(bad), 1, 1, out, st))
+    assert list(st.raw) == [R.g1_from_wire(cp, w)[1] for w in bad]
+    assert out.raw[-2 * n :] == R.g1_to_mont_bytes(cp, pts[0])
+    w = bytearray(R.g1_wire_uncompressed(cp, pts[1]))  # uncompressed, off the curve
+    w[-1] ^= 1
+    st1 = ctypes.create_string_buffer(1)
+    mlhip.check(lib.mlhip_g1_from_bytes(cid, bytes(w), 1, 0, 1, ctypes.create_string_buffer(2 * n), st1))
+    assert st1.raw[0] == 2

@@ -169,3 +169,53 @@ def test_bucket_chunk_reduction_body(hostmath, name):
             w = R.g1_add(cp, w, R.g1_mul(cp, pts[8 * g + i], i) if pts[8 * g + i] is not None else None)
         assert R.g1_from_mont_bytes(cp, oa.raw[g * 2 * n : (g + 1) * 2 * n]) == a
         assert R.g1_from_mont_bytes(cp, ow.raw[g * 2 * n : (g + 1) * 2 * n]) == w
+
+
+@pytest.mark.parametrize("name", list(R.CURVES))
+def test_g1_wire_codec(hostmath, name):
+    """csrc/codec.h (sqrt incl. Tonelli-Shanks for BLS12-377, flag handling, subgroup check) vs the oracle's
+    restatement of gnark's SetBytes / Bytes / RawBytes."""
+    cp = R.CURVES[name]
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("host/codec/" + name)
+    pts = [R.random_g1(cp, d) for _ in range(6)] + [None, cp.g1]
+    for P in pts:
+        for comp, enc in ((1, R.g1_wire_compressed), (0, R.g1_wire_uncompressed)):
+            w = enc(cp, P)
+            out = ctypes.create_string_buffer(2 * n)
+            assert L.hm_g1_decode(cid, w, comp, 1, out) == 0
+            assert out.raw == R.g1_to_mont_bytes(cp, P)
+            back = ctypes.create_string_buffer(len(w))
+            L.hm_g1_encode(cid, out.raw, comp, back)
+            assert back.raw == w
+    bad = []
+    x = 1
+    while len(bad) < 3:
+        x += 1
+        if R.fp_sqrt((x**3 + cp.b) % cp.p, cp.p) is None:
+            w = bytearray(x.to_bytes(n, "big"))
+            w[0] |= 0x80
+            bad.append(bytes(w))
+    w = bytearray(cp.p.to_bytes(n, "big"))
+    w[0] |= 0x80
+    bad.append(bytes(w))
+    w = bytearray(R.g1_wire_compressed(cp, None))
+    w[5] = 1
+    bad.append(bytes(w))
+    if cp.family == "BLS12":
+        x = 2
+        while True:
+            y = R.fp_sqrt((x**3 + cp.b) % cp.p, cp.p)
+            if y is not None and R.g1_mul_unreduced(cp, (x, y), cp.r) is not None:
+                break
+            x += 1
+        bad.append(R.g1_wire_compressed(cp, (x, y)))
+        out = ctypes.create_string_buffer(2 * n)
+        assert L.hm_g1_decode(cid, bad[-1], 1, 0, out) == 0  # accepted when the subgroup check is off
+        assert out.raw == R.g1_to_mont_bytes(cp, (x, y))
+    for w in bad:
+        out = ctypes.create_string_buffer(2 * n)
+        want = R.g1_from_wire(cp, w)[1]
+        assert want != 0
+        assert L.hm_g1_decode(cid, w, 1, 1, out) == want
+        assert out.raw == bytes(2 * n)
