@@ -146,6 +146,14 @@ int mlhip_g1_to_bytes(int curve, const void* affine, size_t n, int compressed, v
 int mlhip_g1_from_bytes_device(int curve, const void* d_wire, size_t n, int compressed, int subgroup_check,
                                void* d_out_affine, unsigned char* d_status, void* stream);
 int mlhip_g1_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream);
+/* G2 (NewG2FromBytes / NewG2FromCompressed, bls12-381.go:541-569): 2 / 4 fp-sized big-endian values per point in
+ * the order X.A1, X.A0 [, Y.A1, Y.A0]; y recovered by a square root in Fp2; subgroup test [r]Q = infinity. */
+int mlhip_g2_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out_affine,
+                        unsigned char* status);
+int mlhip_g2_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire);
+int mlhip_g2_from_bytes_device(int curve, const void* d_wire, size_t n, int compressed, int subgroup_check,
+                               void* d_out_affine, unsigned char* d_status, void* stream);
+int mlhip_g2_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream);
 
 /* ---- group helpers (host, O(n) tiny): combine per-GPU partial results after the RCCL all-gather */
 int mlhip_g1_sum(int curve, const void* affine_points, size_t n, void* out_affine);

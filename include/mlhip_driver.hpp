@@ -221,6 +221,8 @@ class G2 {
   G2 Copy() const { return *this; }
   G2 Mul(const Zr& s) const;
   void Add(const G2& o);
+  Bytes ToBytes() const;     // X.A1 | X.A0 | Y.A1 | Y.A0 (gnark RawBytes), encoded on the device
+  Bytes Compressed() const;  // X.A1 | X.A0 with the header bits
 };
 
 class Gt {
@@ -326,6 +328,16 @@ class Curve {
     if (st) throw std::invalid_argument(std::string("set bytes failed [status ") + std::to_string((int)st) + "]");
     return g;
   }
+  G2 g2_from_wire(const Bytes& b, bool compressed) const {
+    if (b.size() != (size_t)(compressed ? 2 : 4) * fp_bytes) throw std::invalid_argument("set bytes failed [invalid length]");
+    G2 g = NewG2();
+    unsigned char st = 0;
+    check(mlhip_g2_from_bytes(id, b.data(), 1, compressed ? 1 : 0, 1, g.raw.data(), &st));
+    if (st) throw std::invalid_argument(std::string("set bytes failed [status ") + std::to_string((int)st) + "]");
+    return g;
+  }
+  G2 NewG2FromBytes(const Bytes& b) const { return g2_from_wire(b, false); }       // bls12-381.go:541-549
+  G2 NewG2FromCompressed(const Bytes& b) const { return g2_from_wire(b, true); }  // bls12-381.go:561-569
   G1 NewG1FromBytes(const Bytes& b) const { return g1_from_wire(b, false); }
   G1 NewG1FromCompressed(const Bytes& b) const { return g1_from_wire(b, true); }
   G2 NewG2() const {
@@ -549,6 +561,17 @@ inline Bytes G1::ToBytes() const {
   }
   return out;
 }
+inline Bytes G2::ToBytes() const {
+  Bytes out(4 * curve->fp_bytes);
+  check(mlhip_g2_to_bytes(curve->id, raw.data(), 1, 0, out.data()));
+  return out;
+}
+inline Bytes G2::Compressed() const {
+  Bytes out(2 * curve->fp_bytes);
+  check(mlhip_g2_to_bytes(curve->id, raw.data(), 1, 1, out.data()));
+  return out;
+}
+
 inline Bytes G1::Compressed() const {
   const Mod& fp = curve->fp;
   size_t n = curve->fp_bytes;

@@ -49,6 +49,10 @@ SYMBOLS = [
     "mlhip_g1_to_bytes",
     "mlhip_g1_from_bytes_device",
     "mlhip_g1_to_bytes_device",
+    "mlhip_g2_from_bytes",
+    "mlhip_g2_to_bytes",
+    "mlhip_g2_from_bytes_device",
+    "mlhip_g2_to_bytes_device",
     "mlhip_g1_sum",
     "mlhip_g2_sum",
     "mlhip_fp_mul_device",
@@ -114,6 +118,10 @@ def load() -> ctypes.CDLL:
     lib.mlhip_g1_to_bytes.argtypes = [ci, vp, sz, ci, vp]
     lib.mlhip_g1_from_bytes_device.argtypes = [ci, vp, sz, ci, ci, vp, vp, vp]
     lib.mlhip_g1_to_bytes_device.argtypes = [ci, vp, sz, ci, vp, vp]
+    lib.mlhip_g2_from_bytes.argtypes = [ci, vp, sz, ci, ci, vp, vp]
+    lib.mlhip_g2_to_bytes.argtypes = [ci, vp, sz, ci, vp]
+    lib.mlhip_g2_from_bytes_device.argtypes = [ci, vp, sz, ci, ci, vp, vp, vp]
+    lib.mlhip_g2_to_bytes_device.argtypes = [ci, vp, sz, ci, vp, vp]
     lib.mlhip_g1_sum.argtypes = [ci, vp, sz, vp]
     lib.mlhip_g2_sum.argtypes = [ci, vp, sz, vp]
     lib.mlhip_fp_mul_device.argtypes = [ci, vp, vp, sz, ci, vp, vp]

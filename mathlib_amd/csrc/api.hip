@@ -481,45 +481,46 @@ int mlhip_pairing_product(int curve, const void* g1, const void* g2, size_t n, v
   return rc;
 }
 
-static int tu_g1_codec(int curve, int encode, const void* d_in, size_t n, int compressed, int subgroup, void* d_out,
-                       void* d_status, hipStream_t st) {
+static int tu_wire_codec(int curve, int group, int encode, const void* d_in, size_t n, int compressed, int subgroup,
+                         void* d_out, void* d_status, hipStream_t st) {
   switch (curve) {
-    case MLHIP_CURVE_BN254: return mlhip_tu_g1_codec_Bn254(encode, d_in, n, compressed, subgroup, d_out, d_status, st);
-    case MLHIP_CURVE_BLS12_381: return mlhip_tu_g1_codec_Bls381(encode, d_in, n, compressed, subgroup, d_out, d_status, st);
-    case MLHIP_CURVE_BLS12_377: return mlhip_tu_g1_codec_Bls377(encode, d_in, n, compressed, subgroup, d_out, d_status, st);
+    case MLHIP_CURVE_BN254: return mlhip_tu_wire_codec_Bn254(group, encode, d_in, n, compressed, subgroup, d_out, d_status, st);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_wire_codec_Bls381(group, encode, d_in, n, compressed, subgroup, d_out, d_status, st);
+    case MLHIP_CURVE_BLS12_377: return mlhip_tu_wire_codec_Bls377(group, encode, d_in, n, compressed, subgroup, d_out, d_status, st);
     default: return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
   }
 }
 
-int mlhip_g1_from_bytes_device(int curve, const void* d_wire, size_t n, int compressed, int subgroup_check,
-                               void* d_out, unsigned char* d_status, void* stream) {
+static int from_bytes_device(int curve, int group, const void* d_wire, size_t n, int compressed, int subgroup_check,
+                             void* d_out, unsigned char* d_status, void* stream) {
   int rc = ensure_device();
   if (rc) return rc;
-  return tu_g1_codec(curve, 0, d_wire, n, compressed ? 1 : 0, subgroup_check ? 1 : 0, d_out, d_status, (hipStream_t)stream);
+  return tu_wire_codec(curve, group, 0, d_wire, n, compressed ? 1 : 0, subgroup_check ? 1 : 0, d_out, d_status, (hipStream_t)stream);
 }
 
-int mlhip_g1_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream) {
+static int to_bytes_device(int curve, int group, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream) {
   int rc = ensure_device();
   if (rc) return rc;
-  return tu_g1_codec(curve, 1, d_affine, n, compressed ? 1 : 0, 0, d_wire, nullptr, (hipStream_t)stream);
+  return tu_wire_codec(curve, group, 1, d_affine, n, compressed ? 1 : 0, 0, d_wire, nullptr, (hipStream_t)stream);
 }
 
-int mlhip_g1_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out,
-                        unsigned char* status) {
+static int from_bytes_host(int curve, int group, const void* wire, size_t n, int compressed, int subgroup_check, void* out,
+                           unsigned char* status) {
   Sizes sz;
   if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
   if (n == 0) return 0;
   if (!wire || !out || !status) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
   int rc = ensure_device();
   if (rc) return rc;
-  const size_t wlen = (compressed ? 1 : 2) * sz.fp;
+  const size_t psz = group == 2 ? sz.g2 : sz.g1;
+  const size_t wlen = compressed ? psz / 2 : psz;
   void *dw = nullptr, *dout = nullptr, *dst = nullptr;
   do {
-    if (hipMalloc(&dw, n * wlen) != hipSuccess || hipMalloc(&dout, n * sz.g1) != hipSuccess || hipMalloc(&dst, n) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc failed"); break; }
+    if (hipMalloc(&dw, n * wlen) != hipSuccess || hipMalloc(&dout, n * psz) != hipSuccess || hipMalloc(&dst, n) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc failed"); break; }
     if (hipMemcpy(dw, wire, n * wlen, hipMemcpyHostToDevice) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy H2D failed"); break; }
-    rc = mlhip_g1_from_bytes_device(curve, dw, n, compressed, subgroup_check, dout, (unsigned char*)dst, nullptr);
+    rc = from_bytes_device(curve, group, dw, n, compressed, subgroup_check, dout, (unsigned char*)dst, nullptr);
     if (rc) break;
-    if (hipMemcpy(out, dout, n * sz.g1, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(status, dst, n, hipMemcpyDeviceToHost) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy D2H failed"); break; }
+    if (hipMemcpy(out, dout, n * psz, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(status, dst, n, hipMemcpyDeviceToHost) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy D2H failed"); break; }
   } while (0);
   if (dw) (void)hipFree(dw);
   if (dout) (void)hipFree(dout);
@@ -527,25 +528,53 @@ int mlhip_g1_from_bytes(int curve, const void* wire, size_t n, int compressed, i
   return rc;
 }
 
-int mlhip_g1_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire) {
+static int to_bytes_host(int curve, int group, const void* affine, size_t n, int compressed, void* wire) {
   Sizes sz;
   if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
   if (n == 0) return 0;
   if (!affine || !wire) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
   int rc = ensure_device();
   if (rc) return rc;
-  const size_t wlen = (compressed ? 1 : 2) * sz.fp;
+  const size_t psz = group == 2 ? sz.g2 : sz.g1;
+  const size_t wlen = compressed ? psz / 2 : psz;
   void *dp = nullptr, *dw = nullptr;
   do {
-    if (hipMalloc(&dp, n * sz.g1) != hipSuccess || hipMalloc(&dw, n * wlen) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc failed"); break; }
-    if (hipMemcpy(dp, affine, n * sz.g1, hipMemcpyHostToDevice) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy H2D failed"); break; }
-    rc = mlhip_g1_to_bytes_device(curve, dp, n, compressed, dw, nullptr);
+    if (hipMalloc(&dp, n * psz) != hipSuccess || hipMalloc(&dw, n * wlen) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc failed"); break; }
+    if (hipMemcpy(dp, affine, n * psz, hipMemcpyHostToDevice) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy H2D failed"); break; }
+    rc = to_bytes_device(curve, group, dp, n, compressed, dw, nullptr);
     if (rc) break;
     if (hipMemcpy(wire, dw, n * wlen, hipMemcpyDeviceToHost) != hipSuccess) { rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy D2H failed"); break; }
   } while (0);
   if (dp) (void)hipFree(dp);
   if (dw) (void)hipFree(dw);
   return rc;
+}
+
+int mlhip_g1_from_bytes_device(int curve, const void* d_wire, size_t n, int compressed, int subgroup_check, void* d_out,
+                               unsigned char* d_status, void* stream) {
+  return from_bytes_device(curve, 1, d_wire, n, compressed, subgroup_check, d_out, d_status, stream);
+}
+int mlhip_g2_from_bytes_device(int curve, const void* d_wire, size_t n, int compressed, int subgroup_check, void* d_out,
+                               unsigned char* d_status, void* stream) {
+  return from_bytes_device(curve, 2, d_wire, n, compressed, subgroup_check, d_out, d_status, stream);
+}
+int mlhip_g1_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream) {
+  return to_bytes_device(curve, 1, d_affine, n, compressed, d_wire, stream);
+}
+int mlhip_g2_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream) {
+  return to_bytes_device(curve, 2, d_affine, n, compressed, d_wire, stream);
+}
+int mlhip_g1_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out, unsigned char* status) {
+  return from_bytes_host(curve, 1, wire, n, compressed, subgroup_check, out, status);
+}
+int mlhip_g2_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out, unsigned char* status) {
+  return from_bytes_host(curve, 2, wire, n, compressed, subgroup_check, out, status);
+}
+int mlhip_g1_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire) {
+  return to_bytes_host(curve, 1, affine, n, compressed, wire);
+}
+int mlhip_g2_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire) {
+  return to_bytes_host(curve, 2, affine, n, compressed, wire);
 }
 
 int mlhip_g1_sum(int curve, const void* pts, size_t n, void* out) {

@@ -12,6 +12,7 @@
 // status: 0 ok | 1 malformed encoding | 2 not on the curve | 3 not in the subgroup.
 #pragma once
 #include "ec.h"
+#include "pairing.h"  // fp_halve
 
 namespace mlhip {
 
@@ -218,5 +219,183 @@ MLHIP_HD void g1_encode(uint8_t* w, const Affine<FpField<C>>& P, bool compressed
     fp_to_be<C>(w + NB, y);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// G2: coordinates in Fp2, written imaginary part first (X.A1 | X.A0 [| Y.A1 | Y.A0]); the header bits sit in
+// byte 0 as for G1 (NewG2FromBytes / NewG2FromCompressed, driver/gurvy/bls12381/bls12-381.go:541-569; sizes
+// :507-517).  "Largest" for an Fp2 value compares A1 unless it is zero, then A0.
+// ---------------------------------------------------------------------------------------------------------
+
+// square root in Fp2 = Fp[u]/(u^2 - BETA); false when a is not a square.  With a = x^2, x = x0 + x1 u:
+// norm(a) = (x0^2 - BETA x1^2)^2, so s = sqrt(norm(a)) in Fp, x0^2 = (a0 +- s)/2, x1 = a1 / (2 x0).
+template <class C>
+MLHIP_HD bool fp2_sqrt(Fp2<C>& r, const Fp2<C>& a) {
+  Fp<C> t, s, d, x0, x1;
+  if (fp_is_zero<C>(a.c1)) {
+    if (fp_sqrt<C>(x0, a.c0)) {
+      r.c0 = x0;
+      fp_zero<C>(r.c1);
+      return true;
+    }
+    // a0 is a non-residue and so is BETA: a0 / BETA is a square and a = BETA x1^2
+    Fp<C> beta;
+    fp_one<C>(t);
+    fp_mul_beta<C>(beta, t);
+    fp_inv<C>(beta, beta);
+    fp_mul<C>(t, a.c0, beta);
+    if (!fp_sqrt<C>(x1, t)) return false;  // unreachable for prime p; kept as a guard
+    fp_zero<C>(r.c0);
+    r.c1 = x1;
+    return true;
+  }
+  fp_sqr<C>(t, a.c1);
+  fp_mul_beta<C>(t, t);
+  fp_sqr<C>(s, a.c0);
+  fp_sub<C>(s, s, t);  // norm
+  if (!fp_sqrt<C>(s, s)) return false;
+  fp_add<C>(d, a.c0, s);
+  fp_halve<C>(d, d);
+  if (!fp_sqrt<C>(x0, d)) {
+    fp_sub<C>(d, d, s);
+    if (!fp_sqrt<C>(x0, d)) return false;
+  }
+  fp_add<C>(t, x0, x0);
+  fp_inv<C>(t, t);
+  fp_mul<C>(x1, a.c1, t);
+  Fp2<C> x, chk;
+  x.c0 = x0;
+  x.c1 = x1;
+  fp2_sqr<C>(chk, x);
+  if (!fp2_eq<C>(chk, a)) return false;
+  r = x;
+  return true;
+}
+
+template <class C>
+MLHIP_HD bool fp2_is_largest(const Fp2<C>& a) {
+  return fp_is_zero<C>(a.c1) ? fp_is_largest<C>(a.c0) : fp_is_largest<C>(a.c1);
+}
+
+template <class C>
+MLHIP_HD bool g2_in_subgroup(const Affine<Fp2Field<C>>& Q) {
+  typedef Fp2Field<C> F;
+  XYZZ<F> acc;
+  xyzz_set_inf<F>(acc);
+  for (int i = C::FR_BITS - 1; i >= 0; i--) {
+    XYZZ<F> d;
+    xyzz_dbl<F>(d, acc);
+    acc = d;
+    if ((C::FR[i >> 5] >> (i & 31)) & 1u) xyzz_madd<F>(acc, Q, false);
+  }
+  return xyzz_is_inf<F>(acc);
+}
+
+// shared header parsing; returns CODEC_OK and the three flags, or CODEC_MALFORMED
+template <class C>
+MLHIP_HD int wire_flags(uint8_t flags, bool compressed, bool& f_inf, bool& f_largest, uint8_t& mask) {
+  bool f_comp;
+  if (C::ZCASH_FLAGS) {
+    f_comp = (flags & 0x80) != 0;
+    f_inf = (flags & 0x40) != 0;
+    f_largest = (flags & 0x20) != 0;
+    mask = 0x1F;
+    if (!f_comp && f_largest) return CODEC_MALFORMED;
+    if (f_inf && f_largest) return CODEC_MALFORMED;
+  } else {
+    const uint8_t hdr = flags & 0xC0;
+    f_inf = hdr == 0x40;
+    f_comp = (hdr & 0x80) != 0 || (f_inf && compressed);
+    f_largest = hdr == 0xC0;
+    mask = 0x3F;
+  }
+  return f_comp == compressed ? CODEC_OK : CODEC_MALFORMED;
+}
+
+template <class C>
+MLHIP_HD int g2_decode(Affine<Fp2Field<C>>& out, const uint8_t* w, bool compressed, bool subgroup_check) {
+  typedef Fp2Field<C> F;
+  constexpr int NB = C::N * 4;
+  fp2_zero<C>(out.x);
+  fp2_zero<C>(out.y);
+  bool f_inf, f_largest;
+  uint8_t mask;
+  if (wire_flags<C>(w[0], compressed, f_inf, f_largest, mask) != CODEC_OK) return CODEC_MALFORMED;
+  const int len = compressed ? 2 * NB : 4 * NB;
+  if (f_inf) {
+    uint32_t o = w[0] & mask;
+    for (int i = 1; i < len; i++) o |= w[i];
+    return o ? CODEC_MALFORMED : CODEC_OK;
+  }
+  Fp2<C> x, y, rhs, t, bt;
+  if (!fp_from_be<C>(x.c1, w, mask)) return CODEC_MALFORMED;
+  if (!fp_from_be<C>(x.c0, w + NB, 0xFF)) return CODEC_MALFORMED;
+  fp_to_mont<C>(x.c0, x.c0);
+  fp_to_mont<C>(x.c1, x.c1);
+  fp2_sqr<C>(t, x);
+  fp2_mul<C>(rhs, t, x);
+  fp2_from_const<C>(bt, C::B_TW);
+  fp2_add<C>(rhs, rhs, bt);
+  if (compressed) {
+    if (!fp2_sqrt<C>(y, rhs)) return CODEC_NOT_ON_CURVE;
+    if (fp2_is_largest<C>(y) != f_largest) fp2_neg<C>(y, y);
+  } else {
+    if (!fp_from_be<C>(y.c1, w + 2 * NB, 0xFF)) return CODEC_MALFORMED;
+    if (!fp_from_be<C>(y.c0, w + 3 * NB, 0xFF)) return CODEC_MALFORMED;
+    fp_to_mont<C>(y.c0, y.c0);
+    fp_to_mont<C>(y.c1, y.c1);
+    fp2_sqr<C>(t, y);
+    if (!fp2_eq<C>(t, rhs)) return CODEC_NOT_ON_CURVE;
+  }
+  Affine<F> Q;
+  Q.x = x;
+  Q.y = y;
+  if (subgroup_check && !g2_in_subgroup<C>(Q)) return CODEC_NOT_IN_SUBGROUP;
+  out = Q;
+  return CODEC_OK;
+}
+
+template <class C>
+MLHIP_HD void g2_encode(uint8_t* w, const Affine<Fp2Field<C>>& Q, bool compressed) {
+  constexpr int NB = C::N * 4;
+  const int len = compressed ? 2 * NB : 4 * NB;
+  if (affine_is_inf<Fp2Field<C>>(Q)) {
+    for (int i = 0; i < len; i++) w[i] = 0;
+    w[0] = C::ZCASH_FLAGS ? (compressed ? 0xC0 : 0x40) : 0x40;
+    return;
+  }
+  Fp<C> v;
+  fp_from_mont<C>(v, Q.x.c1);
+  fp_to_be<C>(w, v);
+  fp_from_mont<C>(v, Q.x.c0);
+  fp_to_be<C>(w + NB, v);
+  if (compressed) {
+    const bool largest = fp2_is_largest<C>(Q.y);
+    if (C::ZCASH_FLAGS)
+      w[0] |= 0x80 | (largest ? 0x20 : 0x00);
+    else
+      w[0] |= largest ? 0xC0 : 0x80;
+  } else {
+    fp_from_mont<C>(v, Q.y.c1);
+    fp_to_be<C>(w + 2 * NB, v);
+    fp_from_mont<C>(v, Q.y.c0);
+    fp_to_be<C>(w + 3 * NB, v);
+  }
+}
+
+// group tags for the kernels
+template <class C>
+struct G1Wire {
+  typedef Affine<FpField<C>> Aff;
+  static constexpr int XB = C::N * 4;  // bytes of one coordinate
+  MLHIP_HD static int decode(Aff& o, const uint8_t* w, bool comp, bool sg) { return g1_decode<C>(o, w, comp, sg); }
+  MLHIP_HD static void encode(uint8_t* w, const Aff& p, bool comp) { g1_encode<C>(w, p, comp); }
+};
+template <class C>
+struct G2Wire {
+  typedef Affine<Fp2Field<C>> Aff;
+  static constexpr int XB = C::N * 8;
+  MLHIP_HD static int decode(Aff& o, const uint8_t* w, bool comp, bool sg) { return g2_decode<C>(o, w, comp, sg); }
+  MLHIP_HD static void encode(uint8_t* w, const Aff& p, bool comp) { g2_encode<C>(w, p, comp); }
+};
 
 }  // namespace mlhip

@@ -1,4 +1,4 @@
-// codec_kernels.h -- bulk G1 wire decode / encode kernels (one point per lane).  Included by tu_codec_<curve>.hip.
+// codec_kernels.h -- bulk G1 / G2 wire decode / encode kernels (one point per lane).  Included by tu_codec_<curve>.hip.
 // Replaces NewG1FromBytes / NewG1FromCompressed and G1.Bytes / G1.Compressed of the reference drivers
 // (driver/gurvy/bls12381/bls12-381.go:531-569, :286-296) for arrays of points.
 #pragma once
@@ -7,12 +7,12 @@
 
 namespace mlhip {
 
-template <class C>
-__global__ void __launch_bounds__(64) k_g1_decode(const uint8_t* __restrict__ wire, size_t n, int compressed, int subgroup,
-                                                  Affine<FpField<C>>* __restrict__ out, uint8_t* __restrict__ status) {
+template <class W>
+__global__ void __launch_bounds__(64) k_wire_decode(const uint8_t* __restrict__ wire, size_t n, int compressed, int subgroup,
+                                                    typename W::Aff* __restrict__ out, uint8_t* __restrict__ status) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  constexpr int NB = C::N * 4;
+  constexpr int NB = W::XB;
   const int len = compressed ? NB : 2 * NB;
   // stage the point's bytes in registers/scratch through aligned 32-bit loads (len is a multiple of 4)
   uint8_t w[2 * NB];
@@ -24,36 +24,36 @@ __global__ void __launch_bounds__(64) k_g1_decode(const uint8_t* __restrict__ wi
     w[4 * k + 2] = (uint8_t)(v >> 16);
     w[4 * k + 3] = (uint8_t)(v >> 24);
   }
-  Affine<FpField<C>> p;
-  int st = g1_decode<C>(p, w, compressed != 0, subgroup != 0);
+  typename W::Aff p;
+  int st = W::decode(p, w, compressed != 0, subgroup != 0);
   out[i] = p;
   status[i] = (uint8_t)st;
 }
 
-template <class C>
-__global__ void __launch_bounds__(256) k_g1_encode(const Affine<FpField<C>>* __restrict__ pts, size_t n, int compressed,
-                                                   uint8_t* __restrict__ wire) {
+template <class W>
+__global__ void __launch_bounds__(256) k_wire_encode(const typename W::Aff* __restrict__ pts, size_t n, int compressed,
+                                                     uint8_t* __restrict__ wire) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  constexpr int NB = C::N * 4;
+  constexpr int NB = W::XB;
   const int len = compressed ? NB : 2 * NB;
   uint8_t w[2 * NB];
-  g1_encode<C>(w, pts[i], compressed != 0);
+  W::encode(w, pts[i], compressed != 0);
   uint32_t* dst = reinterpret_cast<uint32_t*>(wire + i * (size_t)len);
   for (int k = 0; k < len / 4; k++)
     dst[k] = (uint32_t)w[4 * k] | ((uint32_t)w[4 * k + 1] << 8) | ((uint32_t)w[4 * k + 2] << 16) | ((uint32_t)w[4 * k + 3] << 24);
 }
 
-template <class C>
-int g1_codec_device(int encode, const void* d_in, size_t n, int compressed, int subgroup, void* d_out, void* d_status,
+template <class W>
+int wire_codec_device(int encode, const void* d_in, size_t n, int compressed, int subgroup, void* d_out, void* d_status,
                     hipStream_t st) {
   if (n == 0) return 0;
   if (encode)
-    k_g1_encode<C><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const Affine<FpField<C>>*)d_in, n, compressed,
+    k_wire_encode<W><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const typename W::Aff*)d_in, n, compressed,
                                                                           (uint8_t*)d_out);
   else
-    k_g1_decode<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const uint8_t*)d_in, n, compressed, subgroup,
-                                                                        (Affine<FpField<C>>*)d_out, (uint8_t*)d_status);
+    k_wire_decode<W><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const uint8_t*)d_in, n, compressed, subgroup,
+                                                                        (typename W::Aff*)d_out, (uint8_t*)d_status);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -52,8 +52,8 @@ struct mlhip_msm_plan {
   int mlhip_tu_gt_mul_##NAME(const void* d_a, const void* d_b, size_t n, void* d_out, hipStream_t st);             \
   int mlhip_tu_gt_exp_##NAME(const void* d_in, const void* d_scalars, int mont, size_t n, void* d_out,             \
                              hipStream_t st);                                                                      \
-  int mlhip_tu_g1_codec_##NAME(int encode, const void* d_in, size_t n, int compressed, int subgroup, void* d_out,  \
-                               void* d_status, hipStream_t st);                                                    \
+  int mlhip_tu_wire_codec_##NAME(int group, int encode, const void* d_in, size_t n, int compressed, int subgroup,   \
+                                 void* d_out, void* d_status, hipStream_t st);                                     \
   int mlhip_tu_scalar_mul_##NAME(int group, const void* d_points, size_t point_stride, const void* d_scalars,     \
                                  int mont, size_t n, void* d_out, hipStream_t st);
 MLHIP_DECLARE_CURVE(Bn254)

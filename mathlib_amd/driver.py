@@ -229,6 +229,22 @@ class G2(_Element):
             return bytes(out)
         return b"".join(v.to_bytes(n, "big") for v in (q[0][1], q[0][0], q[1][1], q[1][0]))
 
+    def Compressed(self) -> bytes:
+        """compressed wire form X.A1 | X.A0; the sign bit follows gnark's E2 rule (A1 decides unless zero)"""
+        c = self.curve
+        n = c.fp_bytes
+        q = self.coords()
+        zcash = c.id != 0
+        if q is None:
+            out = bytearray(2 * n)
+            out[0] = 0xC0 if zcash else 0x40
+            return bytes(out)
+        out = bytearray(q[0][1].to_bytes(n, "big") + q[0][0].to_bytes(n, "big"))
+        half = (c.p - 1) // 2
+        big = q[1][1] > half if q[1][1] else q[1][0] > half
+        out[0] |= (0x80 | (0x20 if big else 0)) if zcash else (0xC0 if big else 0x80)
+        return bytes(out)
+
 
 class Gt(_Element):
     def Mul(self, o: "Gt") -> None:
@@ -290,16 +306,29 @@ class Curve:
 
     _CODEC_ERRORS = {1: "invalid point encoding", 2: "invalid point: not on the curve", 3: "invalid point: subgroup check failed"}
 
-    def _g1_from_wire(self, b: bytes, compressed: bool) -> G1:
-        out = ctypes.create_string_buffer(self.g1_bytes)
+    def _from_wire(self, group: int, b: bytes, compressed: bool):
+        size = self.g1_bytes if group == 1 else self.g2_bytes
+        out = ctypes.create_string_buffer(size)
         st = ctypes.create_string_buffer(1)
-        if len(b) != (self.fp_bytes if compressed else 2 * self.fp_bytes):
+        if len(b) != (size // 2 if compressed else size):
             raise ValueError("set bytes failed [invalid length]")
-        check(load().mlhip_g1_from_bytes(self.id, bytes(b), 1, 1 if compressed else 0, 1, out, st))
+        fn = load().mlhip_g1_from_bytes if group == 1 else load().mlhip_g2_from_bytes
+        check(fn(self.id, bytes(b), 1, 1 if compressed else 0, 1, out, st))
         if st.raw[0]:
             # the reference panics ("set bytes failed [...]"), the facade turns it into an error (math.go:761-832)
             raise ValueError("set bytes failed [%s]" % self._CODEC_ERRORS[st.raw[0]])
-        return G1(out.raw, self)
+        return G1(out.raw, self) if group == 1 else G2(out.raw, self)
+
+    def _g1_from_wire(self, b: bytes, compressed: bool) -> G1:
+        return self._from_wire(1, b, compressed)
+
+    def NewG2FromBytes(self, b: bytes) -> G2:
+        """bls12-381.go:541-549"""
+        return self._from_wire(2, b, False)
+
+    def NewG2FromCompressed(self, b: bytes) -> G2:
+        """bls12-381.go:561-569"""
+        return self._from_wire(2, b, True)
 
     def NewG1FromBytes(self, b: bytes) -> G1:
         """uncompressed wire form, subgroup-checked (driver/gurvy/bls12381/bls12-381.go:531-539)"""

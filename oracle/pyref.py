@@ -905,6 +905,91 @@ def g1_from_wire(cp: CurveParams, b: bytes, subgroup_check: bool = True):
     return P, 0
 
 
+def _wire_header(cp: CurveParams, flags: int, nbytes: int, short: int):
+    """(compressed, infinity, largest, mask) from byte 0, or None when the combination is malformed."""
+    if cp.family == "BLS12":
+        hdr, mask = flags & 0xE0, 0x1F
+        compressed, infinity, largest = bool(hdr & 0x80), bool(hdr & 0x40), bool(hdr & 0x20)
+        if (not compressed and largest) or (infinity and largest):
+            return None
+    else:
+        hdr, mask = flags & 0xC0, 0x3F
+        compressed = hdr in (0x80, 0xC0) or (hdr == 0x40 and nbytes == short)
+        infinity, largest = hdr == 0x40, hdr == 0xC0
+    return compressed, infinity, largest, mask
+
+
+def f2_is_largest(cp: CurveParams, a) -> bool:
+    """gnark E2.LexicographicallyLargest: decided by A1 unless it is zero, then by A0."""
+    half = (cp.p - 1) // 2
+    return a[1] > half if a[1] else a[0] > half
+
+
+def g2_wire_uncompressed(cp: CurveParams, Q) -> bytes:
+    """gnark G2Affine.RawBytes(): X.A1 | X.A0 | Y.A1 | Y.A0 big-endian."""
+    n = cp.fp_bytes
+    if Q is None:
+        out = bytearray(4 * n)
+        out[0] |= 0x40
+        return bytes(out)
+    (x0, x1), (y0, y1) = Q
+    return b"".join(v.to_bytes(n, "big") for v in (x1, x0, y1, y0))
+
+
+def g2_wire_compressed(cp: CurveParams, Q) -> bytes:
+    """gnark G2Affine.Bytes(): X.A1 | X.A0 with the header in byte 0."""
+    n = cp.fp_bytes
+    if Q is None:
+        out = bytearray(2 * n)
+        out[0] = 0xC0 if cp.family == "BLS12" else 0x40
+        return bytes(out)
+    (x0, x1), y = Q
+    out = bytearray(x1.to_bytes(n, "big") + x0.to_bytes(n, "big"))
+    big = f2_is_largest(cp, y)
+    if cp.family == "BLS12":
+        out[0] |= 0x80 | (0x20 if big else 0)
+    else:
+        out[0] |= 0xC0 if big else 0x80
+    return bytes(out)
+
+
+def g2_from_wire(cp: CurveParams, b: bytes, subgroup_check: bool = True):
+    """gnark G2Affine.SetBytes semantics (NewG2FromBytes / NewG2FromCompressed,
+    driver/gurvy/bls12381/bls12-381.go:541-569); status codes as g1_from_wire."""
+    n = cp.fp_bytes
+    T = tower(cp)
+    if len(b) not in (2 * n, 4 * n):
+        return None, 1
+    h = _wire_header(cp, b[0], len(b), 2 * n)
+    if h is None:
+        return None, 1
+    compressed, infinity, largest, mask = h
+    if len(b) != (2 * n if compressed else 4 * n):
+        return None, 1
+    body = bytes([b[0] & mask]) + b[1:]
+    if infinity:
+        return (None, 0) if not any(body) else (None, 1)
+    vals = [int.from_bytes(body[i : i + n], "big") for i in range(0, len(body), n)]
+    if any(v >= cp.p for v in vals):
+        return None, 1
+    x = (vals[1], vals[0])
+    rhs = T.f2_add(T.f2_mul(T.f2_sqr(x), x), twist_b(cp))
+    if compressed:
+        y = T.f2_sqrt(rhs)
+        if y is None:
+            return None, 2
+        if f2_is_largest(cp, y) != largest:
+            y = T.f2_neg(y)
+    else:
+        y = (vals[3], vals[2])
+        if T.f2_sqr(y) != rhs:
+            return None, 2
+    Q = (x, y)
+    if subgroup_check and g2_mul_unreduced(cp, Q, cp.r) is not None:
+        return None, 3
+    return Q, 0
+
+
 # --------------------------------------------------------------------------------------
 # Deterministic inputs (BASELINE.md section 3: SHA-256 counter DRBG, seed "mlhip-vec-1")
 # --------------------------------------------------------------------------------------

@@ -160,6 +160,11 @@ static void runPairingTest(const Curve& c, const G2& g2, uint64_t& st) {
   G2 sum = g2.Mul(r1);
   sum.Add(g2.Mul(r2));
   EXPECT(c.MultiScalarMulG2({g2, g2}, {r1, r2}).Equals(sum));
+  // G2 wire round trips (math_test.go:511-589 for G2)
+  EXPECT(c.NewG2FromBytes(sum.ToBytes()).Equals(sum));
+  EXPECT(c.NewG2FromCompressed(sum.Compressed()).Equals(sum));
+  EXPECT(c.NewG2FromCompressed(c.NewG2().Compressed()).IsInfinity());
+  printf("%s gen_g2_compressed %s\n", kNames[c.id], hex(g2.Compressed()).c_str());
 }
 
 int main(int argc, char** argv) {

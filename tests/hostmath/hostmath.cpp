@@ -49,6 +49,9 @@ struct Ops {
       case 1: fp2_sqr<C>(r, x); break;
       case 2: fp2_inv<C>(r, x); break;
       case 3: fp2_mul_xi<C>(r, x); break;
+      case 4:  // square root; returns 1 when x is not a square
+        if (!fp2_sqrt<C>(r, x)) return 1;
+        break;
       default: return -1;
     }
     memcpy(out, &r, sizeof(F2));
@@ -167,6 +170,18 @@ struct Ops {
     g1_encode<C>(w, p, compressed != 0);
     return 0;
   }
+  static int g2dec(const uint8_t* w, int compressed, int subgroup, void* out) {
+    A2 p;
+    int st = g2_decode<C>(p, w, compressed != 0, subgroup != 0);
+    memcpy(out, &p, sizeof(A2));
+    return st;
+  }
+  static int g2enc(const void* pt, int compressed, uint8_t* w) {
+    A2 p;
+    memcpy(&p, pt, sizeof(A2));
+    g2_encode<C>(w, p, compressed != 0);
+    return 0;
+  }
   static int miller(const void* g1s, const void* g2s, int n_pairs, void* out) {
     F12 f;
     miller_loop<C, 4>(f, (const A1*)g1s, (const A2*)g2s, n_pairs);
@@ -195,5 +210,7 @@ int hm_digits(int curve, const void* scalar, int mont, int c, uint32_t* out, int
 int hm_chunks(int curve, const void* pts, int n_chunks, void* outA, void* outW0) { DISPATCH(curve, chunks(pts, n_chunks, outA, outW0)) }
 int hm_g1_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g1dec(w, compressed, subgroup, out)) }
 int hm_g1_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g1enc(pt, compressed, w)) }
+int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g2dec(w, compressed, subgroup, out)) }
+int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }
 int hm_miller(int curve, const void* g1s, const void* g2s, int n_pairs, void* out) { DISPATCH(curve, miller(g1s, g2s, n_pairs, out)) }
 }

@@ -55,3 +55,4 @@ def test_cpp_driver_reference_tests_on_gpu():
         cp = R.CURVES[name]
         assert d[(name, "msm_40G_compressed")] == R.g1_wire_compressed(cp, R.g1_mul(cp, cp.g1, 40)).hex()
         assert d[(name, "gen_gt_bytes")] == load_golden(name)["gen_gt_wire"]
+        assert d[(name, "gen_g2_compressed")] == R.g2_wire_compressed(cp, R.g2_generator(cp)).hex()

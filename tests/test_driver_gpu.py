@@ -202,3 +202,15 @@ def test_runToFroBytesTest_and_compressed(curve):
         c.NewG1FromBytes(bytes(bad))
     with pytest.raises(ValueError):
         c.NewG1FromCompressed(p.Compressed()[:-1])
+
+
+def test_g2_wire_round_trips(curve):
+    c = curve
+    q = c._gen_g2.Mul(c.NewRandomZr(c._rng))
+    assert c.NewG2FromBytes(q.Bytes()).Equals(q)
+    assert c.NewG2FromCompressed(q.Compressed()).Equals(q)
+    assert c.NewG2FromCompressed(c.NewG2().Compressed()).IsInfinity()
+    bad = bytearray(q.Bytes())
+    bad[-1] ^= 1
+    with pytest.raises(ValueError):
+        c.NewG2FromBytes(bytes(bad))

@@ -325,3 +325,53 @@ def test_g1_wire_codec_vs_oracle(lib, mlhip, curve):
     st1 = ctypes.create_string_buffer(1)
     mlhip.check(lib.mlhip_g1_from_bytes(cid, bytes(w), 1, 0, 1, ctypes.create_string_buffer(2 * n), st1))
     assert st1.raw[0] == 2
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_g2_wire_codec_vs_oracle(lib, mlhip, curve):
+    from oracle import pyref as R
+
+    cp = R.CURVES[curve]
+    T = R.tower(cp)
+    cid = cp.curve_id
+    n = cp.fp_bytes
+    d = R.Drbg("gpu/codec2/" + curve)
+    g2 = R.g2_generator(cp)
+    pts = [R.random_g2(cp, d) for _ in range(12)] + [None, g2, R.g2_neg(cp, g2)]
+    for comp, enc in ((1, R.g2_wire_compressed), (0, R.g2_wire_uncompressed)):
+        wire = b"".join(enc(cp, p) for p in pts)
+        out = ctypes.create_string_buffer(4 * n * len(pts))
+        st = ctypes.create_string_buffer(len(pts))
+        mlhip.check(lib.mlhip_g2_from_bytes(cid, wire, len(pts), comp, 1, out, st))
+        assert st.raw == bytes(len(pts))
+        assert out.raw == b"".join(R.g2_to_mont_bytes(cp, p) for p in pts)
+        back = ctypes.create_string_buffer(len(wire))
+        mlhip.check(lib.mlhip_g2_to_bytes(cid, out.raw, len(pts), comp, back))
+        assert back.raw == wire
+    bad = []
+    k = 1
+    while len(bad) < 3:
+        k += 1
+        x = (k, 0) if len(bad) == 0 else (k, 1)
+        if T.f2_sqrt(T.f2_add(T.f2_mul(T.f2_sqr(x), x), R.twist_b(cp))) is None:
+            w = bytearray(x[1].to_bytes(n, "big") + x[0].to_bytes(n, "big"))
+            w[0] |= 0x80
+            bad.append(bytes(w))
+    w = bytearray((1).to_bytes(n, "big") + cp.p.to_bytes(n, "big"))
+    w[0] |= 0x80
+    bad.append(bytes(w))
+    w = bytearray(R.g2_wire_compressed(cp, None))
+    w[n + 3] = 1
+    bad.append(bytes(w))
+    Qx = R._g2_some_point(cp, 3)
+    bad.append(R.g2_wire_compressed(cp, Qx))
+    bad.append(R.g2_wire_compressed(cp, pts[0]))
+    st = ctypes.create_string_buffer(len(bad))
+    out = ctypes.create_string_buffer(4 * n * len(bad))
+    mlhip.check(lib.mlhip_g2_from_bytes(cid, b"".join(bad), len(bad), 1, 1, out, st))
+    want = [R.g2_from_wire(cp, w)[1] for w in bad]
+    assert want[-2] == 3 and want[-1] == 0
+    assert list(st.raw) == want
+    assert out.raw[-4 * n :] == R.g2_to_mont_bytes(cp, pts[0])
+    mlhip.check(lib.mlhip_g2_from_bytes(cid, b"".join(bad), len(bad), 1, 0, out, st))  # subgroup check off
+    assert st.raw[-2] == 0 and out.raw[-8 * n : -4 * n] == R.g2_to_mont_bytes(cp, Qx)
