@@ -72,8 +72,14 @@ __device__ __forceinline__ void lp_load_gt(Fp12<C, Fp2L<C>>& f, const Fp12<C>* i
 }
 
 // what: 0 = Miller loop of ppp pairs per product, 1 = final exponentiation, 2 = Miller (1 pair) + final exp
+// Two waves per SIMD: left alone, the register allocator takes ~36 AGPRs on top of the 256 VGPRs, which halves the
+// occupancy to one wave per SIMD -- and a lone wave can issue at most every other VALU slot on gfx950
+// (profiles/r01_ubench_int.txt, wps=1 vs wps=2).  The cap costs no extra scratch.
+#ifndef MLHIP_LP_OCC
+#define MLHIP_LP_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 template <class C, int WHAT>
-__global__ void __launch_bounds__(64) k_pairing_lp(const Affine<FpField<C>>* __restrict__ g1,
+__global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp(const Affine<FpField<C>>* __restrict__ g1,
                                                    const Affine<Fp2Field<C>>* __restrict__ g2, int ppp, size_t n,
                                                    const Fp12<C>* __restrict__ in, Fp12<C>* __restrict__ out) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
