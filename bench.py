@@ -198,6 +198,9 @@ def main() -> None:
         "int_alu": {
             "fp_mul_per_s": (n * 16 * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
             "mac_frac_of_measured_peak": ((n * 16 * 10 * MACS_PER_FP_MUL) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
+            # every multiply-add of the saturated 32-bit Montgomery product carries one add-with-carry: the issue
+            # peak of that instruction pair (profiles/r01_ubench_int.txt, "mad_u64+addc (pair)", 2 waves/SIMD)
+            "mad_addc_pair_frac_of_measured_peak": ((n * 16 * 10 * MACS_PER_FP_MUL) / (acc_ms * 1e-3)) / 1.572e13 if acc_ms > 0 else 0.0,
         },
     }
 
