@@ -31,6 +31,7 @@ struct mlhip_msm_plan {
   size_t zero_bytes = 0;
   void *d_buckets = nullptr, *d_A = nullptr, *d_W0 = nullptr, *d_out = nullptr;
   void* h_out = nullptr;
+  void* d_points28 = nullptr;  // G1: the points in the carry-free 28-bit-limb form (ec28.h), rewritten every MSM
   bool profiling = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t done = nullptr;

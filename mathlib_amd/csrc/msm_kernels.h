@@ -19,6 +19,7 @@
 
 #include <type_traits>
 
+#include "ec28.h"
 #include "fp2_lanes.h"
 #include "mlhip_internal.h"
 #include "msm_body.h"
@@ -371,6 +372,60 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
   buckets[g] = acc;
 }
 
+// ---- G1 accumulation in the carry-free 28-bit-limb form (fp28.h / ec28.h) -------------------------------------
+// k_points_to28 rewrites the n input points once per MSM (2 products per point); k_accumulate28 is k_accumulate on
+// that copy: ~14 % more mixed additions per second because a limb product is one v_mad_i64_i32 with no v_addc and
+// field additions carry nothing.  Bucket sums are stored in the boundary form, so every later kernel is unchanged.
+template <class C>
+__global__ void __launch_bounds__(256) k_points_to28(const Affine<FpField<C>>* __restrict__ points, size_t n,
+                                                     Affine28<C>* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine28<C> q;
+  affine28_from<C>(q, points[i]);
+  out[i] = q;
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_accumulate28(const Affine28<C>* __restrict__ points,
+                                                      const uint32_t* __restrict__ sorted,
+                                                      const uint32_t* __restrict__ offsets,
+                                                      const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                      const uint32_t* __restrict__ order, uint32_t big_threshold,
+                                                      uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
+                                                      XYZZ<FpField<C>>* __restrict__ buckets) {
+  size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n_buckets) return;
+  const size_t g = order[tid];
+  uint32_t cnt = counts[g];
+  if (cnt > big_threshold) {  // summed by a whole workgroup in k_accumulate_big (boundary form)
+    uint32_t pos = atomicAdd(big_count, 1u);
+    big_list[pos] = (uint32_t)g;
+    return;
+  }
+  XYZZ28<C> acc;
+  bool inf = true;
+  const size_t begin = offsets[g], end = begin + cnt;
+  if (cnt != 0) {
+    uint32_t e = sorted[begin];
+    Affine28<C> p = points[e & 0x7fffffffu];
+    for (size_t k = begin; k < end; k++) {
+      uint32_t en = e;
+      Affine28<C> pn = p;
+      if (k + 1 < end) {  // prefetch the next index and point under this addition
+        en = sorted[k + 1];
+        pn = points[en & 0x7fffffffu];
+      }
+      xyzz28_madd<C>(acc, inf, p, (e >> 31) != 0);
+      e = en;
+      p = pn;
+    }
+  }
+  XYZZ<FpField<C>> r;
+  xyzz28_to<C>(r, acc, inf);
+  buckets[g] = r;
+}
+
 // out-of-line group operations for kernels that use several of them (bounds the code size)
 template <class F>
 __device__ __noinline__ void xyzz_madd_ool(XYZZ<F>& acc, const Affine<F>& q) {
@@ -718,6 +773,15 @@ int plan_alloc(mlhip_msm_plan* p) {
     const size_t tiles = (std::max(nbuckets, hist_n) + SCAN_TILE - 1) / SCAN_TILE;
     HIPCHK(hipMalloc(&p->d_tilesums, (tiles + 1) * 4));
   }
+  if constexpr (std::is_same<F, FpField<typename F::Curve>>::value) {
+    // G1 accumulation in the carry-free form pays for the 12-limb fields (BLS12-381 / 377: -25 % cycles, -10 % time --
+    // the kernel is power limited, profiles/r01_pmc_clocks.txt); for BN254 (8 -> 10 limbs) it is slower, so
+    // MLHIP_ACC28=1 is needed to select it there.  MLHIP_ACC32=1 forces the boundary-form kernel everywhere.
+    const char* acc32 = getenv("MLHIP_ACC32");
+    const char* acc28 = getenv("MLHIP_ACC28");
+    const bool want28 = (F::Curve::N28 == 14 || (acc28 && acc28[0] == '1')) && !(acc32 && acc32[0] == '1');
+    if (want28) HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(Affine28<typename F::Curve>)));
+  }
   HIPCHK(hipMalloc(&p->d_buckets, nbuckets * p->xyzz_size));
   HIPCHK(hipMalloc(&p->d_A, (size_t)p->W * p->T * p->xyzz_size));
   HIPCHK(hipMalloc(&p->d_W0, (size_t)p->W * p->T * p->xyzz_size));
@@ -815,6 +879,12 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
       k_accumulate_lp<C><<<dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, st>>>(
           (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
           p->d_bigcount, (X*)p->d_buckets);
+    } else if (p->d_points28) {
+      k_points_to28<C><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const A*)d_points, n,
+                                                                                (Affine28<C>*)p->d_points28);
+      k_accumulate28<C><<<dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+          (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
+          p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
     } else {
       k_accumulate<F><<<dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st>>>(
           (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,

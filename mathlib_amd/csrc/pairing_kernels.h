@@ -135,10 +135,8 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
   if (n == 0) return 0;
   typedef Affine<FpField<C>> A1;
   typedef Affine<Fp2Field<C>> A2;
-  static const bool one_lane = [] {
-    const char* e = getenv("MLHIP_PAIRING_ONE_LANE");
-    return e && e[0] == '1';
-  }();
+  const char* one_lane_env = getenv("MLHIP_PAIRING_ONE_LANE");  // read per batch so a test can switch paths
+  const bool one_lane = one_lane_env && one_lane_env[0] == '1';
   if (one_lane) {
     unsigned blocks = (unsigned)((n + 63) / 64);
     switch (what) {

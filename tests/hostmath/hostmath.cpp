@@ -8,6 +8,7 @@
 #include "../../mathlib_amd/csrc/pairing.h"
 #include "../../mathlib_amd/csrc/msm_body.h"
 #include "../../mathlib_amd/csrc/codec.h"
+#include "../../mathlib_amd/csrc/ec28.h"
 
 using namespace mlhip;
 
@@ -170,6 +171,66 @@ struct Ops {
     g1_encode<C>(w, p, compressed != 0);
     return 0;
   }
+  // carry-free 28-bit-limb form (fp28.h): op 0 round trip, 1 mul, 2 sqr, 3 dual product a b + c d, all through the
+  // boundary conversions; op 4: (a - b) is zero mod p ?  returns the exact test's answer in out[0]
+  static int fp28_op(int op, const void* a, const void* b, const void* c, const void* d, void* out) {
+    F x[4], r;
+    const void* in[4] = {a, b, c, d};
+    Fp28<C> v[4], w, t;
+    for (int i = 0; i < 4; i++) {
+      if (!in[i]) { fp_zero<C>(x[i]); } else memcpy(&x[i], in[i], sizeof(F));
+      fp28_from_fp<C>(v[i], x[i]);
+    }
+    switch (op) {
+      case 0: w = v[0]; break;
+      case 1: fp28_mul<C>(w, v[0], v[1]); break;
+      case 2: fp28_sqr<C>(w, v[0]); break;
+      case 3: fp28_mul2<C>(w, v[0], v[1], v[2], v[3]); break;
+      case 4: {
+        fp28_sub<C>(w, v[0], v[1]);
+        bool z = fp28_maybe_zero<C>(w) && fp28_is_zero_exact<C>(w);
+        *(int*)out = z ? 1 : 0;
+        return 0;
+      }
+      case 5:  // stress the weight limits: (a + b) (c - d) with weights 2 x 2, then squared sum (weight 2)
+        fp28_add<C>(w, v[0], v[1]);
+        fp28_sub<C>(t, v[2], v[3]);
+        fp28_mul<C>(w, w, t);
+        break;
+      case 6:  // ((a - b) - c - c) normalized (weight 4 -> 1), times d
+        fp28_sub<C>(w, v[0], v[1]);
+        fp28_sub<C>(w, w, v[2]);
+        fp28_sub<C>(w, w, v[2]);
+        fp28_normalize<C>(w, w);
+        fp28_mul<C>(w, w, v[3]);
+        break;
+      case 7:  // (a - b)^2
+        fp28_sub<C>(w, v[0], v[1]);
+        fp28_sqr<C>(w, w);
+        break;
+      default: return -1;
+    }
+    fp28_to_fp<C>(r, w);
+    memcpy(out, &r, sizeof(F));
+    return 0;
+  }
+  // bucket accumulation through xyzz28_madd: sum of +-points, returned affine in the boundary form
+  static int madd28_chain(const void* pts, const uint8_t* neg, int n, void* out) {
+    const A1* p = (const A1*)pts;
+    XYZZ28<C> acc;
+    bool inf = true;
+    for (int i = 0; i < n; i++) {
+      Affine28<C> q;
+      affine28_from<C>(q, p[i]);
+      xyzz28_madd<C>(acc, inf, q, neg[i] != 0);
+    }
+    X1 a;
+    xyzz28_to<C>(a, acc, inf);
+    A1 r;
+    xyzz_to_affine<FpField<C>>(r, a);
+    memcpy(out, &r, sizeof(A1));
+    return 0;
+  }
   static int g2dec(const uint8_t* w, int compressed, int subgroup, void* out) {
     A2 p;
     int st = g2_decode<C>(p, w, compressed != 0, subgroup != 0);
@@ -210,6 +271,8 @@ int hm_digits(int curve, const void* scalar, int mont, int c, uint32_t* out, int
 int hm_chunks(int curve, const void* pts, int n_chunks, void* outA, void* outW0) { DISPATCH(curve, chunks(pts, n_chunks, outA, outW0)) }
 int hm_g1_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g1dec(w, compressed, subgroup, out)) }
 int hm_g1_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g1enc(pt, compressed, w)) }
+int hm_fp28_op(int curve, int op, const void* a, const void* b, const void* c, const void* d, void* out) { DISPATCH(curve, fp28_op(op, a, b, c, d, out)) }
+int hm_madd28_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_chain(pts, neg, n, out)) }
 int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g2dec(w, compressed, subgroup, out)) }
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }
 int hm_miller(int curve, const void* g1s, const void* g2s, int n_pairs, void* out) { DISPATCH(curve, miller(g1s, g2s, n_pairs, out)) }

@@ -375,3 +375,42 @@ def test_g2_wire_codec_vs_oracle(lib, mlhip, curve):
     assert out.raw[-4 * n :] == R.g2_to_mont_bytes(cp, pts[0])
     mlhip.check(lib.mlhip_g2_from_bytes(cid, b"".join(bad), len(bad), 1, 0, out, st))  # subgroup check off
     assert st.raw[-2] == 0 and out.raw[-8 * n : -4 * n] == R.g2_to_mont_bytes(cp, Qx)
+
+
+# ---------------------------------------------------------------------------------------------
+# alternate code paths selected by environment switches (read when a plan is created / a batch is launched):
+# every one must give the same bytes as the default path
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("switch", ["MLHIP_LEGACY_SORT", "MLHIP_ACC32", "MLHIP_ACC28"])
+def test_msm_alternate_paths(lib, mlhip, curve, switch, monkeypatch):
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    fpb, g1b, _, _ = mlhip.sizes(cid)
+    pts, scs, exp = load_msm1000(curve, fpb)
+    monkeypatch.setenv(switch, "1")
+    for window_c in (9, 16):
+        out = ctypes.create_string_buffer(g1b)
+        mlhip.check(lib.mlhip_msm_g1(cid, pts, scs, 0, 1000, window_c, out))
+        assert out.raw == exp, (curve, switch, window_c)
+    for case in g["msm_g1"]:  # the edge cases: infinity inputs, P and -P, duplicates, zero scalars ...
+        p = b"".join(_h(x) for x in case["points"])
+        sc = b"".join(_h(x) for x in case["scalars"])
+        out = ctypes.create_string_buffer(g1b)
+        mlhip.check(lib.mlhip_msm_g1(cid, p, sc, 0, len(case["points"]), 5, out))
+        assert out.raw == _h(case["expected"]), (curve, switch, case["name"])
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_pairing_one_lane_kernels_agree(lib, mlhip, curve, monkeypatch):
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, g1b, g2b, gtb = mlhip.sizes(cid)
+    cases = g["pairing"]
+    p1 = b"".join(_h(c["g1"]) for c in cases)
+    p2 = b"".join(_h(c["g2"]) for c in cases)
+    exp = b"".join(_h(c["fexp"]) for c in cases)
+    monkeypatch.setenv("MLHIP_PAIRING_ONE_LANE", "1")
+    out = ctypes.create_string_buffer(gtb * len(cases))
+    mlhip.check(lib.mlhip_pairing_batch(cid, p1, p2, len(cases), out))
+    assert out.raw == exp

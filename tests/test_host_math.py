@@ -307,3 +307,66 @@ def test_fp2_sqrt_all_branches(hostmath, name):
             r = (R.fp_from_mont_bytes(cp, out.raw[: cp.fp_bytes]), R.fp_from_mont_bytes(cp, out.raw[cp.fp_bytes :]))
             assert T.f2_sqr(r) == (a[0] % cp.p, a[1] % cp.p)  # either root is valid; the codec fixes the sign afterwards
     assert 5 <= squares < len(cases)
+
+
+@pytest.mark.parametrize("name", list(R.CURVES))
+def test_fp28_carry_free_form(hostmath, name):
+    """csrc/fp28.h: conversions, product / square / dual product, lazy sums at the documented weight limits and
+    the exact zero test, against Python integers."""
+    cp = R.CURVES[name]
+    L, cid, p = hostmath, cp.curve_id, cp.p
+    d = R.Drbg("host/fp28/" + name)
+    mb = lambda v: R.fp_to_mont_bytes(cp, v % p)
+
+    def run(op, vals):
+        out = ctypes.create_string_buffer(cp.fp_bytes)
+        args = [mb(v) for v in vals] + [None] * (4 - len(vals))
+        assert L.hm_fp28_op(cid, op, *args, out) == 0
+        return out.raw
+
+    edge = [0, 1, p - 1, p - 2, (p - 1) // 2, 2, (1 << 28) - 1, 1 << 28, (1 << (cp.fp_bytes * 8 - 8)) % p]
+    rnd = [d.below(p) for _ in range(24)]
+    for a in edge + rnd[:8]:
+        assert run(0, [a]) == mb(a)
+        assert run(2, [a]) == mb(a * a)
+    vals = edge + rnd
+    for i in range(0, len(vals) - 3):
+        a, b, c, e = vals[i : i + 4]
+        assert run(1, [a, b]) == mb(a * b)
+        assert run(3, [a, b, c, e]) == mb(a * b + c * e)
+        assert run(5, [a, b, c, e]) == mb((a + b) * (c - e))
+        assert run(6, [a, b, c, e]) == mb((a - b - 2 * c) * e)
+        assert run(7, [a, b]) == mb((a - b) ** 2)
+    zt = ctypes.create_string_buffer(cp.fp_bytes)
+    for a, b in [(5, 5), (0, 0), (p - 1, p - 1), (rnd[0], rnd[0]), (rnd[0], rnd[1]), (1, 0), (0, p - 1)]:
+        assert L.hm_fp28_op(cid, 4, mb(a), mb(b), None, None, zt) == 0
+        assert int.from_bytes(zt.raw[:4], "little") == (1 if (a - b) % p == 0 else 0)
+
+
+@pytest.mark.parametrize("name", list(R.CURVES))
+def test_madd28_bucket_accumulation(hostmath, name):
+    """ec28.h: a bucket's running sum in the carry-free form equals the oracle's, including the exceptional
+    cases (P + P, P - P, infinity inputs, restart after cancelling to infinity)."""
+    cp = R.CURVES[name]
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("host/madd28/" + name)
+    P = [R.random_g1(cp, d) for _ in range(6)]
+    cases = [
+        [(P[0], 0)],
+        [(P[0], 1)],
+        [(P[i], i & 1) for i in range(6)],
+        [(P[0], 0), (P[0], 0), (P[1], 0)],            # doubling inside the chain
+        [(P[0], 0), (P[0], 1), (P[1], 1), (P[2], 0)],  # cancels to infinity, then restarts
+        [(None, 0), (P[3], 0), (None, 1), (P[3], 0), (P[3], 0)],
+        [(P[0], 0), (P[1], 0), (R.g1_add(cp, P[0], P[1]), 1)],  # ends at infinity
+        [(P[i % 6], (i * 7) & 1) for i in range(40)],
+    ]
+    for seq in cases:
+        pts = b"".join(R.g1_to_mont_bytes(cp, q) for q, _ in seq)
+        neg = bytes(s for _, s in seq)
+        want = None
+        for q, s in seq:
+            want = R.g1_add(cp, want, R.g1_neg(cp, q) if s else q)
+        out = ctypes.create_string_buffer(2 * n)
+        assert L.hm_madd28_chain(cid, pts, neg, len(seq), out) == 0
+        assert out.raw == R.g1_to_mont_bytes(cp, want)
