@@ -33,6 +33,7 @@ struct mlhip_msm_plan {
   void* h_out = nullptr;
   void* d_points28 = nullptr;  // G1: the points in the carry-free 28-bit-limb form (ec28.h), rewritten every MSM
   bool profiling = false;
+  bool reduce_one_lane = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t done = nullptr;
   bool pending = false;

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "ec28.h"
+#include "ec_quad.h"
 #include "fp2_lanes.h"
 #include "mlhip_internal.h"
 #include "msm_body.h"
@@ -516,6 +517,99 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums(const XYZZ<F>* __restrict
   if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
+// ---- the same two reduction levels with one point per QUAD of lanes (ec_quad.h): 3.5x shallower chains -------
+template <class C>
+__device__ __forceinline__ void quad_load(Fp<C>& v, const XYZZ<FpField<C>>* arr, size_t idx) {
+  v = reinterpret_cast<const Fp<C>*>(arr + idx)[threadIdx.x & 3u];
+}
+template <class C>
+__device__ __forceinline__ void quad_store(XYZZ<FpField<C>>* arr, size_t idx, const Fp<C>& v) {
+  reinterpret_cast<Fp<C>*>(arr + idx)[threadIdx.x & 3u] = v;
+}
+template <class C>
+__device__ __forceinline__ void quad_set_inf(Fp<C>& v) {  // (1, 1, 0, 0)
+  Fp<C> one, zero;
+  fp_one<C>(one);
+  fp_zero<C>(zero);
+  fp_select<C>(v, (threadIdx.x & 2u) != 0, zero, one);
+}
+
+// quad g of window w owns buckets [g L, (g+1) L): A = sum B_b, W0 = sum_i i B_{gL+i} (msm_chunk_body's order)
+template <class C>
+__global__ void __launch_bounds__(256) k_chunks_q(const XYZZ<FpField<C>>* __restrict__ buckets, size_t n_chunks, int l_eff,
+                                                  XYZZ<FpField<C>>* __restrict__ A, XYZZ<FpField<C>>* __restrict__ W0) {
+  typedef QuadDevice<C> B;
+  const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (g >= n_chunks) return;  // quad-uniform
+  const XYZZ<FpField<C>>* b = buckets + g * (size_t)l_eff;
+  Fp<C> acc, w0, cur, x, y;
+  quad_set_inf<C>(acc);
+  quad_set_inf<C>(w0);
+  quad_load<C>(cur, b, l_eff - 1);
+  const int steps = 2 * (l_eff - 1) + 1;  // acc += b[i]; w0 += acc; ... ; acc += b[0]
+#pragma unroll 1
+  for (int s = 0; s < steps; s++) {
+    const bool odd = (s & 1) != 0;
+    const int i = l_eff - 1 - (s >> 1);
+    fp_select<C>(x, odd, w0, acc);
+    fp_select<C>(y, odd, acc, cur);
+    if (!odd && i > 0) quad_load<C>(cur, b, i - 1);  // the next bucket arrives under this addition
+    quad_xyzz_add<C, B>(x, y);
+    fp_select<C>(w0, odd, x, w0);
+    fp_select<C>(acc, odd, acc, x);
+  }
+  quad_store<C>(A, g, acc);
+  quad_store<C>(W0, g, w0);
+}
+
+// same selections as k_masked_sums; BLOCK / 4 quads per block
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_masked_sums_q(const XYZZ<FpField<C>>* __restrict__ A,
+                                                         const XYZZ<FpField<C>>* __restrict__ W0, uint32_t T, int nsel,
+                                                         XYZZ<FpField<C>>* __restrict__ out) {
+  typedef QuadDevice<C> B;
+  typedef XYZZ<FpField<C>> X;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  X* sh = reinterpret_cast<X*>(smem);
+  constexpr uint32_t NQ = BLOCK / 4;
+  const uint32_t quad = threadIdx.x >> 2;
+  const uint32_t w = blockIdx.x / nsel;
+  const int sel = blockIdx.x % nsel;
+  const X* src = (sel < 2 ? W0 : A) + (size_t)w * T;
+  Fp<C> acc, v;
+  quad_set_inf<C>(acc);
+  // element j of this block's list -> index t into src (plain halves or "bit k set")
+  uint32_t count, lo = 0;
+  int k = 0;
+  if (sel < 4) {
+    const uint32_t half = (T + 1) / 2;
+    lo = (sel & 1) ? half : 0u;
+    count = ((sel & 1) ? T : half) - lo;
+  } else {
+    k = sel - 4;
+    count = T / 2;
+  }
+  const uint32_t lowmask = (1u << k) - 1u;
+#pragma unroll 1
+  for (uint32_t j = quad; j < count; j += NQ) {
+    const uint32_t t = sel < 4 ? lo + j : (((j >> k) << (k + 1)) | (1u << k) | (j & lowmask));
+    quad_load<C>(v, src, t);
+    quad_xyzz_add<C, B>(acc, v);
+  }
+  quad_store<C>(sh, quad, acc);
+  __syncthreads();
+#pragma unroll 1
+  for (uint32_t s = NQ / 2; s > 0; s >>= 1) {
+    if (quad < s) {  // quad-uniform
+      quad_load<C>(v, sh, quad + s);
+      quad_xyzz_add<C, B>(acc, v);
+      quad_store<C>(sh, quad, acc);
+    }
+    __syncthreads();
+  }
+  if (quad == 0) quad_store<C>(out, blockIdx.x, acc);
+}
+
 // out[i] = [s_i] P_i: batched single-scalar multiplication (the reference's G1.Mul / G2.Mul,
 // driver/gurvy/bls12381/bls12-381.go:238-247, :342-351; double-and-add shape of :920-932), one lane per
 // product, 4-bit fixed windows: 15-entry table in scratch, 4 doublings + 1 addition per window.
@@ -773,6 +867,10 @@ int plan_alloc(mlhip_msm_plan* p) {
     const size_t tiles = (std::max(nbuckets, hist_n) + SCAN_TILE - 1) / SCAN_TILE;
     HIPCHK(hipMalloc(&p->d_tilesums, (tiles + 1) * 4));
   }
+  {
+    const char* one_lane = getenv("MLHIP_REDUCE_ONE_LANE");  // =1: the one-point-per-lane reduction kernels
+    p->reduce_one_lane = one_lane && one_lane[0] == '1';
+  }
   if constexpr (std::is_same<F, FpField<typename F::Curve>>::value) {
     // G1 accumulation in the carry-free form pays for the 12-limb fields (BLS12-381 / 377: -25 % cycles, -10 % time --
     // the kernel is power limited, profiles/r01_pmc_clocks.txt); for BN254 (8 -> 10 limbs) it is slower, so
@@ -906,11 +1004,20 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
         k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 2) * sizeof(X), st>>>(
             (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
       } else {
-        k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
-                                                                                     p->L, (X*)p->d_A, (X*)p->d_W0);
-        constexpr int RB = 256;  // 48 KB of LDS per block
-        k_masked_sums<F, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), RB * sizeof(X), st>>>(
-            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+        if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created
+          k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                       p->L, (X*)p->d_A, (X*)p->d_W0);
+          constexpr int RB = 256;  // 48 KB of LDS per block
+          k_masked_sums<F, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), RB * sizeof(X), st>>>(
+              (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+        } else {
+          // one point per quad of lanes: a group addition is 4 rounds of one multiplication instead of 14 in a row
+          k_chunks_q<C><<<dim3((unsigned)((4 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                           p->L, (X*)p->d_A, (X*)p->d_W0);
+          constexpr int RB = 512;  // 128 quads, 24 KB of LDS per block
+          k_masked_sums_q<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
+              (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+        }
       }
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[4], st));

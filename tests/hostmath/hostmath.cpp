@@ -9,6 +9,7 @@
 #include "../../mathlib_amd/csrc/msm_body.h"
 #include "../../mathlib_amd/csrc/codec.h"
 #include "../../mathlib_amd/csrc/ec28.h"
+#include "../../mathlib_amd/csrc/ec_quad.h"
 
 using namespace mlhip;
 
@@ -231,6 +232,39 @@ struct Ops {
     memcpy(out, &r, sizeof(A1));
     return 0;
   }
+  // quad-lane XYZZ addition (ec_quad.h) through the host emulation backend: fold a list of XYZZ points given as
+  // affine inputs scaled by per-point z (so that ZZ != 1): out = affine sum
+  static int quad_chain(const void* pts, const void* zs, int n, void* out) {
+    typedef QuadHost<C> B;
+    const A1* p = (const A1*)pts;
+    const F* z = (const F*)zs;
+    typename B::V acc;
+    X1 inf;
+    xyzz_set_inf<FpField<C>>(inf);
+    B::scatter(acc, inf);
+    for (int i = 0; i < n; i++) {
+      X1 q;
+      xyzz_from_affine<FpField<C>>(q, p[i]);
+      if (!xyzz_is_inf<FpField<C>>(q) && !fp_is_zero<C>(z[i])) {  // (x z^2, y z^3, z^2, z^3) is the same point
+        F z2, z3;
+        fp_sqr<C>(z2, z[i]);
+        fp_mul<C>(z3, z2, z[i]);
+        fp_mul<C>(q.x, q.x, z2);
+        fp_mul<C>(q.y, q.y, z3);
+        q.zz = z2;
+        q.zzz = z3;
+      }
+      typename B::V b;
+      B::scatter(b, q);
+      quad_xyzz_add<C, B>(acc, b);
+    }
+    X1 r;
+    B::gather(r, acc);
+    A1 a;
+    xyzz_to_affine<FpField<C>>(a, r);
+    memcpy(out, &a, sizeof(A1));
+    return 0;
+  }
   static int g2dec(const uint8_t* w, int compressed, int subgroup, void* out) {
     A2 p;
     int st = g2_decode<C>(p, w, compressed != 0, subgroup != 0);
@@ -273,6 +307,7 @@ int hm_g1_decode(int curve, const uint8_t* w, int compressed, int subgroup, void
 int hm_g1_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g1enc(pt, compressed, w)) }
 int hm_fp28_op(int curve, int op, const void* a, const void* b, const void* c, const void* d, void* out) { DISPATCH(curve, fp28_op(op, a, b, c, d, out)) }
 int hm_madd28_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_chain(pts, neg, n, out)) }
+int hm_quad_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, quad_chain(pts, zs, n, out)) }
 int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g2dec(w, compressed, subgroup, out)) }
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }
 int hm_miller(int curve, const void* g1s, const void* g2s, int n_pairs, void* out) { DISPATCH(curve, miller(g1s, g2s, n_pairs, out)) }

@@ -370,3 +370,32 @@ def test_madd28_bucket_accumulation(hostmath, name):
         out = ctypes.create_string_buffer(2 * n)
         assert L.hm_madd28_chain(cid, pts, neg, len(seq), out) == 0
         assert out.raw == R.g1_to_mont_bytes(cp, want)
+
+
+@pytest.mark.parametrize("name", list(R.CURVES))
+def test_quad_lane_xyzz_add(hostmath, name):
+    """ec_quad.h: the four-rounds-of-one-multiplication schedule of XYZZ + XYZZ (host emulation of the DPP
+    permutes) equals the oracle, including doubling, cancellation and infinity operands."""
+    cp = R.CURVES[name]
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("host/quad/" + name)
+    P = [R.random_g1(cp, d) for _ in range(5)]
+    neg = lambda q: R.g1_neg(cp, q)
+    cases = [
+        [P[0]],
+        [P[0], P[1], P[2], P[3], P[4]],
+        [P[0], P[0]],                      # doubling (different z on both sides)
+        [P[0], P[1], neg(R.g1_add(cp, P[0], P[1])), P[2]],  # hits infinity, then restarts
+        [None, P[0], None, P[1]],
+        [P[2], neg(P[2])],
+        [P[i % 5] for i in range(23)],
+    ]
+    for seq in cases:
+        pts = b"".join(R.g1_to_mont_bytes(cp, q) for q in seq)
+        zs = b"".join(R.fp_to_mont_bytes(cp, 1 + d.below(cp.p - 1)) for _ in seq)
+        want = None
+        for q in seq:
+            want = R.g1_add(cp, want, q)
+        out = ctypes.create_string_buffer(2 * n)
+        assert L.hm_quad_chain(cid, pts, zs, len(seq), out) == 0
+        assert out.raw == R.g1_to_mont_bytes(cp, want)
