@@ -239,6 +239,9 @@ int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
   for (int i = 0; i < 5; i++)
     if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
   if (p->done) (void)hipEventDestroy(p->done);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  if (p->aux) (void)hipStreamDestroy(p->aux);
   delete p;
   return 0;
 }

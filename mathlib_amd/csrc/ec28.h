@@ -78,7 +78,14 @@ MLHIP_HD void xyzz28_madd(XYZZ28<C>& acc, bool& inf, const Affine28<C>& q_in, bo
   fp28_sub<C>(R, S2, acc.y);      // weight 2
   if (fp28_maybe_zero<C>(P)) {
     if (fp28_is_zero_exact<C>(P)) {
-      xyzz28_madd_exact<C>(acc, inf, q);
+      // copies: only these cold-path temporaries have their address taken, so the caller's accumulator stays in
+      // registers (handing `acc` itself to the out-of-line function pins it in scratch for the whole loop)
+      XYZZ28<C> ta = acc;
+      Affine28<C> tq = q;
+      bool ti = inf;
+      xyzz28_madd_exact<C>(ta, ti, tq);
+      acc = ta;
+      inf = ti;
       return;
     }
   }

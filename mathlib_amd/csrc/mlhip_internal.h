@@ -36,6 +36,8 @@ struct mlhip_msm_plan {
   bool reduce_one_lane = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t done = nullptr;
+  hipStream_t aux = nullptr;  // the point conversion runs here, beside the sort kernels
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool pending = false;
   size_t pending_n = 0;
   float ms[6] = {0, 0, 0, 0, 0, 0};

@@ -382,7 +382,7 @@ def test_g2_wire_codec_vs_oracle(lib, mlhip, curve):
 # every one must give the same bytes as the default path
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("switch", ["MLHIP_LEGACY_SORT", "MLHIP_ACC32", "MLHIP_ACC28", "MLHIP_REDUCE_ONE_LANE"])
+@pytest.mark.parametrize("switch", ["MLHIP_LEGACY_SORT", "MLHIP_ACC32", "MLHIP_REDUCE_ONE_LANE"])
 def test_msm_alternate_paths(lib, mlhip, curve, switch, monkeypatch):
     g = load_golden(curve)
     cid = g["curve_id"]
