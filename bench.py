@@ -168,8 +168,13 @@ def main() -> None:
     phase = {kname: v / steps for kname, v in phase.items()}
     value = world * n * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (k_accumulate): algorithmic bytes / its HIP-event duration
+    # ---- roofline of the dominant kernel (the bucket accumulation): algorithmic bytes / its HIP-event duration
     acc_ms = phase.get("accumulate", 0.0)
+    acc32 = os.environ.get("MLHIP_ACC32", "") == "1"
+    acc_kernel = "k_accumulate<FpField<Bls381>>" if acc32 else "k_accumulate28<Bls381>"
+    # multiplier instructions per mixed addition: 10 x 288 v_mad_u64_u32 (+ as many v_addc) in the boundary form;
+    # 8 x 196 + 2 x 105 product and 9 x 210 reduction v_mad_i64_i32 + 9 x 14 v_mul_lo_u32 in the carry-free form
+    v_mad_per_madd = 10 * MACS_PER_FP_MUL if acc32 else (8 * 196 + 2 * 105 + 9 * 210 + 9 * 14)
     achieved = (MSM_BYTES_PER_UNIT * n) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
     # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json): the
     # counters cannot be read from inside this process, so this is the per-launch figure of the same workload
@@ -177,14 +182,14 @@ def main() -> None:
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             pm = json.load(f)
-        kk = next(v for k_, v in pm["kernels"].items() if k_.startswith("k_accumulate<") and "Fp2" not in k_)
+        kk = next(v for k_, v in pm["kernels"].items() if k_.startswith(acc_kernel.split("<")[0] + "<") and "Fp2" not in k_)
         traffic = (kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024.0
-        traffic_note = "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01_pmc_traffic.json, uncorrected (gather pattern, Infinity-Cache hits included): every point row is re-read once per window (16 x 96 MiB)"
+        traffic_note = "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01_pmc_traffic.json, uncorrected (gather pattern, Infinity-Cache hits included): every point row is re-read once per window (16 x 112 B x n), plus the 96 MiB bucket array written once"
     except Exception:
         pass
     roofline = {
         "bound": "hbm",
-        "kernel": "k_accumulate<FpField<Bls381>>",
+        "kernel": acc_kernel,
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -193,14 +198,14 @@ def main() -> None:
         "traffic_note": traffic_note,
         "avg_kernel_ms": acc_ms,
         "phase_ms": phase,
-        # the path is integer-ALU bound, not HBM bound: ~10 Fp multiplications per mixed addition,
-        # W = 16 additions per scalar => fraction of the measured v_mad_u64_u32 issue peak
+        # the path is integer-ALU bound, not HBM bound: W = 16 mixed additions per scalar, each V_MAD_PER_MADD
+        # multiplier instructions => fraction of the measured v_mad issue peak (profiles/r01_ubench_int.txt).  The
+        # kernel is power limited: its effective clock is ~1.9-2.2 GHz, not 2.4 (profiles/r01_pmc_clocks.txt).
         "int_alu": {
+            "form": "carry-free 28-bit limbs (fp28.h)" if not acc32 else "saturated 32-bit limbs (fp.h)",
             "fp_mul_per_s": (n * 16 * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
-            "mac_frac_of_measured_peak": ((n * 16 * 10 * MACS_PER_FP_MUL) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
-            # every multiply-add of the saturated 32-bit Montgomery product carries one add-with-carry: the issue
-            # peak of that instruction pair (profiles/r01_ubench_int.txt, "mad_u64+addc (pair)", 2 waves/SIMD)
-            "mad_addc_pair_frac_of_measured_peak": ((n * 16 * 10 * MACS_PER_FP_MUL) / (acc_ms * 1e-3)) / 1.572e13 if acc_ms > 0 else 0.0,
+            "v_mad_per_mixed_add": v_mad_per_madd,
+            "v_mad_frac_of_measured_peak": ((n * 16 * v_mad_per_madd) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
         },
     }
 
