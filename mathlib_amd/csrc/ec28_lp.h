@@ -1,0 +1,259 @@
+// ec28_lp.h -- G2 bucket accumulation in the carry-free form (fp28.h) over lane pairs.
+//
+// Same idea as ec28.h for G1, combined with the lane-pair layout of fp2_lanes.h: lane 2i holds the real part
+// and lane 2i+1 the imaginary part of every Fp2 coordinate, each as an Fp28.  Only curves with u^2 = -1
+// (BN254, BLS12-381) take this path: there an Fp2 product is ONE fused dual product per lane,
+//     c0 = a0 b0 + (-a1) b1        c1 = a1 b0 + a0 b1
+// (for u^2 = -5 the factor 5 would exceed the weight budget of a column; BLS12-377 G2 keeps the boundary form),
+// and an Fp2 square is one single product per lane: c0 = (a0 + a1)(a0 - a1), c1 = (2 a1) a0.
+// Weight rules (fp28.h): a dual product needs w_a w_b <= 4, the single-product square needs w_a = 1 -- so P and
+// R are carry-propagated right after the subtraction, X3 and Y3 before they are stored: four propagations and
+// 8 dual + 2 single products per mixed addition.
+// Written over a backend (device: one Fp28 per lane + DPP; host: a 2-entry array) like ec_quad.h.
+#pragma once
+#include "ec.h"
+#include "fp28.h"
+#include "tower.h"
+
+namespace mlhip {
+
+template <class C>
+struct PairHost {
+  struct V {
+    Fp28<C> v[2];
+  };
+  static void xchg(V& r, const V& a) {
+    V t = a;
+    r.v[0] = t.v[1];
+    r.v[1] = t.v[0];
+  }
+  static void sel_hi(V& r, const V& hi_val, const V& lo_val) {
+    r.v[0] = lo_val.v[0];
+    r.v[1] = hi_val.v[1];
+  }
+  template <class FN>
+  static void each(FN fn) {
+    for (int i = 0; i < 2; i++) fn(i);
+  }
+  static Fp28<C>& at(V& x, int i) { return x.v[i]; }
+  static const Fp28<C>& at(const V& x, int i) { return x.v[i]; }
+  static bool both(const bool (&b)[2]) { return b[0] && b[1]; }
+  static void gather(Fp2<C>& out, const Fp<C> (&own)[2]) {
+    out.c0 = own[0];
+    out.c1 = own[1];
+  }
+  static void scatter(Fp<C> (&own)[2], const Fp2<C>& in) {
+    own[0] = in.c0;
+    own[1] = in.c1;
+  }
+  static constexpr int LANES = 2;
+};
+
+#if defined(__HIPCC__)
+template <class C>
+struct PairDevice {
+  typedef Fp28<C> V;
+  static __device__ __forceinline__ uint32_t x1(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+#else
+    return v;
+#endif
+  }
+  static __device__ __forceinline__ bool hi() { return (threadIdx.x & 1u) != 0; }
+  static __device__ __forceinline__ void xchg(V& r, const V& a) {
+#pragma unroll
+    for (int i = 0; i < C::N28; i++) r.l[i] = (int32_t)x1((uint32_t)a.l[i]);
+  }
+  static __device__ __forceinline__ void sel_hi(V& r, const V& hi_val, const V& lo_val) {
+    fp28_select<C>(r, hi(), hi_val, lo_val);
+  }
+  template <class FN>
+  static __device__ __forceinline__ void each(FN fn) {
+    fn(0);
+  }
+  static __device__ __forceinline__ Fp28<C>& at(V& x, int) { return x; }
+  static __device__ __forceinline__ const Fp28<C>& at(const V& x, int) { return x; }
+  static __device__ __forceinline__ bool both(const bool (&b)[1]) {
+    uint32_t z = b[0] ? 1u : 0u;
+    return (z & x1(z)) != 0;
+  }
+  static __device__ __forceinline__ void gather(Fp2<C>& out, const Fp<C> (&own)[1]) {
+    Fp<C> other;
+#pragma unroll
+    for (int i = 0; i < C::N; i++) other.l[i] = x1(own[0].l[i]);
+    fp_select<C>(out.c0, hi(), other, own[0]);
+    fp_select<C>(out.c1, hi(), own[0], other);
+  }
+  static __device__ __forceinline__ void scatter(Fp<C> (&own)[1], const Fp2<C>& in) {
+    fp_select<C>(own[0], hi(), in.c1, in.c0);
+  }
+  static constexpr int LANES = 1;
+};
+#endif
+
+// lane-wise helpers over a backend value
+#define MLHIP_LP28_EACH(B, body) B::each([&](int li_) { body; })
+
+template <class C, class B>
+MLHIP_HD void lp28_sub(typename B::V& r, const typename B::V& a, const typename B::V& b) {
+  MLHIP_LP28_EACH(B, fp28_sub<C>(B::at(r, li_), B::at(a, li_), B::at(b, li_)));
+}
+template <class C, class B>
+MLHIP_HD void lp28_neg(typename B::V& r, const typename B::V& a) {
+  MLHIP_LP28_EACH(B, fp28_neg<C>(B::at(r, li_), B::at(a, li_)));
+}
+template <class C, class B>
+MLHIP_HD void lp28_normalize(typename B::V& r, const typename B::V& a) {
+  MLHIP_LP28_EACH(B, fp28_normalize<C>(B::at(r, li_), B::at(a, li_)));
+}
+template <class C, class B>
+MLHIP_HD void lp28_select(typename B::V& r, bool c, const typename B::V& a, const typename B::V& b) {
+  MLHIP_LP28_EACH(B, fp28_select<C>(B::at(r, li_), c, B::at(a, li_), B::at(b, li_)));
+}
+template <class C, class B>
+MLHIP_HD bool lp28_all_zero(const typename B::V& a) {
+  bool z[B::LANES];
+  MLHIP_LP28_EACH(B, z[li_] = fp28_all_zero<C>(B::at(a, li_)));
+  return B::both(z);
+}
+template <class C, class B>
+MLHIP_HD bool lp28_is_zero_exact(const typename B::V& a) {
+  bool z[B::LANES];
+  MLHIP_LP28_EACH(B, z[li_] = fp28_maybe_zero<C>(B::at(a, li_)));
+  if (!B::both(z)) return false;
+  MLHIP_LP28_EACH(B, z[li_] = fp28_is_zero_exact<C>(B::at(a, li_)));
+  return B::both(z);
+}
+
+// r = a b in Fp2 (u^2 = -1): one dual product per lane; needs w_a w_b <= 4
+template <class C, class B>
+MLHIP_HD void lp28_mul(typename B::V& r, const typename B::V& a, const typename B::V& b) {
+  static_assert(C::BETA == -1, "lane-pair carry-free products assume u^2 = -1");
+  typename B::V ax, bx, nax, y1, x2, y2;
+  B::xchg(ax, a);
+  B::xchg(bx, b);
+  lp28_neg<C, B>(nax, ax);
+  B::sel_hi(y1, bx, b);    // c0: b0 (own)   | c1: b0 (partner)
+  B::sel_hi(x2, ax, nax);  // c0: -a1        | c1: a0
+  B::sel_hi(y2, b, bx);    // c0: b1         | c1: b1 (own)
+  MLHIP_LP28_EACH(B, fp28_mul2<C>(B::at(r, li_), B::at(a, li_), B::at(y1, li_), B::at(x2, li_), B::at(y2, li_)));
+}
+
+// r = a^2, a normalized (weight 1): one single product per lane
+template <class C, class B>
+MLHIP_HD void lp28_sqr(typename B::V& r, const typename B::V& a) {
+  typename B::V ax, s, d, dd, x, y;
+  B::xchg(ax, a);
+  MLHIP_LP28_EACH(B, fp28_add<C>(B::at(s, li_), B::at(a, li_), B::at(ax, li_)));   // a0 + a1
+  MLHIP_LP28_EACH(B, fp28_sub<C>(B::at(d, li_), B::at(a, li_), B::at(ax, li_)));   // c0 lane: a0 - a1
+  MLHIP_LP28_EACH(B, fp28_add<C>(B::at(dd, li_), B::at(a, li_), B::at(a, li_)));   // c1 lane: 2 a1
+  B::sel_hi(x, dd, s);
+  B::sel_hi(y, ax, d);
+  MLHIP_LP28_EACH(B, fp28_mul<C>(B::at(r, li_), B::at(x, li_), B::at(y, li_)));
+}
+
+template <class V>
+struct XYZZ28L {
+  V x, y, zz, zzz;  // normalized
+};
+template <class V>
+struct Affine28L {
+  V x, y;
+};
+
+// exceptional cases (q = +-acc): every lane rebuilds the full Fp2 points in the boundary form, runs the one-lane
+// formulas and keeps its own component
+template <class C, class B>
+MLHIP_HD_NOINLINE void xyzz28_lp_madd_exact(XYZZ28L<typename B::V>& acc, bool& inf, const Affine28L<typename B::V>& q) {
+  typedef Fp2Field<C> F2;
+  XYZZ<F2> a;
+  Affine<F2> p;
+  auto to2 = [](Fp2<C>& out, const typename B::V& v) {
+    Fp<C> own[B::LANES];
+    MLHIP_LP28_EACH(B, fp28_to_fp<C>(own[li_], B::at(v, li_)));
+    B::gather(out, own);
+  };
+  auto from2 = [](typename B::V& v, const Fp2<C>& in) {
+    Fp<C> own[B::LANES];
+    B::scatter(own, in);
+    MLHIP_LP28_EACH(B, fp28_from_fp<C>(B::at(v, li_), own[li_]));
+  };
+  if (inf) {
+    xyzz_set_inf<F2>(a);
+  } else {
+    to2(a.x, acc.x);
+    to2(a.y, acc.y);
+    to2(a.zz, acc.zz);
+    to2(a.zzz, acc.zzz);
+  }
+  to2(p.x, q.x);
+  to2(p.y, q.y);
+  xyzz_madd<F2>(a, p, false);
+  inf = xyzz_is_inf<F2>(a);
+  if (!inf) {
+    from2(acc.x, a.x);
+    from2(acc.y, a.y);
+    from2(acc.zz, a.zz);
+    from2(acc.zzz, a.zzz);
+  }
+}
+
+// acc += q (q negated first when `negate`); pair-uniform control flow
+template <class C, class B>
+MLHIP_HD void xyzz28_lp_madd(XYZZ28L<typename B::V>& acc, bool& inf, const Affine28L<typename B::V>& q_in, bool negate) {
+  typedef typename B::V V;
+  if (lp28_all_zero<C, B>(q_in.x) && lp28_all_zero<C, B>(q_in.y)) return;  // point at infinity
+  Affine28L<V> q;
+  q.x = q_in.x;
+  V ny;
+  lp28_neg<C, B>(ny, q_in.y);
+  lp28_select<C, B>(q.y, negate, ny, q_in.y);
+  if (inf) {
+    acc.x = q.x;
+    acc.y = q.y;
+    V zero, one;
+    MLHIP_LP28_EACH(B, fp28_zero<C>(B::at(zero, li_)));
+    MLHIP_LP28_EACH(B, fp28_from_const<C>(B::at(one, li_), C::ONE28));
+    B::sel_hi(acc.zz, zero, one);  // 1 + 0 u
+    acc.zzz = acc.zz;
+    inf = false;
+    return;
+  }
+  V U2, S2, P, R, PP, PPP, Q, X3, t, e, Vv, T;
+  lp28_mul<C, B>(U2, q.x, acc.zz);
+  lp28_mul<C, B>(S2, q.y, acc.zzz);
+  lp28_sub<C, B>(t, U2, acc.x);
+  lp28_normalize<C, B>(P, t);
+  lp28_sub<C, B>(t, S2, acc.y);
+  lp28_normalize<C, B>(R, t);
+  if (lp28_is_zero_exact<C, B>(P)) {
+    XYZZ28L<V> ta = acc;  // cold-path copies: keep the caller's accumulator in registers
+    Affine28L<V> tq = q;
+    bool ti = inf;
+    xyzz28_lp_madd_exact<C, B>(ta, ti, tq);
+    acc = ta;
+    inf = ti;
+    return;
+  }
+  lp28_sqr<C, B>(PP, P);
+  lp28_mul<C, B>(PPP, P, PP);
+  lp28_mul<C, B>(Q, acc.x, PP);
+  lp28_sqr<C, B>(t, R);
+  lp28_sub<C, B>(t, t, PPP);
+  lp28_sub<C, B>(t, t, Q);
+  lp28_sub<C, B>(t, t, Q);
+  lp28_normalize<C, B>(X3, t);
+  lp28_sub<C, B>(e, Q, X3);            // weight 2
+  lp28_mul<C, B>(Vv, R, e);            // 1 x 2
+  lp28_mul<C, B>(T, acc.y, PPP);       // 1 x 1
+  lp28_sub<C, B>(t, Vv, T);
+  lp28_normalize<C, B>(acc.y, t);
+  acc.x = X3;
+  lp28_mul<C, B>(t, acc.zz, PP);
+  acc.zz = t;
+  lp28_mul<C, B>(t, acc.zzz, PPP);
+  acc.zzz = t;
+}
+
+}  // namespace mlhip

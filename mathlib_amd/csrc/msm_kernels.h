@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "ec28.h"
+#include "ec28_lp.h"
 #include "ec_quad.h"
 #include "fp2_lanes.h"
 #include "mlhip_internal.h"
@@ -755,6 +756,80 @@ __global__ void __launch_bounds__(256) k_accumulate_lp(const Affine<Fp2Field<C>>
   lp_store_xyzz<C>(buckets, g, acc, hi);
 }
 
+// ---- G2 accumulation in the carry-free form over lane pairs (ec28_lp.h; curves with u^2 = -1) -----------------
+template <class C>
+struct alignas(8) AffineG2_28 {  // x.c0 | x.c1 | y.c0 | y.c1, 56 (40) bytes each
+  Fp28<C> c[4];
+};
+
+template <class C>
+__global__ void __launch_bounds__(256) k_points_to28_g2(const Affine<Fp2Field<C>>* __restrict__ points, size_t n,
+                                                        AffineG2_28<C>* __restrict__ out) {
+  // one coordinate component per thread: 4 threads per point
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 4 * n) return;
+  const Fp<C>* src = reinterpret_cast<const Fp<C>*>(points);
+  Fp28<C> v;
+  fp28_from_fp<C>(v, src[t]);
+  reinterpret_cast<Fp28<C>*>(out)[t] = v;
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_accumulate28_lp(const AffineG2_28<C>* __restrict__ points,
+                                                         const uint32_t* __restrict__ sorted,
+                                                         const uint32_t* __restrict__ offsets,
+                                                         const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                         const uint32_t* __restrict__ order, uint32_t big_threshold,
+                                                         uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
+                                                         XYZZ<Fp2Field<C>>* __restrict__ buckets) {
+  typedef PairDevice<C> B;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t pair = t >> 1;  // both lanes of a pair share the bucket: every branch below is pair-uniform
+  if (pair >= n_buckets) return;
+  const int hi = (int)(threadIdx.x & 1u);
+  const size_t g = order[pair];
+  const uint32_t cnt = counts[g];
+  if (cnt > big_threshold) {  // summed by a whole workgroup in k_accumulate_big (boundary form)
+    if (!hi) {
+      uint32_t pos = atomicAdd(big_count, 1u);
+      big_list[pos] = (uint32_t)g;
+    }
+    return;
+  }
+  XYZZ28L<Fp28<C>> acc;
+  bool inf = true;
+  const size_t begin = offsets[g], end = begin + cnt;
+  if (cnt != 0) {
+    uint32_t e = sorted[begin];
+    Affine28L<Fp28<C>> p, pn;
+    p.x = points[e & 0x7fffffffu].c[hi];
+    p.y = points[e & 0x7fffffffu].c[2 + hi];
+    for (size_t k = begin; k < end; k++) {
+      uint32_t en = e;
+      pn = p;
+      if (k + 1 < end) {  // prefetch the next index and point under this addition
+        en = sorted[k + 1];
+        pn.x = points[en & 0x7fffffffu].c[hi];
+        pn.y = points[en & 0x7fffffffu].c[2 + hi];
+      }
+      xyzz28_lp_madd<C, B>(acc, inf, p, (e >> 31) != 0);
+      e = en;
+      p = pn;
+    }
+  }
+  // back to the boundary form, one Fp2 component per lane
+  XYZZ<Fp2LField<C>> r;
+  if (inf) {
+    xyzz_set_inf<Fp2LField<C>>(r);
+  } else {
+    fp28_to_fp<C>(r.x.v, acc.x);
+    fp28_to_fp<C>(r.y.v, acc.y);
+    fp28_to_fp<C>(r.zz.v, acc.zz);
+    fp28_to_fp<C>(r.zzz.v, acc.zzz);
+  }
+  lp_store_xyzz<C>(buckets, g, r, hi);
+}
+
 template <class C>
 __global__ void __launch_bounds__(256) k_chunks_lp(const XYZZ<Fp2Field<C>>* __restrict__ buckets, size_t n_chunks, int l_eff,
                                                    XYZZ<Fp2Field<C>>* __restrict__ A, XYZZ<Fp2Field<C>>* __restrict__ W0) {
@@ -878,6 +953,12 @@ int plan_alloc(mlhip_msm_plan* p) {
     const bool want28 = !(acc32 && acc32[0] == '1');
     if (want28) HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(Affine28<typename F::Curve>)));
   }
+  if constexpr (std::is_same<F, Fp2Field<typename F::Curve>>::value && F::Curve::BETA == -1 && F::Curve::N28 == 14) {
+    // G2 in the carry-free form: BLS12-381 only (-14 % accumulation time); u^2 = -5 does not fit the weight budget
+    // (BLS12-377) and the 10-limb BN254 form gains nothing over its 8 saturated limbs on lane pairs
+    const char* acc32 = getenv("MLHIP_ACC32");
+    if (!(acc32 && acc32[0] == '1')) HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(AffineG2_28<typename F::Curve>)));
+  }
   HIPCHK(hipMalloc(&p->d_buckets, nbuckets * p->xyzz_size));
   HIPCHK(hipMalloc(&p->d_A, (size_t)p->W * p->T * p->xyzz_size));
   HIPCHK(hipMalloc(&p->d_W0, (size_t)p->W * p->T * p->xyzz_size));
@@ -935,15 +1016,19 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     // window (2-4x the mean for these group orders), stay on the one-thread-per-bucket path.
     uint32_t big_threshold = (uint32_t)std::min<size_t>((n >> (p->c - 1)) * 8, 1u << 30);
     if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
-    if constexpr (!std::is_same<F, Fp2Field<C>>::value) {
-      if (p->d_points28) {
-        // the conversion of the points is independent of the sort: run it beside the (LDS-atomic bound) sort kernels
-        HIPCHK(hipEventRecord(p->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
+    if (p->d_points28) {
+      // the conversion of the points is independent of the sort: run it beside the (LDS-atomic bound) sort kernels
+      HIPCHK(hipEventRecord(p->ev_fork, st));
+      HIPCHK(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
+      if constexpr (std::is_same<F, Fp2Field<C>>::value) {
+        if constexpr (C::BETA == -1)
+          k_points_to28_g2<C><<<dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, p->aux>>>(
+              (const A*)d_points, n, (AffineG2_28<C>*)p->d_points28);
+      } else {
         k_points_to28<C><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->aux>>>((const A*)d_points, n,
                                                                                      (Affine28<C>*)p->d_points28);
-        HIPCHK(hipEventRecord(p->ev_join, p->aux));
       }
+      HIPCHK(hipEventRecord(p->ev_join, p->aux));
     }
     HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
     if (prof) HIPCHK(hipEventRecord(p->ev[0], st));
@@ -987,9 +1072,20 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     if (prof) HIPCHK(hipEventRecord(p->ev[2], st));
     constexpr bool kLanePairs = std::is_same<F, Fp2Field<C>>::value;  // G2: two lanes per bucket
     if constexpr (kLanePairs) {
-      k_accumulate_lp<C><<<dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, st>>>(
-          (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
-          p->d_bigcount, (X*)p->d_buckets);
+      bool done28 = false;
+      if constexpr (C::BETA == -1) {
+        if (p->d_points28) {
+          HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
+          k_accumulate28_lp<C><<<dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+              (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+              big_threshold, p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
+          done28 = true;
+        }
+      }
+      if (!done28)
+        k_accumulate_lp<C><<<dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+            (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
+            p->d_bigcount, (X*)p->d_buckets);
     } else if (p->d_points28) {
       HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
       k_accumulate28<C><<<dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st>>>(

@@ -10,6 +10,7 @@
 #include "../../mathlib_amd/csrc/codec.h"
 #include "../../mathlib_amd/csrc/ec28.h"
 #include "../../mathlib_amd/csrc/ec_quad.h"
+#include "../../mathlib_amd/csrc/ec28_lp.h"
 
 using namespace mlhip;
 
@@ -265,6 +266,42 @@ struct Ops {
     memcpy(out, &a, sizeof(A1));
     return 0;
   }
+  // G2 bucket accumulation in the carry-free lane-pair form (ec28_lp.h) through the host emulation backend
+  static int madd28_lp_chain(const void* pts, const uint8_t* neg, int n, void* out) {
+    if constexpr (C::BETA == -1) {
+      typedef PairHost<C> B;
+      const A2* p = (const A2*)pts;
+      XYZZ28L<typename B::V> acc;
+      bool inf = true;
+      for (int i = 0; i < n; i++) {
+        Affine28L<typename B::V> q;
+        fp28_from_fp<C>(q.x.v[0], p[i].x.c0);
+        fp28_from_fp<C>(q.x.v[1], p[i].x.c1);
+        fp28_from_fp<C>(q.y.v[0], p[i].y.c0);
+        fp28_from_fp<C>(q.y.v[1], p[i].y.c1);
+        xyzz28_lp_madd<C, B>(acc, inf, q, neg[i] != 0);
+      }
+      X2 a;
+      if (inf) {
+        xyzz_set_inf<Fp2Field<C>>(a);
+      } else {
+        fp28_to_fp<C>(a.x.c0, acc.x.v[0]);
+        fp28_to_fp<C>(a.x.c1, acc.x.v[1]);
+        fp28_to_fp<C>(a.y.c0, acc.y.v[0]);
+        fp28_to_fp<C>(a.y.c1, acc.y.v[1]);
+        fp28_to_fp<C>(a.zz.c0, acc.zz.v[0]);
+        fp28_to_fp<C>(a.zz.c1, acc.zz.v[1]);
+        fp28_to_fp<C>(a.zzz.c0, acc.zzz.v[0]);
+        fp28_to_fp<C>(a.zzz.c1, acc.zzz.v[1]);
+      }
+      A2 r;
+      xyzz_to_affine<Fp2Field<C>>(r, a);
+      memcpy(out, &r, sizeof(A2));
+      return 0;
+    } else {
+      return -2;  // u^2 != -1: this path is not built for the curve
+    }
+  }
   static int g2dec(const uint8_t* w, int compressed, int subgroup, void* out) {
     A2 p;
     int st = g2_decode<C>(p, w, compressed != 0, subgroup != 0);
@@ -308,6 +345,7 @@ int hm_g1_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPAT
 int hm_fp28_op(int curve, int op, const void* a, const void* b, const void* c, const void* d, void* out) { DISPATCH(curve, fp28_op(op, a, b, c, d, out)) }
 int hm_madd28_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_chain(pts, neg, n, out)) }
 int hm_quad_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, quad_chain(pts, zs, n, out)) }
+int hm_madd28_lp_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_lp_chain(pts, neg, n, out)) }
 int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g2dec(w, compressed, subgroup, out)) }
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }
 int hm_miller(int curve, const void* g1s, const void* g2s, int n_pairs, void* out) { DISPATCH(curve, miller(g1s, g2s, n_pairs, out)) }

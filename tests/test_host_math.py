@@ -399,3 +399,32 @@ def test_quad_lane_xyzz_add(hostmath, name):
         out = ctypes.create_string_buffer(2 * n)
         assert L.hm_quad_chain(cid, pts, zs, len(seq), out) == 0
         assert out.raw == R.g1_to_mont_bytes(cp, want)
+
+
+@pytest.mark.parametrize("name", ["BN254", "BLS12-381"])
+def test_madd28_lane_pair_g2_accumulation(hostmath, name):
+    """ec28_lp.h (G2, u^2 = -1 curves): bucket sums in the carry-free lane-pair form, host emulation of the pair
+    exchange, against the oracle -- including doubling, cancellation, infinity inputs."""
+    cp = R.CURVES[name]
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("host/madd28lp/" + name)
+    P = [R.random_g2(cp, d) for _ in range(5)]
+    cases = [
+        [(P[0], 0)],
+        [(P[0], 1)],
+        [(P[i], i & 1) for i in range(5)],
+        [(P[0], 0), (P[0], 0), (P[1], 0)],
+        [(P[0], 0), (P[0], 1), (P[1], 1), (P[2], 0)],
+        [(None, 0), (P[3], 0), (None, 1), (P[3], 0), (P[3], 0)],
+        [(P[0], 0), (P[1], 0), (R.g2_add(cp, P[0], P[1]), 1)],
+        [(P[i % 5], (i * 7) & 1) for i in range(24)],
+    ]
+    for seq in cases:
+        pts = b"".join(R.g2_to_mont_bytes(cp, q) for q, _ in seq)
+        neg = bytes(s for _, s in seq)
+        want = None
+        for q, s in seq:
+            want = R.g2_add(cp, want, R.g2_neg(cp, q) if s else q)
+        out = ctypes.create_string_buffer(4 * n)
+        assert L.hm_madd28_lp_chain(cid, pts, neg, len(seq), out) == 0
+        assert out.raw == R.g2_to_mont_bytes(cp, want)
