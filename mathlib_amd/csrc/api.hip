@@ -210,8 +210,14 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
   p->W = msm_num_windows(sz.fr_bits, window_c);
   p->max_n = max_n;
   p->M = 1u << (window_c - 1);
-  p->L = 8;
-  p->lgL = 3;
+  // buckets per level-1 reduction chunk: 16 for G1 (the quad-lane kernels are bound by work, and a longer chunk
+  // halves the second level), 8 for G2 and for tiny windows
+  p->lgL = (group == MLHIP_GROUP_G1 && p->M >= 256) ? 4 : 3;
+  if (const char* e = getenv("MLHIP_CHUNK_LOG2")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 6 && (1u << v) <= p->M) p->lgL = v;
+  }
+  p->L = 1 << p->lgL;
   p->T = p->M / p->L;
   p->nb = ilog2(p->T);
   p->nsel = 4 + p->nb;  // two half-sums of W0, two of A, nb bit-masked sums
