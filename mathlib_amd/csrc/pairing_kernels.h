@@ -78,7 +78,9 @@ __device__ __forceinline__ void lp_load_gt(Fp12<C, Fp2L<C>>& f, const Fp12<C>* i
 #ifndef MLHIP_LP_OCC
 #define MLHIP_LP_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
-template <class C, int WHAT>
+// MAXP: pairs per product the instance can hold (1 for the plain pairing: the per-pair arrays then live in
+// registers instead of dynamically indexed scratch)
+template <class C, int WHAT, int MAXP>
 __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp(const Affine<FpField<C>>* __restrict__ g1,
                                                    const Affine<Fp2Field<C>>* __restrict__ g2, int ppp, size_t n,
                                                    const Fp12<C>* __restrict__ in, Fp12<C>* __restrict__ out) {
@@ -90,11 +92,11 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp(const Affine<FpF
   if (WHAT == 1) {
     lp_load_gt<C>(f, in, i);
   } else {
-    Fp<C> px[4], py[4];
-    E2 qx[4], qy[4];
-    bool live[4];
+    Fp<C> px[MAXP], py[MAXP];
+    E2 qx[MAXP], qy[MAXP];
+    bool live[MAXP];
     const int hi = lane_is_hi() ? 1 : 0;
-    for (int k = 0; k < ppp && k < 4; k++) {
+    for (int k = 0; k < ppp && k < MAXP; k++) {
       const Affine<FpField<C>> P = g1[i * ppp + k];
       const Fp<C>* q = reinterpret_cast<const Fp<C>*>(g2 + i * ppp + k);
       px[k] = P.x;
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp(const Affine<FpF
       zq &= pair_xchg_u32(zq);
       live[k] = !(affine_is_inf<FpField<C>>(P) | (zq != 0));
     }
-    miller_loop_core<C, 4, E2>(f, px, py, qx, qy, live, ppp);
+    miller_loop_core<C, MAXP, E2>(f, px, py, qx, qy, live, ppp);
   }
   if (WHAT == 0) {
     lp_store_gt<C>(out, i, f);
@@ -154,15 +156,19 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
     unsigned blocks = (unsigned)((2 * n + 63) / 64);
     switch (what) {
       case 0:
-        k_pairing_lp<C, 0><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, nullptr,
-                                                             (Fp12<C>*)d_out);
+        if (ppp == 1)
+          k_pairing_lp<C, 0, 1><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr,
+                                                                  (Fp12<C>*)d_out);
+        else
+          k_pairing_lp<C, 0, 4><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, nullptr,
+                                                                  (Fp12<C>*)d_out);
         break;
       case 1:
-        k_pairing_lp<C, 1><<<dim3(blocks), dim3(64), 0, st>>>(nullptr, nullptr, 1, n, (const Fp12<C>*)d_in,
+        k_pairing_lp<C, 1, 1><<<dim3(blocks), dim3(64), 0, st>>>(nullptr, nullptr, 1, n, (const Fp12<C>*)d_in,
                                                              (Fp12<C>*)d_out);
         break;
       default:
-        k_pairing_lp<C, 2><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr,
+        k_pairing_lp<C, 2, 1><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr,
                                                              (Fp12<C>*)d_out);
         break;
     }
