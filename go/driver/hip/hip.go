@@ -159,3 +159,52 @@ func (c *Curve) PairingBatch(g2s []driver.G2, g1s []driver.G1) []driver.Gt {
 	}
 	return out
 }
+
+// NewG1sFromCompressed decodes n compressed G1 points (the wire form of G1.Compressed, bls12-381.go:292-296)
+// on the device: decompression, curve check and subgroup check per point.  It is the bulk form of
+// NewG1FromCompressed (bls12-381.go:551-559) and panics like it on the first invalid encoding, with gnark's
+// message class ("set bytes failed [...]"); the façade's deserializers recover the panic into an error
+// (math.go:761-832).
+func (c *Curve) NewG1sFromCompressed(raw []byte) []driver.G1 {
+	const sz = bls12381.SizeOfG1AffineCompressed
+	if len(raw)%sz != 0 {
+		panic("set bytes failed [invalid length]")
+	}
+	n := len(raw) / sz
+	if n == 0 {
+		return nil
+	}
+	pts := make([]bls12381.G1Affine, n)
+	status := make([]byte, n)
+	check(C.mlhip_g1_from_bytes(C.MLHIP_CURVE_BLS12_381, unsafe.Pointer(&raw[0]), C.size_t(n), 1, 1,
+		unsafe.Pointer(&pts[0]), (*C.uchar)(unsafe.Pointer(&status[0]))))
+	out := make([]driver.G1, n)
+	for i := range pts {
+		switch status[i] {
+		case 0:
+			out[i] = &gurvy381.G1{G1Affine: pts[i]}
+		case 1:
+			panic("set bytes failed [invalid point encoding]")
+		case 2:
+			panic("set bytes failed [invalid point: not on the curve]")
+		default:
+			panic("set bytes failed [invalid point: subgroup check failed]")
+		}
+	}
+	return out
+}
+
+// G1sCompressed is the inverse: the compressed wire form of every point, concatenated.
+func (c *Curve) G1sCompressed(pts []driver.G1) []byte {
+	n := len(pts)
+	if n == 0 {
+		return nil
+	}
+	aff := make([]bls12381.G1Affine, n)
+	for i := range pts {
+		aff[i] = pts[i].(*gurvy381.G1).G1Affine
+	}
+	out := make([]byte, n*bls12381.SizeOfG1AffineCompressed)
+	check(C.mlhip_g1_to_bytes(C.MLHIP_CURVE_BLS12_381, unsafe.Pointer(&aff[0]), C.size_t(n), 1, unsafe.Pointer(&out[0])))
+	return out
+}
