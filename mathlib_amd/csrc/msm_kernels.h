@@ -127,7 +127,10 @@ static inline void launch_scan(const uint32_t* in, uint32_t* out, uint32_t* tile
 //                     (fine bucket bits | sign | point index)
 //   k_fine_sort       one block per coarse bin: LDS histogram of the 2^LOW fine buckets -> counts/offsets
 //                     of the real buckets (coalesced), then LDS-ranked placement of the point indices
-constexpr int SORT_TILE = 1024;  // scalars per block in the coarse passes
+#ifndef MLHIP_SORT_TILE
+#define MLHIP_SORT_TILE 1024
+#endif
+constexpr int SORT_TILE = MLHIP_SORT_TILE;  // scalars per block in the coarse passes
 
 template <class C>
 __global__ void __launch_bounds__(256) k_coarse_hist(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,

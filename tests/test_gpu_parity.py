@@ -414,3 +414,55 @@ def test_pairing_one_lane_kernels_agree(lib, mlhip, curve, monkeypatch):
     out = ctypes.create_string_buffer(gtb * len(cases))
     mlhip.check(lib.mlhip_pairing_batch(cid, p1, p2, len(cases), out))
     assert out.raw == exp
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_differential_sweep(lib, mlhip, curve):
+    """Seeded sweep over (n, window, scalar width, duplicates / negated duplicates / infinities) against the C
+    oracle: the shapes the fixed cases do not hit -- ragged n around the sort tile and chunk sizes, buckets with a
+    point and its negative (accumulator returns to infinity mid-bucket), runs of the same point (doubling path
+    inside the carry-free accumulation), scalars at r-1 / 2^k boundaries."""
+    import numpy as np
+    import random
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, g1b, g2b, _ = mlhip.sizes(cid)
+    rnd = random.Random(1000 + cid)
+    r_order = int(g["r"], 16)
+
+    def scalars(count, bits):
+        vals = [rnd.getrandbits(bits) % r_order for _ in range(count)]
+        vals[0] = r_order - 1
+        if count > 2:
+            vals[1] = 1 << (bits - 1)
+            vals[2] = 0
+        return np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint64).reshape(count, 4).copy()
+
+    for trial in range(14):
+        group = 2 if trial % 5 == 4 else 1
+        sz = g1b if group == 1 else g2b
+        n = rnd.choice([1, 2, 3, 7, 63, 64, 65, 255, 257, 1023, 1025, 2049, 4097]) if trial < 9 else rnd.randrange(1, 3000)
+        c = rnd.choice([4, 5, 8, 11, 13, 16]) if trial % 3 else 0
+        pts = bytearray(cref.gen_points(cid, group, 5000 + trial, 77 + trial, n))
+        sc = scalars(n, rnd.choice([16, 64, 200, 252]))
+        # structure: copies of earlier points with equal scalars (same bucket -> doubling), and copies whose
+        # scalar is the negative (same bucket, opposite sign -> cancellation), a few infinities
+        for k in range(n // 5):
+            i, j = rnd.randrange(n), rnd.randrange(n)
+            pts[j * sz : (j + 1) * sz] = pts[i * sz : (i + 1) * sz]
+            if k % 2 == 0:
+                sc[j] = sc[i]
+            else:
+                v = (r_order - int.from_bytes(sc[i].tobytes(), "little")) % r_order
+                sc[j] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint64)
+        for k in range(n // 40):
+            j = rnd.randrange(n)
+            pts[j * sz : (j + 1) * sz] = bytes(sz)
+        pts = bytes(pts)
+        exp = cref.msm(cid, group, pts, sc, n, False, 0, 8)
+        out = ctypes.create_string_buffer(sz)
+        fn = lib.mlhip_msm_g1 if group == 1 else lib.mlhip_msm_g2
+        mlhip.check(fn(cid, pts, sc.tobytes(), 0, n, c, out))
+        assert out.raw == exp, (curve, trial, group, n, c)
