@@ -133,6 +133,10 @@ int mlhip_scalar_mul_device(int curve, int group, const void* d_points, size_t p
 int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stride, const void* scalars,
                      int scalars_mont, size_t n, void* out_affine);
 
+/* The host-buffer MSM entry points above keep up to four plans + input buffers alive between calls (creating and
+ * destroying them costs as much as a 2^20-point MSM); this frees the idle ones.  MLHIP_NO_PLAN_CACHE=1 disables the pool. */
+int mlhip_release_cache(void);
+
 /* ---- wire format (bulk NewG1FromBytes / NewG1FromCompressed and G1.Bytes / G1.Compressed,
  * driver/gurvy/bls12381/bls12-381.go:531-569, :286-296) --------------------------------------------------
  * Decode n points of gnark's wire format (BLS12 curves: zcash 3-bit header; BN254: 2-bit header), all of the

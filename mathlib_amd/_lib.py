@@ -45,6 +45,7 @@ SYMBOLS = [
     "mlhip_gt_exp_device",
     "mlhip_scalar_mul_device",
     "mlhip_scalar_mul",
+    "mlhip_release_cache",
     "mlhip_g1_from_bytes",
     "mlhip_g1_to_bytes",
     "mlhip_g1_from_bytes_device",

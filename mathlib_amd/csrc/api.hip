@@ -1,7 +1,10 @@
 // api.hip -- the extern "C" surface of libmlhip.so (include/mlhip.h): argument checking, device
 // selection, host-buffer staging and dispatch to the per-curve translation units.  No kernels here.
 // There is no CPU fallback: every compute entry point needs a HIP device (MLHIP_ENODEVICE otherwise).
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 #include <string>
 
 #include "ec.h"
@@ -116,6 +119,100 @@ int pairing_host(int curve, int what, const void* g1, const void* g2, size_t ppp
   return rc;
 }
 
+// ---- a small pool of plans + device input buffers for the host-buffer entry points ---------------------------
+// The reference's MultiScalarMul takes fresh host slices per call; creating and, above all, destroying a plan
+// (a dozen hipFree's, ~2.5 ms) and the input buffers per call cost as much as the kernels of a 2^20-point MSM.
+// Entries are reused across calls and threads when curve / group / window / device match and the size fits
+// (capacity between n and 4 n).  At most POOL_MAX entries stay allocated (~0.6 GB each at n = 2^20);
+// MLHIP_NO_PLAN_CACHE=1 disables the pool, mlhip_release_cache() empties it.
+struct PoolEntry {
+  mlhip_msm_plan* plan = nullptr;
+  void *d_pts = nullptr, *d_sc = nullptr;
+  int curve = 0, group = 0, c = 0, device = 0;
+  size_t cap = 0;
+  bool busy = false, pooled = false;
+  unsigned long stamp = 0;
+};
+constexpr size_t POOL_MAX = 4;
+std::mutex g_pool_mu;
+std::vector<PoolEntry*> g_pool;
+unsigned long g_pool_clock = 0;
+
+void pool_free_entry(PoolEntry* e) {
+  (void)hipSetDevice(e->device);
+  if (e->d_pts) (void)hipFree(e->d_pts);
+  if (e->d_sc) (void)hipFree(e->d_sc);
+  if (e->plan) mlhip_msm_plan_destroy(e->plan);
+  delete e;
+}
+
+PoolEntry* pool_acquire(int curve, int group, int c, size_t n, size_t ptsz, int& rc) {
+  const char* off = getenv("MLHIP_NO_PLAN_CACHE");
+  const bool use_pool = !(off && off[0] == '1');
+  PoolEntry* victim = nullptr;
+  if (use_pool) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (PoolEntry* e : g_pool)
+      if (!e->busy && e->curve == curve && e->group == group && e->c == c && e->device == g_device && e->cap >= n &&
+          e->cap <= 4 * n) {
+        e->busy = true;
+        e->stamp = ++g_pool_clock;
+        return e;
+      }
+    if (g_pool.size() >= POOL_MAX) {  // evict the least recently used idle entry
+      size_t vi = g_pool.size();
+      for (size_t i = 0; i < g_pool.size(); i++)
+        if (!g_pool[i]->busy && (vi == g_pool.size() || g_pool[i]->stamp < g_pool[vi]->stamp)) vi = i;
+      if (vi < g_pool.size()) {
+        victim = g_pool[vi];
+        g_pool.erase(g_pool.begin() + vi);
+      }
+    }
+  }
+  if (victim) pool_free_entry(victim);
+  PoolEntry* e = new PoolEntry();
+  e->curve = curve;
+  e->group = group;
+  e->c = c;
+  e->device = g_device;
+  e->cap = n;
+  e->busy = true;
+  rc = mlhip_msm_plan_create(curve, group, n, c, &e->plan);
+  if (!rc && (hipMalloc(&e->d_pts, n * ptsz) != hipSuccess || hipMalloc(&e->d_sc, n * 32) != hipSuccess))
+    rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of MSM inputs failed");
+  if (rc) {
+    pool_free_entry(e);
+    return nullptr;
+  }
+  if (use_pool) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool.size() < POOL_MAX) {
+      e->pooled = true;
+      e->stamp = ++g_pool_clock;
+      g_pool.push_back(e);
+    }
+  }
+  return e;
+}
+
+void pool_release(PoolEntry* e, bool failed) {
+  if (e->pooled && failed) {  // do not keep an entry whose last run ended in an error
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++)
+      if (g_pool[i] == e) {
+        g_pool.erase(g_pool.begin() + i);
+        break;
+      }
+    e->pooled = false;
+  }
+  if (!e->pooled) {
+    pool_free_entry(e);
+    return;
+  }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  e->busy = false;
+}
+
 int msm_host_buffers(int curve, int group, const void* points, const void* scalars, int mont, size_t n, int window_c,
                      void* out) {
   Sizes sz;
@@ -129,25 +226,23 @@ int msm_host_buffers(int curve, int group, const void* points, const void* scala
     return 0;
   }
   if (!points || !scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
-  mlhip_msm_plan* plan = nullptr;
-  int rc = mlhip_msm_plan_create(curve, group, n, window_c, &plan);
+  if (window_c == 0) window_c = pick_window(n);
+  int rc = ensure_device();
   if (rc) return rc;
-  void *d_pts = nullptr, *d_sc = nullptr;
+  PoolEntry* e = pool_acquire(curve, group, window_c, n, ptsz, rc);
+  if (!e) return rc;
   do {
-    if (hipMalloc(&d_pts, n * ptsz) != hipSuccess || hipMalloc(&d_sc, n * 32) != hipSuccess) {
-      rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of MSM inputs failed");
+    // scalars first (the sort needs only them); the points follow on the plan's auxiliary stream while the sort runs
+    if (hipMemcpy(e->d_sc, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess) {
+      rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy of MSM scalars failed");
       break;
     }
-    if (hipMemcpy(d_pts, points, n * ptsz, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_sc, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess) {
-      rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy of MSM inputs failed");
-      break;
-    }
-    rc = mlhip_msm_run(plan, d_pts, d_sc, mont, n, nullptr, out, nullptr);
+    e->plan->upload_src = points;
+    e->plan->upload_bytes = n * ptsz;
+    rc = mlhip_msm_run(e->plan, e->d_pts, e->d_sc, mont, n, nullptr, out, nullptr);
+    e->plan->upload_src = nullptr;
   } while (0);
-  if (d_pts) (void)hipFree(d_pts);
-  if (d_sc) (void)hipFree(d_sc);
-  mlhip_msm_plan_destroy(plan);
+  pool_release(e, rc != 0);
   return rc;
 }
 
@@ -296,6 +391,22 @@ int mlhip_msm_plan_timings(mlhip_msm_plan* p, float* ms, int cap) {
   int k = cap < 6 ? cap : 6;
   for (int i = 0; i < k; i++) ms[i] = p->ms[i];
   return k;
+}
+
+int mlhip_release_cache(void) {
+  std::vector<PoolEntry*> idle;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size();)
+      if (!g_pool[i]->busy) {
+        idle.push_back(g_pool[i]);
+        g_pool.erase(g_pool.begin() + i);
+      } else {
+        i++;
+      }
+  }
+  for (PoolEntry* e : idle) pool_free_entry(e);
+  return 0;
 }
 
 int mlhip_msm_g1(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,

@@ -38,6 +38,9 @@ struct mlhip_msm_plan {
   hipEvent_t done = nullptr;
   hipStream_t aux = nullptr;  // the point conversion runs here, beside the sort kernels
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // host-buffer entry points: points still in host memory, uploaded on `aux` beside the sort (cleared per launch)
+  const void* upload_src = nullptr;
+  size_t upload_bytes = 0;
   bool pending = false;
   size_t pending_n = 0;
   float ms[6] = {0, 0, 0, 0, 0, 0};

@@ -1019,20 +1019,14 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     // window (2-4x the mean for these group orders), stay on the one-thread-per-bucket path.
     uint32_t big_threshold = (uint32_t)std::min<size_t>((n >> (p->c - 1)) * 8, 1u << 30);
     if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
-    if (p->d_points28) {
-      // the conversion of the points is independent of the sort: run it beside the (LDS-atomic bound) sort kernels
-      HIPCHK(hipEventRecord(p->ev_fork, st));
-      HIPCHK(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
-      if constexpr (std::is_same<F, Fp2Field<C>>::value) {
-        if constexpr (C::BETA == -1)
-          k_points_to28_g2<C><<<dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, p->aux>>>(
-              (const A*)d_points, n, (AffineG2_28<C>*)p->d_points28);
-      } else {
-        k_points_to28<C><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->aux>>>((const A*)d_points, n,
-                                                                                     (Affine28<C>*)p->d_points28);
-      }
-      HIPCHK(hipEventRecord(p->ev_join, p->aux));
+    if (p->upload_src && !p->d_points28) {  // no auxiliary stream on this path: plain upload first
+      HIPCHK(hipMemcpy(const_cast<void*>(d_points), p->upload_src, p->upload_bytes, hipMemcpyHostToDevice));
+      p->upload_src = nullptr;
     }
+    // the conversion of the points is independent of the sort: it runs on the auxiliary stream beside the
+    // (LDS-atomic bound) sort kernels.  The fork is recorded now (after the previous MSM's work on `st`); the work
+    // itself is queued after the sort launches so that a host-blocking upload cannot delay them.
+    if (p->d_points28) HIPCHK(hipEventRecord(p->ev_fork, st));
     HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
     if (prof) HIPCHK(hipEventRecord(p->ev[0], st));
     if (p->sort_low > 0) {
@@ -1071,6 +1065,22 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
       k_order_hist<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist);
       launch_scan(p->d_hist, p->d_hist, p->d_tilesums, (size_t)ORDER_BINS * nblk, st);
       k_order_place<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist, p->d_order);
+    }
+    if (p->d_points28) {
+      HIPCHK(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
+      if (p->upload_src) {  // host-buffer call: the upload of the points rides the same stream, ahead of the conversion
+        HIPCHK(hipMemcpyAsync(const_cast<void*>(d_points), p->upload_src, p->upload_bytes, hipMemcpyHostToDevice, p->aux));
+        p->upload_src = nullptr;
+      }
+      if constexpr (std::is_same<F, Fp2Field<C>>::value) {
+        if constexpr (C::BETA == -1)
+          k_points_to28_g2<C><<<dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, p->aux>>>(
+              (const A*)d_points, n, (AffineG2_28<C>*)p->d_points28);
+      } else {
+        k_points_to28<C><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->aux>>>((const A*)d_points, n,
+                                                                                     (Affine28<C>*)p->d_points28);
+      }
+      HIPCHK(hipEventRecord(p->ev_join, p->aux));
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[2], st));
     constexpr bool kLanePairs = std::is_same<F, Fp2Field<C>>::value;  // G2: two lanes per bucket

@@ -382,7 +382,7 @@ def test_g2_wire_codec_vs_oracle(lib, mlhip, curve):
 # every one must give the same bytes as the default path
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("switch", ["MLHIP_LEGACY_SORT", "MLHIP_ACC32", "MLHIP_REDUCE_ONE_LANE"])
+@pytest.mark.parametrize("switch", ["MLHIP_LEGACY_SORT", "MLHIP_ACC32", "MLHIP_REDUCE_ONE_LANE", "MLHIP_NO_PLAN_CACHE"])
 def test_msm_alternate_paths(lib, mlhip, curve, switch, monkeypatch):
     g = load_golden(curve)
     cid = g["curve_id"]
@@ -466,3 +466,28 @@ def test_msm_differential_sweep(lib, mlhip, curve):
         fn = lib.mlhip_msm_g1 if group == 1 else lib.mlhip_msm_g2
         mlhip.check(fn(cid, pts, sc.tobytes(), 0, n, c, out))
         assert out.raw == exp, (curve, trial, group, n, c)
+
+
+def test_plan_pool_reuse_and_release(lib, mlhip):
+    """the host-buffer entry points reuse pooled plans: same answers when sizes / curves / groups interleave, after
+    mlhip_release_cache(), and when a pooled plan (capacity 1000) serves a smaller n"""
+    order = ["BLS12-381", "BN254", "BLS12-381", "BLS12-377", "BN254", "BLS12-381"]
+    for rep, curve in enumerate(order):
+        g = load_golden(curve)
+        cid = g["curve_id"]
+        fpb, g1b, _, _ = mlhip.sizes(cid)
+        pts, scs, exp = load_msm1000(curve, fpb)
+        out = ctypes.create_string_buffer(g1b)
+        mlhip.check(lib.mlhip_msm_g1(cid, pts, scs, 0, 1000, 12, out))
+        assert out.raw == exp
+        # a 300-point prefix of the same vectors through the pooled 1000-point plan (capacity <= 4 n), checked by
+        # linearity: MSM(first 300) + MSM(rest) == MSM(all)
+        a = ctypes.create_string_buffer(g1b)
+        b = ctypes.create_string_buffer(g1b)
+        mlhip.check(lib.mlhip_msm_g1(cid, pts[: 300 * g1b], scs[: 300 * 32], 0, 300, 12, a))
+        mlhip.check(lib.mlhip_msm_g1(cid, pts[300 * g1b :], scs[300 * 32 :], 0, 700, 12, b))
+        tot = ctypes.create_string_buffer(g1b)
+        mlhip.check(lib.mlhip_g1_sum(cid, a.raw + b.raw, 2, tot))
+        assert tot.raw == exp
+        if rep == 2:
+            assert lib.mlhip_release_cache() == 0

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Wall time of the reference-shaped entry point mlhip_msm_g1 (host buffers in, affine point out): upload +
+plan + kernels + host tail per call, n = 2^20 BLS12-381.  This is the PCIe-inclusive number of DESIGN.md section 6."""
+import ctypes
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_golden  # noqa: E402
+from mathlib_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
+g = load_golden("BLS12-381")
+cid = g["curve_id"]
+fpb, g1b, g2b, gtb = _lib.sizes(cid)
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream().cuda_stream
+gen = torch.Generator(device=dev)
+gen.manual_seed(3)
+
+
+def rnd(k):
+    return torch.randint(-(1 << 63), (1 << 63) - 1, (k, 4), dtype=torch.int64, generator=gen, device=dev).view(torch.uint8).reshape(k, 32).contiguous()
+
+
+base = torch.frombuffer(bytearray(bytes.fromhex(g["g1_gen"])), dtype=torch.uint8).to(dev)
+P = torch.empty(n * g1b, dtype=torch.uint8, device=dev)
+_lib.check(lib.mlhip_scalar_mul_device(cid, 1, base.data_ptr(), 0, rnd(n).data_ptr(), 0, n, P.data_ptr(), st))
+S = rnd(n)
+torch.cuda.synchronize()
+hp = P.cpu().numpy().tobytes()
+hs = S.cpu().numpy().tobytes()
+out = ctypes.create_string_buffer(g1b)
+res = []
+for rep in range(6):
+    t0 = time.perf_counter()
+    _lib.check(lib.mlhip_msm_g1(cid, hp, hs, 0, n, 16, out))
+    res.append((time.perf_counter() - t0) * 1e3)
+plan = _lib.MsmPlan(cid, 1, n, 16)
+ref = plan.run(P.data_ptr(), S.data_ptr(), n, False, st)
+print("mlhip_msm_g1 host-buffer call, n=2^%d: %s ms (first call includes lazy init); matches resident-plan result: %s" % (
+    n.bit_length() - 1, ", ".join("%.2f" % x for x in res), out.raw == ref))
