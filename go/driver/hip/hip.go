@@ -44,6 +44,19 @@ import (
 // WindowC is the Pippenger window (0 = chosen from n; BASELINE config 2 uses 16).
 var WindowC = 0
 
+// The GPU is a throughput device.  Measured on one MI355X through this ABI (tools/perf_latency.py): a
+// MultiScalarMul of 2 points takes 0.35 ms, of 2^20 points 6.2 ms; but ONE Miller loop takes 6.4 ms and ONE final
+// exponentiation 16.8 ms, because a single pairing occupies a single lane pair (65 536 of them take 31 ms).
+// gnark on the CPU does a single pairing in about a millisecond.  Hence:
+//
+// MinDeviceMSM: MultiScalarMul with fewer pairs stays on the embedded gurvy driver.
+var MinDeviceMSM = 32
+
+// DevicePairing: when false (default) the single-shot Pairing / Pairing2 / FExp stay on the embedded gurvy driver
+// and only the batched entry points (PairingBatch) use the GPU.  Mixing is safe: FExp of either Miller loop's
+// output is the same canonical Gt (SURVEY.md section 8c).
+var DevicePairing = false
+
 func init() {
 	// the C ABI assumes gnark's in-memory layout; refuse to run if it ever changes
 	if unsafe.Sizeof(bls12381.G1Affine{}) != 96 || unsafe.Sizeof(bls12381.G2Affine{}) != 192 ||
@@ -81,6 +94,9 @@ func (c *Curve) MultiScalarMul(a []driver.G1, b []driver.Zr) driver.G1 {
 		// gnark's MultiExp errors on a length mismatch and the driver drops the error: identity
 		return out
 	}
+	if n < MinDeviceMSM {
+		return c.Curve.MultiScalarMul(a, b)
+	}
 	check(C.mlhip_msm_g1(C.MLHIP_CURVE_BLS12_381,
 		unsafe.Pointer(&points[0]), unsafe.Pointer(&scalars[0]), 1, C.size_t(n), C.int(WindowC),
 		unsafe.Pointer(&out.G1Affine)))
@@ -89,6 +105,9 @@ func (c *Curve) MultiScalarMul(a []driver.G1, b []driver.Zr) driver.G1 {
 
 // Pairing replaces bls12-381.go:448-455: Miller loop only, compare after FExp.
 func (c *Curve) Pairing(p2 driver.G2, p1 driver.G1) driver.Gt {
+	if !DevicePairing {
+		return c.Curve.Pairing(p2, p1)
+	}
 	out := &gurvy381.Gt{}
 	check(C.mlhip_miller_loop(C.MLHIP_CURVE_BLS12_381,
 		unsafe.Pointer(&p1.(*gurvy381.G1).G1Affine), unsafe.Pointer(&p2.(*gurvy381.G2).G2Affine),
@@ -98,6 +117,9 @@ func (c *Curve) Pairing(p2 driver.G2, p1 driver.G1) driver.Gt {
 
 // Pairing2 replaces bls12-381.go:457-464 (one shared Miller loop over two pairs).
 func (c *Curve) Pairing2(p2a, p2b driver.G2, p1a, p1b driver.G1) driver.Gt {
+	if !DevicePairing {
+		return c.Curve.Pairing2(p2a, p2b, p1a, p1b)
+	}
 	g1 := [2]bls12381.G1Affine{p1a.(*gurvy381.G1).G1Affine, p1b.(*gurvy381.G1).G1Affine}
 	g2 := [2]bls12381.G2Affine{p2a.(*gurvy381.G2).G2Affine, p2b.(*gurvy381.G2).G2Affine}
 	out := &gurvy381.Gt{}
@@ -108,6 +130,9 @@ func (c *Curve) Pairing2(p2a, p2b driver.G2, p1a, p1b driver.G1) driver.Gt {
 
 // FExp replaces bls12-381.go:466-468.
 func (c *Curve) FExp(a driver.Gt) driver.Gt {
+	if !DevicePairing {
+		return c.Curve.FExp(a)
+	}
 	out := &gurvy381.Gt{}
 	check(C.mlhip_final_exp(C.MLHIP_CURVE_BLS12_381,
 		unsafe.Pointer(&a.(*gurvy381.Gt).GT), 1, unsafe.Pointer(&out.GT)))
