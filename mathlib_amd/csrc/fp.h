@@ -328,8 +328,13 @@ MLHIP_HD void fp_mul_small(Fp<C>& r, const Fp<C>& a, int k) {
 
 // a^(p-2): Fermat inversion (0 -> 0).  Used once per pairing (final-exponentiation easy part) and
 // in the O(1) host tail of an MSM; never in a hot loop.
+// r = a^-1 (0 -> 0): constant-time divsteps inversion, defined in modinv.h (included at the end of this file)
 template <class C>
-MLHIP_HD void fp_inv(Fp<C>& r, const Fp<C>& a) {
+MLHIP_HD_NOINLINE void fp_inv(Fp<C>& r, const Fp<C>& a);
+
+// Fermat: a^(p-2); kept as the independent second implementation for the tests
+template <class C>
+MLHIP_HD void fp_inv_fermat(Fp<C>& r, const Fp<C>& a) {
   constexpr int N = C::N;
   uint32_t e[N];
   // e = p - 2 (BLS12-377's p ends in ...0001, so the borrow must propagate)
@@ -374,3 +379,5 @@ MLHIP_HD void fp_from_mont(Fp<C>& r, const Fp<C>& a) {
 }
 
 }  // namespace mlhip
+
+#include "modinv.h"  // fp_inv

@@ -11,6 +11,7 @@
 #include "../../mathlib_amd/csrc/ec28.h"
 #include "../../mathlib_amd/csrc/ec_quad.h"
 #include "../../mathlib_amd/csrc/ec28_lp.h"
+#include "../../mathlib_amd/csrc/modinv.h"
 
 using namespace mlhip;
 
@@ -38,6 +39,8 @@ struct Ops {
       case 6: fp_halve<C>(r, x); break;
       case 7: fp_to_mont<C>(r, x); break;
       case 8: fp_from_mont<C>(r, x); break;
+      case 9: fp_inv_divsteps<C>(r, x); break;
+      case 10: fp_inv_fermat<C>(r, x); break;
       default: return -1;
     }
     memcpy(out, &r, sizeof(F));

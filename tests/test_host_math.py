@@ -428,3 +428,24 @@ def test_madd28_lane_pair_g2_accumulation(hostmath, name):
         out = ctypes.create_string_buffer(4 * n)
         assert L.hm_madd28_lp_chain(cid, pts, neg, len(seq), out) == 0
         assert out.raw == R.g2_to_mont_bytes(cp, want)
+
+
+@pytest.mark.parametrize("name", list(R.CURVES))
+def test_divsteps_inversion(hostmath, name):
+    """modinv.h (Bernstein-Yang divsteps, fixed iteration count) against Python's pow(x, -1, p): edge values, values
+    whose gcd chains are long (Fibonacci-like neighbours), and random ones; 0 maps to 0 as with Fermat."""
+    cp = R.CURVES[name]
+    L, cid, p = hostmath, cp.curve_id, cp.p
+    d = R.Drbg("host/modinv/" + name)
+    vals = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 30, (1 << 30) - 1, 1 << 60, (1 << (p.bit_length() - 1)),
+            (1 << (p.bit_length() - 1)) - 1, cp.R % p, pow(cp.R, -1, p)]
+    a, b = 1, 2
+    while b < p:  # consecutive Fibonacci numbers: the classical worst case of Euclid-type chains
+        a, b = b, a + b
+    vals += [a, b - a, p - a]
+    vals += [d.below(p) for _ in range(200)]
+    for x in vals:
+        out = ctypes.create_string_buffer(cp.fp_bytes)
+        assert L.hm_fp_op(cid, 9, R.fp_to_mont_bytes(cp, x), None, out) == 0
+        want = pow(x, -1, p) if x % p else 0
+        assert out.raw == R.fp_to_mont_bytes(cp, want), (name, x)
