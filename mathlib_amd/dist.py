@@ -30,9 +30,14 @@ def combine_partials(curve: int, group: int, local_affine: bytes, device: torch.
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     mine = torch.frombuffer(bytearray(local_affine), dtype=torch.uint8).to(device)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in gathered)
+    try:  # one flat buffer: one collective, one copy back to the host
+        flat = torch.empty(world * mine.numel(), dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(flat, mine)
+        blob = bytes(flat.cpu().numpy().tobytes())
+    except (RuntimeError, NotImplementedError):  # a backend without the flat form
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in gathered)
     out = ctypes.create_string_buffer(len(local_affine))
     fn = _lib.load().mlhip_g1_sum if group == _lib.GROUP_G1 else _lib.load().mlhip_g2_sum
     _lib.check(fn(curve, blob, world, out))
