@@ -198,18 +198,175 @@ MLHIP_HD void miller_loop(Fp12<C>& f, const Affine<FpField<C>>* P, const Affine<
   miller_loop_core<C, MAXP, Fp2<C>>(f, px, py, qx, qy, live, n_pairs);
 }
 
+// ---- Karabina's compressed cyclotomic squaring ----------------------------------------------------------------
+// Write a cyclotomic element over Fp4 = Fp2[s]/(s^2 - xi), s = w^3:  f = A + B w + C w^2 with
+// A = (c0.c0, c1.c1), B = (c1.c0, c0.c2), C = (c0.c1, c1.c2).  In the Granger-Scott squaring (fp12_cyclo_sqr) the
+// new B and C depend on B and C only, so a chain of squarings can carry just these four Fp2 values: 6 Fp2
+// squarings per step instead of 9.  A is recovered once at the end from the subgroup relation
+//     a1 = (xi d1^2 + 3 d0^2 - 2 b1) / (4 b0)      [b0 = 0:  a1 = 2 d0 d1 / b1]
+//     a0 = (2 a1^2 + b0 d1 - 3 b1 d0) xi + 1
+// (K. Karabina, "Squaring in cyclotomic subgroups", 2013; checked numerically in this basis against
+// oracle/pyref.py).  z^|x| = prod over the set bits of z^(2^i): every z^(2^i) comes out of ONE chain of compressed
+// squarings and all of them are decompressed with one shared inversion (Montgomery's trick).  Worth it when |x|
+// has few set bits (BLS12-381: 6, BLS12-377: 7); BN254's seed (27 set bits) keeps the plain chain.
+template <class C, class E2>
+struct CycloComp {
+  E2 b0, b1, d0, d1;
+};
+
+template <class C, class E2>
+MLHIP_HD_NOINLINE void cyclo_sqr_compressed(CycloComp<C, E2>& k) {
+  E2 t2, t3, t4, t5, t7, t8, s;
+  fp2_sqr<C>(t2, k.b1);
+  fp2_sqr<C>(t3, k.b0);
+  fp2_add<C>(s, k.b0, k.b1);
+  fp2_sqr<C>(t7, s);
+  fp2_sub<C>(t7, t7, t2);
+  fp2_sub<C>(t7, t7, t3);  // 2 b0 b1
+  fp2_sqr<C>(t4, k.d1);
+  fp2_sqr<C>(t5, k.d0);
+  fp2_add<C>(s, k.d0, k.d1);
+  fp2_sqr<C>(t8, s);
+  fp2_sub<C>(t8, t8, t4);
+  fp2_sub<C>(t8, t8, t5);
+  fp2_mul_xi<C>(t8, t8);  // 2 xi d0 d1
+  fp2_mul_xi<C>(t2, t2);
+  fp2_add<C>(t2, t2, t3);  // xi b1^2 + b0^2
+  fp2_mul_xi<C>(t4, t4);
+  fp2_add<C>(t4, t4, t5);  // xi d1^2 + d0^2
+  // d0' = 3 t2 - 2 d0 ; d1' = 3 t7 + 2 d1 ; b1' = 3 t4 - 2 b1 ; b0' = 3 t8 + 2 b0
+  fp2_sub<C>(s, t2, k.d0);
+  fp2_dbl<C>(s, s);
+  fp2_add<C>(k.d0, s, t2);
+  fp2_add<C>(s, t7, k.d1);
+  fp2_dbl<C>(s, s);
+  fp2_add<C>(k.d1, s, t7);
+  fp2_sub<C>(s, t4, k.b1);
+  fp2_dbl<C>(s, s);
+  fp2_add<C>(k.b1, s, t4);
+  fp2_add<C>(s, t8, k.b0);
+  fp2_dbl<C>(s, s);
+  fp2_add<C>(k.b0, s, t8);
+}
+
+// numerator and denominator of a1 for one compressed value (both formulas, selected by b0 = 0 / b1 = 0)
+template <class C, class E2>
+MLHIP_HD_NOINLINE void cyclo_a1_fraction(E2& num, E2& den, const CycloComp<C, E2>& k) {
+  E2 n1, n2, t, one;
+  fp2_sqr<C>(t, k.d1);
+  fp2_mul_xi<C>(n1, t);
+  fp2_sqr<C>(t, k.d0);
+  fp2_add<C>(n1, n1, t);
+  fp2_dbl<C>(t, t);
+  fp2_add<C>(n1, n1, t);  // xi d1^2 + 3 d0^2
+  fp2_dbl<C>(t, k.b1);
+  fp2_sub<C>(n1, n1, t);
+  fp2_mul<C>(n2, k.d0, k.d1);
+  fp2_dbl<C>(n2, n2);
+  const bool z0 = fp2_is_zero<C>(k.b0), z1 = fp2_is_zero<C>(k.b1);
+  fp2_select<C>(num, z0, n2, n1);
+  fp2_dbl<C>(t, k.b0);
+  fp2_dbl<C>(t, t);  // 4 b0
+  fp2_one<C>(one);
+  fp2_select<C>(den, z0, k.b1, t);
+  fp2_select<C>(den, z0 & z1, one, den);  // f = A + C w^2 with B = 0 (e.g. f = 1): a1 = 0 / 1
+}
+
+template <class C, class E2>
+MLHIP_HD_NOINLINE void cyclo_decompress(Fp12<C, E2>& r, const CycloComp<C, E2>& k, const E2& a1) {
+  E2 t, u, one;
+  fp2_sqr<C>(t, a1);
+  fp2_dbl<C>(t, t);
+  fp2_mul<C>(u, k.b0, k.d1);
+  fp2_add<C>(t, t, u);
+  fp2_mul<C>(u, k.b1, k.d0);
+  fp2_sub<C>(t, t, u);
+  fp2_dbl<C>(u, u);
+  fp2_sub<C>(t, t, u);  // 2 a1^2 + b0 d1 - 3 b1 d0
+  fp2_mul_xi<C>(t, t);
+  fp2_one<C>(one);
+  fp2_add<C>(r.c0.c0, t, one);
+  r.c1.c1 = a1;
+  r.c1.c0 = k.b0;
+  r.c0.c2 = k.b1;
+  r.c0.c1 = k.d0;
+  r.c1.c2 = k.d1;
+}
+
+constexpr int mlhip_popcount64(uint64_t v) {
+  int n = 0;
+  while (v) {
+    n += (int)(v & 1);
+    v >>= 1;
+  }
+  return n;
+}
+
 // z^|x| by cyclotomic squarings (z in the cyclotomic subgroup), conjugated when the seed is negative
 template <class C, class E2>
 MLHIP_HD_NOINLINE void fp12_expt(Fp12<C, E2>& r, const Fp12<C, E2>& z) {
-  Fp12<C, E2> acc = z;
   int top = 63;
   while (!((C::X_ABS >> top) & 1)) top--;
-  for (int i = top - 1; i >= 0; i--) {
-    fp12_cyclo_sqr<C>(acc, acc);
-    if ((C::X_ABS >> i) & 1) fp12_mul<C>(acc, acc, z);
+  constexpr int NSET = mlhip_popcount64(C::X_ABS);
+  if constexpr (NSET <= 8) {
+    // one chain of compressed squarings; the values at the set bits are kept, decompressed together, multiplied
+    constexpr int NS = NSET - (int)(C::X_ABS & 1);  // saved compressed values (bit 0 is z itself)
+    CycloComp<C, E2> k, saved[NS > 0 ? NS : 1];
+    k.b0 = z.c1.c0;
+    k.b1 = z.c0.c2;
+    k.d0 = z.c0.c1;
+    k.d1 = z.c1.c2;
+    int ns = 0;
+    for (int i = 1; i <= top; i++) {
+      cyclo_sqr_compressed<C>(k);
+      if ((C::X_ABS >> i) & 1) saved[ns++] = k;
+    }
+    // shared inversion of the NS denominators
+    E2 num[NS > 0 ? NS : 1], den[NS > 0 ? NS : 1], pre[NS > 0 ? NS : 1], inv, t;
+    for (int j = 0; j < NS; j++) {
+      cyclo_a1_fraction<C>(num[j], den[j], saved[j]);
+      if (j == 0)
+        pre[0] = den[0];
+      else
+        fp2_mul<C>(pre[j], pre[j - 1], den[j]);
+    }
+    Fp12<C, E2> acc, v;
+    bool have = false;
+    if (C::X_ABS & 1) {
+      acc = z;
+      have = true;
+    }
+    if (NS > 0) {
+      fp2_inv<C>(inv, pre[NS - 1]);
+      for (int j = NS - 1; j >= 0; j--) {
+        E2 dj_inv;
+        if (j > 0) {
+          fp2_mul<C>(dj_inv, inv, pre[j - 1]);
+          fp2_mul<C>(inv, inv, den[j]);
+        } else {
+          dj_inv = inv;
+        }
+        fp2_mul<C>(t, num[j], dj_inv);  // a1
+        cyclo_decompress<C>(v, saved[j], t);
+        if (have) {
+          fp12_mul<C>(acc, acc, v);
+        } else {
+          acc = v;
+          have = true;
+        }
+      }
+    }
+    if (C::X_NEG) fp12_conj<C>(acc, acc);
+    r = acc;
+  } else {
+    Fp12<C, E2> acc = z;
+    for (int i = top - 1; i >= 0; i--) {
+      fp12_cyclo_sqr<C>(acc, acc);
+      if ((C::X_ABS >> i) & 1) fp12_mul<C>(acc, acc, z);
+    }
+    if (C::X_NEG) fp12_conj<C>(acc, acc);
+    r = acc;
   }
-  if (C::X_NEG) fp12_conj<C>(acc, acc);
-  r = acc;
 }
 
 // r = f^(k (p^12 - 1)/r_order): the reference's FExp (bls12-381.go:466-468 etc.)

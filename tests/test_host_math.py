@@ -54,6 +54,11 @@ def test_fp12_tower(hostmath, name):
         assert R.gt_from_mont_bytes(cp, out.raw) == T.f12_pow(c, cp.x)
         L.hm_fp12_op(cid, 9, gb(f), None, out)
         assert R.gt_from_mont_bytes(cp, out.raw) == R.final_exp(cp, f)
+    # the unit (pairings with a point at infinity): the compressed-squaring chain must survive B = C = 0
+    one = T.f12_one
+    for op in (8, 9):
+        L.hm_fp12_op(cid, op, gb(one), None, out)
+        assert R.gt_from_mont_bytes(cp, out.raw) == one
 
 
 @pytest.mark.parametrize("name", CURVES)
