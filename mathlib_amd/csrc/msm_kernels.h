@@ -1,12 +1,15 @@
 // msm_kernels.h -- Pippenger MSM kernels and their launch sequence (gfx950).  Included by the per-curve
 // translation units tu_msm_<curve>.hip.  Pipeline and data layout: DESIGN.md section 3.
-//   k_digits      scalars -> signed window digits [W][n] + per-bucket histogram (global atomics)
-//   k_scan        exclusive scan of the W*M bucket counts
-//   k_scatter     counting-sort scatter: point indices grouped by (window, bucket)
-//   k_accumulate  one thread per bucket: XYZZ += points[idx] (mixed additions, gathered reads)
-//   k_accumulate_big  buckets longer than BIG_BUCKET: one workgroup each, LDS tree (degenerate inputs)
-//   k_chunks      level-1 bucket reduction: per 8 consecutive buckets, sum and locally weighted sum
-//   k_masked_sums level-2: per window, plain / bit-masked sums of the chunk sums (LDS tree)
+//   k_coarse_hist / k_coarse_scatter / k_fine_sort   two-level LDS counting sort of the (window, bucket) keys
+//                 (k_digits / k_scan / k_scatter: the global-atomic variant for n > 2^24, MLHIP_LEGACY_SORT=1)
+//   k_order_*     buckets ordered by population, so that a wave's lanes run equally long loops
+//   k_points_to28 / k_accumulate28      G1: points into the carry-free form (fp28.h), one thread per bucket:
+//                 XYZZ += points[idx] (mixed additions, gathered reads); k_accumulate is the boundary-form variant
+//   k_points_to28_g2 / k_accumulate28_lp / k_accumulate_lp   G2: two lanes per bucket (one Fp2 component each)
+//   k_accumulate_big  buckets longer than the threshold: one workgroup each, LDS tree (degenerate inputs)
+//   k_chunks_q / k_masked_sums_q   G1 bucket reduction, one point per quad of lanes (ec_quad.h): per 16 consecutive
+//                 buckets sum and locally weighted sum, then per window the plain / bit-masked sums of the chunk sums
+//                 (k_chunks / k_masked_sums: one lane per point; *_lp: G2 lane pairs)
 //   host tail     Horner over <= W*c bit positions + one inversion (O(1) work, 64-bit limbs)
 // Replaces gnark-crypto's MultiExp behind MultiScalarMul (reference
 // driver/gurvy/bls12381/bls12-381.go:766-783, driver/gurvy/bn254.go:232-245, driver/gurvy/bls12-377.go:229-242).
