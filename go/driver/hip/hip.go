@@ -233,3 +233,49 @@ func (c *Curve) G1sCompressed(pts []driver.G1) []byte {
 	check(C.mlhip_g1_to_bytes(C.MLHIP_CURVE_BLS12_381, unsafe.Pointer(&aff[0]), C.size_t(n), 1, unsafe.Pointer(&out[0])))
 	return out
 }
+
+// Bases is a G1 point table kept on the device (SURVEY.md 8f row 1): NewBases uploads it once, MultiScalarMul then
+// moves only the scalars (32 bytes each) per call -- the shape of a prover with a fixed SRS.
+type Bases struct {
+	h *C.mlhip_bases
+	n int
+}
+
+func (c *Curve) NewBases(points []driver.G1) *Bases {
+	n := len(points)
+	if n == 0 {
+		panic("hip: NewBases needs at least one point")
+	}
+	aff := make([]bls12381.G1Affine, n)
+	for i := range points {
+		aff[i] = points[i].(*gurvy381.G1).G1Affine
+	}
+	b := &Bases{n: n}
+	check(C.mlhip_bases_create(C.MLHIP_CURVE_BLS12_381, C.MLHIP_GROUP_G1, unsafe.Pointer(&aff[0]), C.size_t(n),
+		C.int(WindowC), &b.h))
+	return b
+}
+
+// MultiScalarMul returns sum_i [scalars[i]] bases[i] over the first len(scalars) bases.
+func (b *Bases) MultiScalarMul(scalars []driver.Zr) driver.G1 {
+	out := &gurvy381.G1{}
+	if len(scalars) == 0 {
+		return out
+	}
+	if len(scalars) > b.n {
+		panic("hip: more scalars than resident bases")
+	}
+	sc := make([]fr.Element, len(scalars))
+	for i := range scalars {
+		sc[i] = gurvy381.ZrValue(scalars[i])
+	}
+	check(C.mlhip_bases_msm(b.h, unsafe.Pointer(&sc[0]), 1, C.size_t(len(sc)), unsafe.Pointer(&out.G1Affine)))
+	return out
+}
+
+func (b *Bases) Close() {
+	if b.h != nil {
+		C.mlhip_bases_destroy(b.h)
+		b.h = nil
+	}
+}

@@ -133,6 +133,15 @@ int mlhip_scalar_mul_device(int curve, int group, const void* d_points, size_t p
 int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stride, const void* scalars,
                      int scalars_mont, size_t n, void* out_affine);
 
+/* ---- resident bases (upload-once point table, only the scalars travel per call) ----------
+ * For callers that cannot hold device pointers themselves (the Go shim): the points are uploaded once, every
+ * mlhip_bases_msm() uploads n x 32 bytes of scalars and returns sum_i [s_i] P_i over the first n bases (n <= the
+ * count given at creation).  One MSM at a time per handle; handles are independent of each other and of threads. */
+typedef struct mlhip_bases mlhip_bases;
+int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** bases);
+int mlhip_bases_msm(mlhip_bases* bases, const void* scalars, int scalars_mont, size_t n, void* out_affine);
+int mlhip_bases_destroy(mlhip_bases* bases);
+
 /* The host-buffer MSM entry points above keep up to four plans + input buffers alive between calls (creating and
  * destroying them costs as much as a 2^20-point MSM); this frees the idle ones.  MLHIP_NO_PLAN_CACHE=1 disables the pool. */
 int mlhip_release_cache(void);

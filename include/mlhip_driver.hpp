@@ -488,6 +488,37 @@ class Curve {
       memcpy(sc.data() + 32 * i, l.data(), 32);
     }
   }
+  friend class Bases;
+};
+
+// A G1 point table kept on the device (mlhip_bases_*): uploaded once, then only the scalars move per call.
+class Bases {
+ public:
+  Bases(const Curve& c, const std::vector<G1>& points) : curve_(&c), n_(points.size()) {
+    Bytes pts;
+    for (auto& x : points) pts.insert(pts.end(), x.raw.begin(), x.raw.end());
+    check(mlhip_bases_create(c.id, MLHIP_GROUP_G1, pts.data(), n_, c.window_c, &h_));
+  }
+  Bases(const Bases&) = delete;
+  Bases& operator=(const Bases&) = delete;
+  ~Bases() { mlhip_bases_destroy(h_); }
+  G1 MultiScalarMul(const std::vector<Zr>& b) const {
+    if (b.size() > n_) throw std::out_of_range("MultiScalarMul: more scalars than resident bases");
+    G1 out = curve_->NewG1();
+    if (b.empty()) return out;
+    Bytes sc(32 * b.size());
+    for (size_t i = 0; i < b.size(); i++) {
+      auto l = b[i].abi_limbs();
+      memcpy(sc.data() + 32 * i, l.data(), 32);
+    }
+    check(mlhip_bases_msm(h_, sc.data(), curve_->scalars_mont ? 1 : 0, b.size(), out.raw.data()));
+    return out;
+  }
+
+ private:
+  const Curve* curve_;
+  size_t n_;
+  mlhip_bases* h_ = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------------

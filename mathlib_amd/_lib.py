@@ -45,6 +45,9 @@ SYMBOLS = [
     "mlhip_gt_exp_device",
     "mlhip_scalar_mul_device",
     "mlhip_scalar_mul",
+    "mlhip_bases_create",
+    "mlhip_bases_msm",
+    "mlhip_bases_destroy",
     "mlhip_release_cache",
     "mlhip_g1_from_bytes",
     "mlhip_g1_to_bytes",
@@ -115,6 +118,9 @@ def load() -> ctypes.CDLL:
     lib.mlhip_gt_mul_device.argtypes = [ci, vp, vp, sz, vp, vp]
     lib.mlhip_scalar_mul_device.argtypes = [ci, ci, vp, sz, vp, ci, sz, vp, vp]
     lib.mlhip_scalar_mul.argtypes = [ci, ci, vp, sz, vp, ci, sz, vp]
+    lib.mlhip_bases_create.argtypes = [ci, ci, vp, sz, ci, ctypes.POINTER(c_void_p)]
+    lib.mlhip_bases_msm.argtypes = [vp, vp, ci, sz, vp]
+    lib.mlhip_bases_destroy.argtypes = [vp]
     lib.mlhip_g1_from_bytes.argtypes = [ci, vp, sz, ci, ci, vp, vp]
     lib.mlhip_g1_to_bytes.argtypes = [ci, vp, sz, ci, vp]
     lib.mlhip_g1_from_bytes_device.argtypes = [ci, vp, sz, ci, ci, vp, vp, vp]

@@ -393,6 +393,63 @@ int mlhip_msm_plan_timings(mlhip_msm_plan* p, float* ms, int cap) {
   return k;
 }
 
+struct mlhip_bases {
+  mlhip_msm_plan* plan = nullptr;
+  void *d_pts = nullptr, *d_sc = nullptr;
+  size_t n = 0, ptsz = 0;
+  int device = 0;
+};
+
+int mlhip_bases_destroy(mlhip_bases* b) {
+  if (!b) return 0;
+  (void)hipSetDevice(b->device);
+  if (b->d_pts) (void)hipFree(b->d_pts);
+  if (b->d_sc) (void)hipFree(b->d_sc);
+  if (b->plan) mlhip_msm_plan_destroy(b->plan);
+  delete b;
+  return 0;
+}
+
+int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** out) {
+  if (!out) return mlhip_rt::fail(MLHIP_EINVAL, "null output pointer");
+  *out = nullptr;
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (group != MLHIP_GROUP_G1 && group != MLHIP_GROUP_G2) return mlhip_rt::fail(MLHIP_EINVAL, "group must be 1 (G1) or 2 (G2)");
+  if (!points || n == 0) return mlhip_rt::fail(MLHIP_EINVAL, "bases need at least one point");
+  int rc = ensure_device();
+  if (rc) return rc;
+  mlhip_bases* b = new mlhip_bases();
+  b->device = g_device;
+  b->n = n;
+  b->ptsz = group == MLHIP_GROUP_G1 ? sz.g1 : sz.g2;
+  rc = mlhip_msm_plan_create(curve, group, n, window_c, &b->plan);
+  if (!rc && (hipMalloc(&b->d_pts, n * b->ptsz) != hipSuccess || hipMalloc(&b->d_sc, n * 32) != hipSuccess))
+    rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of the bases failed");
+  if (!rc && hipMemcpy(b->d_pts, points, n * b->ptsz, hipMemcpyHostToDevice) != hipSuccess)
+    rc = mlhip_rt::fail(MLHIP_EHIP, "upload of the bases failed");
+  if (rc) {
+    mlhip_bases_destroy(b);
+    return rc;
+  }
+  *out = b;
+  return 0;
+}
+
+int mlhip_bases_msm(mlhip_bases* b, const void* scalars, int scalars_mont, size_t n, void* out_affine) {
+  if (!b || !out_affine) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  if (n > b->n) return mlhip_rt::fail(MLHIP_EINVAL, "more scalars than resident bases");
+  if (n == 0) {
+    memset(out_affine, 0, b->ptsz);
+    return 0;
+  }
+  if (!scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  if (hipSetDevice(b->device) != hipSuccess) return mlhip_rt::fail(MLHIP_EHIP, "hipSetDevice failed");
+  if (hipMemcpy(b->d_sc, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess)
+    return mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy of MSM scalars failed");
+  return mlhip_msm_run(b->plan, b->d_pts, b->d_sc, scalars_mont, n, nullptr, out_affine, nullptr);
+}
+
 int mlhip_release_cache(void) {
   std::vector<PoolEntry*> idle;
   {

@@ -395,6 +395,10 @@ class Curve:
         check(load().mlhip_msm_g2(self.id, pts, self._scalars(b), 1 if self.scalars_mont else 0, len(a), self.window_c, out))
         return G2(out.raw, self)
 
+    def NewBases(self, points: Sequence[G1]) -> "Bases":
+        """Upload a G1 point table once; Bases.MultiScalarMul(scalars) then moves only the scalars."""
+        return Bases(self, points)
+
     def Pairing(self, p2: G2, p1: G1) -> Gt:
         """Miller loop only, like the gurvy drivers (bls12-381.go:448-455); compare after FExp."""
         out = ctypes.create_string_buffer(self.gt_bytes)
@@ -433,3 +437,33 @@ class Curve:
 def NewCurve(name: str, **kw) -> Curve:
     ids = {"BN254": CURVE_BN254, "BLS12_381": CURVE_BLS12_381, "BLS12_377": CURVE_BLS12_377}
     return Curve(ids[name.upper().replace("-", "_")], **kw)
+
+
+class Bases:
+    """Resident G1 bases (mlhip_bases_*): the additive API a prover with a fixed SRS would use."""
+
+    def __init__(self, curve: "Curve", points: Sequence[G1]):
+        self.curve = curve
+        self.n = len(points)
+        self._h = ctypes.c_void_p()
+        blob = b"".join(p.raw for p in points)
+        check(load().mlhip_bases_create(curve.id, GROUP_G1, blob, self.n, curve.window_c, ctypes.byref(self._h)))
+
+    def MultiScalarMul(self, scalars: Sequence[Zr]) -> G1:
+        if len(scalars) > self.n:
+            raise IndexError("MultiScalarMul: more scalars than resident bases")
+        out = ctypes.create_string_buffer(self.curve.g1_bytes)
+        c = self.curve
+        check(load().mlhip_bases_msm(self._h, c._scalars(scalars), 1 if c.scalars_mont else 0, len(scalars), out))
+        return G1(out.raw, c)
+
+    def Close(self) -> None:
+        if self._h:
+            load().mlhip_bases_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.Close()
+        except Exception:
+            pass

@@ -102,6 +102,13 @@ static void runMultiScalarMul(const Curve& c, uint64_t& st) {
   G1 fixed = c.MultiScalarMul(ps, ss);
   EXPECT(fixed.Equals(c.GenG1().Mul(c.NewZrFromInt(40))));
   printf("%s msm_40G_compressed %s\n", kNames[c.id], hex(fixed.Compressed()).c_str());
+  {  // resident bases: same element as the host-slice call, for the whole table and a prefix
+    Bases bases(c, ps);
+    EXPECT(bases.MultiScalarMul(ss).Equals(fixed));
+    std::vector<Zr> few(ss.begin(), ss.begin() + 3);
+    std::vector<G1> fewp(ps.begin(), ps.begin() + 3);
+    EXPECT(bases.MultiScalarMul(few).Equals(c.MultiScalarMul(fewp, few)));
+  }
 }
 
 // math_test.go:272-321 on the GPU path

@@ -214,3 +214,19 @@ def test_g2_wire_round_trips(curve):
     bad[-1] ^= 1
     with pytest.raises(ValueError):
         c.NewG2FromBytes(bytes(bad))
+
+
+def test_resident_bases_match_multiscalarmul(curve):
+    """the upload-once point table gives the same element as MultiScalarMul, for the full table and
+    for a prefix of it, on repeated calls."""
+    c = curve
+    g = c.GenG1()
+    pts = [g.Mul(c.NewRandomZr(c._rng)) for _ in range(40)]
+    bases = c.NewBases(pts)
+    for n in (40, 17, 1, 40):
+        sc = [c.NewRandomZr(c._rng) for _ in range(n)]
+        assert bases.MultiScalarMul(sc).Equals(c.MultiScalarMul(pts[:n], sc))
+    assert bases.MultiScalarMul([]).IsInfinity()
+    with pytest.raises(IndexError):
+        bases.MultiScalarMul([c.NewRandomZr(c._rng)] * 41)
+    bases.Close()
