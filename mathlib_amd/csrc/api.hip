@@ -37,11 +37,13 @@ int ilog2(size_t v) {
   return l;
 }
 
+// measured optimum on one MI355X (tools/sweep_window.py, profiles/r01_sweep_window.txt): the fixed cost per window
+// (sort passes, launch latencies) outweighs the bucket count early, so c = 16 wins from n = 2^14 upwards
 int pick_window(size_t n) {
-  int c = ilog2(n ? n : 1) - 3;
-  if (c < 4) c = 4;
-  if (c > 16) c = 16;
-  return c;
+  if (n <= 128) return 4;
+  if (n <= 2048) return 8;
+  if (n <= 8192) return 12;
+  return 16;
 }
 
 template <class F>
