@@ -99,3 +99,45 @@ def test_pairing_batch_65536_properties(mlhip):
     mlhip.check(lib.mlhip_pairing_batch_device(cid, pts.data_ptr() + h * 96, q.data_ptr() + h * 192, n - h, out2.data_ptr() + h * 576, st))
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("curve_name,group,log_n", [("BLS12-381", 2, 18), ("BLS12-377", 1, 19), ("BN254", 1, 20)])
+def test_msm_other_config_shapes(mlhip, curve_name, group, log_n):
+    """BASELINE configs 4 and 5 shapes per GPU (G2 on BLS12-381 -- the carry-free lane-pair path at scale --, BLS12-377
+    G1 2^19) and BN254 2^20: split-sum property and the C oracle on the whole input."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from conftest import load_golden
+    from oracle import cref
+
+    g = load_golden(curve_name)
+    cid = g["curve_id"]
+    lib = mlhip.load()
+    fpb, g1b, g2b, gtb = mlhip.sizes(cid)
+    sz = g1b if group == 1 else g2b
+    n = 1 << log_n
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(100 + cid + group)
+    rnd = lambda m: torch.randint(-(1 << 63), (1 << 63) - 1, (m, 4), dtype=torch.int64, generator=gen, device=dev).view(torch.uint8).reshape(m, 32).contiguous()  # noqa: E731
+    base = torch.frombuffer(bytearray(bytes.fromhex(g["g1_gen" if group == 1 else "g2_gen"])), dtype=torch.uint8).to(dev)
+    pts = torch.empty(n * sz, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    mlhip.check(lib.mlhip_scalar_mul_device(cid, group, base.data_ptr(), 0, rnd(n).data_ptr(), 0, n, pts.data_ptr(), st))
+    s = rnd(n)
+    torch.cuda.synchronize()
+    plan = mlhip.MsmPlan(cid, group, n, 16)
+    full = plan.run(pts.data_ptr(), s.data_ptr(), n, False, st)
+    h = n // 3 + 777
+    a = plan.run(pts.data_ptr(), s.data_ptr(), h, False, st)
+    b = plan.run(pts.data_ptr() + h * sz, s.data_ptr() + h * 32, n - h, False, st)
+    out = ctypes.create_string_buffer(sz)
+    mlhip.check((lib.mlhip_g1_sum if group == 1 else lib.mlhip_g2_sum)(cid, a + b, 2, out))
+    assert out.raw == full
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    ss = s.cpu().numpy().view(np.uint64).reshape(n, 4)
+    assert cref.msm(cid, group, pts.cpu().numpy(), ss, n, False, 16, threads) == full
+    plan.close()
