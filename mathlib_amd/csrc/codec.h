@@ -18,19 +18,29 @@ namespace mlhip {
 
 enum { CODEC_OK = 0, CODEC_MALFORMED = 1, CODEC_NOT_ON_CURVE = 2, CODEC_NOT_IN_SUBGROUP = 3 };
 
-// r = a^e, e given as N little-endian 32-bit words
+// r = a^e, e given as N little-endian 32-bit words: fixed 4-bit windows (15 table entries), so a 381-bit
+// exponent costs 380 squarings + <= 95 + 14 multiplications instead of ~190 with the binary ladder
 template <class C>
 MLHIP_HD void fp_pow_words(Fp<C>& r, const Fp<C>& a, const uint32_t (&e)[C::N]) {
+  Fp<C> tab[15];  // a^1 .. a^15
+  tab[0] = a;
+  for (int i = 1; i < 15; i++) fp_mul<C>(tab[i], tab[i - 1], a);
   Fp<C> acc;
   fp_one<C>(acc);
   bool started = false;
-  for (int i = C::N * 32 - 1; i >= 0; i--) {
-    if (started) fp_sqr<C>(acc, acc);
-    if ((e[i >> 5] >> (i & 31)) & 1u) {
+  for (int i = C::N * 8 - 1; i >= 0; i--) {  // nibbles, most significant first
+    if (started) {
+      fp_sqr<C>(acc, acc);
+      fp_sqr<C>(acc, acc);
+      fp_sqr<C>(acc, acc);
+      fp_sqr<C>(acc, acc);
+    }
+    const uint32_t nib = (e[i >> 3] >> ((i & 7) * 4)) & 15u;
+    if (nib) {
       if (started)
-        fp_mul<C>(acc, acc, a);
+        fp_mul<C>(acc, acc, tab[nib - 1]);
       else {
-        acc = a;
+        acc = tab[nib - 1];
         started = true;
       }
     }
