@@ -151,8 +151,9 @@ int mlhip_release_cache(void);
  * Decode n points of gnark's wire format (BLS12 curves: zcash 3-bit header; BN254: 2-bit header), all of the
  * same form: compressed (fp bytes each) or uncompressed (2 x fp bytes).  Every point gets a status byte:
  * 0 ok | 1 malformed (flags, coordinate >= p, bad infinity) | 2 not on the curve | 3 not in the r-torsion
- * subgroup; out_affine[i] is (0,0) unless status[i] == 0.  subgroup_check = 0 skips the [r]P test (gnark's
- * SetBytes always does it; its cost is ~6x the decompression itself). */
+ * subgroup; out_affine[i] is (0,0) unless status[i] == 0.  subgroup_check: 0 skips the test (gnark's SetBytes always
+ * does it), 1 runs the fastest exact test (BLS12 G1: phi(P) = [-x^2]P, two 64-bit ladders, the criterion gnark
+ * uses; otherwise the [r]P ladder), 2 forces the plain [r]P ladder (kept for cross-checking). */
 int mlhip_g1_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out_affine,
                         unsigned char* status);
 int mlhip_g1_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire);

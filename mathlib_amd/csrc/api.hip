@@ -674,7 +674,8 @@ static int from_bytes_device(int curve, int group, const void* d_wire, size_t n,
                              void* d_out, unsigned char* d_status, void* stream) {
   int rc = ensure_device();
   if (rc) return rc;
-  return tu_wire_codec(curve, group, 0, d_wire, n, compressed ? 1 : 0, subgroup_check ? 1 : 0, d_out, d_status, (hipStream_t)stream);
+  return tu_wire_codec(curve, group, 0, d_wire, n, compressed ? 1 : 0, subgroup_check == 2 ? 2 : (subgroup_check ? 1 : 0), d_out, d_status,
+                       (hipStream_t)stream);
 }
 
 static int to_bytes_device(int curve, int group, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream) {

@@ -136,9 +136,9 @@ MLHIP_HD void fp_to_be(uint8_t* b, const Fp<C>& a_plain) {
   }
 }
 
-// [r]P == infinity ?
+// [r]P == infinity ?  (the plain ladder: 255 doublings + ~128 additions)
 template <class C>
-MLHIP_HD bool g1_in_subgroup(const Affine<FpField<C>>& P) {
+MLHIP_HD bool g1_in_subgroup_ladder(const Affine<FpField<C>>& P) {
   typedef FpField<C> F;
   XYZZ<F> acc;
   xyzz_set_inf<F>(acc);
@@ -151,8 +151,50 @@ MLHIP_HD bool g1_in_subgroup(const Affine<FpField<C>>& P) {
   return xyzz_is_inf<F>(acc);
 }
 
+// BLS12 curves: P is in G1  <=>  phi(P) = [-x^2] P, with phi(x, y) = (beta x, y) the order-3 endomorphism and x the
+// curve seed (the test gnark-crypto's IsInSubGroup uses; M. Scott, "A note on group membership tests for G1, G2 and
+// GT on BLS pairing-friendly curves", 2021).  Sound on every curve point by algebra alone: phi^2 + phi + 1 = 0
+// holds on the whole curve, so phi(P) = [-x^2]P forces [x^4 - x^2 + 1]P = [r]P = O; complete because phi acts as
+// the scalar -x^2 on the r-torsion for this beta (tools/gen_constants.py picks it).  Two 64-bit ladders (2 x 63
+// doublings + a dozen additions) instead of a 255-bit one.
 template <class C>
-MLHIP_HD int g1_decode(Affine<FpField<C>>& out, const uint8_t* w, bool compressed, bool subgroup_check) {
+MLHIP_HD bool g1_in_subgroup_endo(const Affine<FpField<C>>& P) {
+  typedef FpField<C> F;
+  int top = 63;
+  while (!((C::X_ABS >> top) & 1)) top--;
+  XYZZ<F> R, S, d;
+  xyzz_from_affine<F>(R, P);  // [|x|] P
+  for (int i = top - 1; i >= 0; i--) {
+    xyzz_dbl<F>(d, R);
+    R = d;
+    if ((C::X_ABS >> i) & 1) xyzz_madd<F>(R, P, false);
+  }
+  S = R;  // [|x|] R = [x^2] P
+  for (int i = top - 1; i >= 0; i--) {
+    xyzz_dbl<F>(d, S);
+    S = d;
+    if ((C::X_ABS >> i) & 1) xyzz_add<F>(S, R);
+  }
+  if (xyzz_is_inf<F>(S)) return false;  // the order of P divides x^2: not in G1 (P is finite here)
+  // S == -phi(P) = (beta Px, -Py) ?   i.e.  S.X = beta Px S.ZZ  and  S.Y = -Py S.ZZZ
+  Fp<C> beta, t, u;
+  fp_from_const<C>(beta, C::ENDO_BETA);
+  fp_mul<C>(t, P.x, beta);
+  fp_mul<C>(t, t, S.zz);
+  fp_mul<C>(u, P.y, S.zzz);
+  fp_neg<C>(u, u);
+  return fp_eq<C>(t, S.x) & fp_eq<C>(u, S.y);
+}
+
+// mode 1: the fastest exact test available for the curve; mode 2: always the plain [r]P ladder
+template <class C>
+MLHIP_HD bool g1_in_subgroup(const Affine<FpField<C>>& P, int mode) {
+  if (!C::IS_BN && mode != 2) return g1_in_subgroup_endo<C>(P);
+  return g1_in_subgroup_ladder<C>(P);
+}
+
+template <class C>
+MLHIP_HD int g1_decode(Affine<FpField<C>>& out, const uint8_t* w, bool compressed, int subgroup_check) {
   typedef FpField<C> F;
   constexpr int NB = C::N * 4;
   fp_zero<C>(out.x);
@@ -201,7 +243,7 @@ MLHIP_HD int g1_decode(Affine<FpField<C>>& out, const uint8_t* w, bool compresse
   Affine<F> P;
   P.x = x;
   P.y = y;
-  if (subgroup_check && !C::G1_COFACTOR_ONE && !g1_in_subgroup<C>(P)) return CODEC_NOT_IN_SUBGROUP;
+  if (subgroup_check && !C::G1_COFACTOR_ONE && !g1_in_subgroup<C>(P, subgroup_check)) return CODEC_NOT_IN_SUBGROUP;
   out = P;
   return CODEC_OK;
 }
@@ -322,7 +364,7 @@ MLHIP_HD int wire_flags(uint8_t flags, bool compressed, bool& f_inf, bool& f_lar
 }
 
 template <class C>
-MLHIP_HD int g2_decode(Affine<Fp2Field<C>>& out, const uint8_t* w, bool compressed, bool subgroup_check) {
+MLHIP_HD int g2_decode(Affine<Fp2Field<C>>& out, const uint8_t* w, bool compressed, int subgroup_check) {
   typedef Fp2Field<C> F;
   constexpr int NB = C::N * 4;
   fp2_zero<C>(out.x);
@@ -397,14 +439,14 @@ template <class C>
 struct G1Wire {
   typedef Affine<FpField<C>> Aff;
   static constexpr int XB = C::N * 4;  // bytes of one coordinate
-  MLHIP_HD static int decode(Aff& o, const uint8_t* w, bool comp, bool sg) { return g1_decode<C>(o, w, comp, sg); }
+  MLHIP_HD static int decode(Aff& o, const uint8_t* w, bool comp, int sg) { return g1_decode<C>(o, w, comp, sg); }
   MLHIP_HD static void encode(uint8_t* w, const Aff& p, bool comp) { g1_encode<C>(w, p, comp); }
 };
 template <class C>
 struct G2Wire {
   typedef Affine<Fp2Field<C>> Aff;
   static constexpr int XB = C::N * 8;
-  MLHIP_HD static int decode(Aff& o, const uint8_t* w, bool comp, bool sg) { return g2_decode<C>(o, w, comp, sg); }
+  MLHIP_HD static int decode(Aff& o, const uint8_t* w, bool comp, int sg) { return g2_decode<C>(o, w, comp, sg); }
   MLHIP_HD static void encode(uint8_t* w, const Aff& p, bool comp) { g2_encode<C>(w, p, comp); }
 };
 

@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(64) k_wire_decode(const uint8_t* __restrict__ 
     w[4 * k + 3] = (uint8_t)(v >> 24);
   }
   typename W::Aff p;
-  int st = W::decode(p, w, compressed != 0, subgroup != 0);
+  int st = W::decode(p, w, compressed != 0, subgroup);
   out[i] = p;
   status[i] = (uint8_t)st;
 }

@@ -166,7 +166,7 @@ struct Ops {
   }
   static int g1dec(const uint8_t* w, int compressed, int subgroup, void* out) {
     A1 p;
-    int st = g1_decode<C>(p, w, compressed != 0, subgroup != 0);
+    int st = g1_decode<C>(p, w, compressed != 0, subgroup);
     memcpy(out, &p, sizeof(A1));
     return st;
   }
@@ -307,7 +307,7 @@ struct Ops {
   }
   static int g2dec(const uint8_t* w, int compressed, int subgroup, void* out) {
     A2 p;
-    int st = g2_decode<C>(p, w, compressed != 0, subgroup != 0);
+    int st = g2_decode<C>(p, w, compressed != 0, subgroup);
     memcpy(out, &p, sizeof(A2));
     return st;
   }

@@ -317,9 +317,10 @@ def test_g1_wire_codec_vs_oracle(lib, mlhip, curve):
     bad.append(R.g1_wire_compressed(cp, pts[0]))  # a good one in between
     st = ctypes.create_string_buffer(len(bad))
     out = ctypes.create_string_buffer(2 * n * len(bad))
-    mlhip.check(lib.mlhip_g1_from_bytes(cid, b"".join(bad), len(bad), 1, 1, out, st))
-    assert list(st.raw) == [R.g1_from_wire(cp, w)[1] for w in bad]
-    assert out.raw[-2 * n :] == R.g1_to_mont_bytes(cp, pts[0])
+    for mode in (1, 2):  # 1: endomorphism test (BLS12), 2: the plain [r]P ladder -- both exact
+        mlhip.check(lib.mlhip_g1_from_bytes(cid, b"".join(bad), len(bad), 1, mode, out, st))
+        assert list(st.raw) == [R.g1_from_wire(cp, w)[1] for w in bad], mode
+        assert out.raw[-2 * n :] == R.g1_to_mont_bytes(cp, pts[0])
     w = bytearray(R.g1_wire_uncompressed(cp, pts[1]))  # uncompressed, off the curve
     w[-1] ^= 1
     st1 = ctypes.create_string_buffer(1)

@@ -454,3 +454,57 @@ def test_divsteps_inversion(hostmath, name):
         assert L.hm_fp_op(cid, 9, R.fp_to_mont_bytes(cp, x), None, out) == 0
         want = pow(x, -1, p) if x % p else 0
         assert out.raw == R.fp_to_mont_bytes(cp, want), (name, x)
+
+
+@pytest.mark.parametrize("name", ["BLS12-381", "BLS12-377"])
+def test_g1_subgroup_test_by_endomorphism(hostmath, name):
+    """codec.h g1_in_subgroup_endo (phi(P) = [-x^2]P) must agree with the plain [r]P ladder on every kind of curve
+    point: r-torsion points, random curve points (cofactor components), points of each small prime order dividing the
+    cofactor, and sums subgroup + small-order."""
+    from math import gcd
+
+    cp = R.CURVES[name]
+    L, cid, n, p = hostmath, cp.curve_id, cp.fp_bytes, cp.p
+    d = R.Drbg("host/endo/" + name)
+    order = p + 1 - (cp.x + 1)  # #E(Fp) for BLS12: t = x + 1
+    h = order // cp.r
+    assert h * cp.r == order
+
+    def curve_point():
+        while True:
+            x = d.below(p)
+            y = R.fp_sqrt((x * x * x + cp.b) % p, p)
+            if y is not None:
+                return (x, y)
+
+    # small prime factors of the cofactor (trial division is enough for these h)
+    fac, m, q = [], h, 2
+    while q * q <= m and q < 1 << 22:
+        if m % q == 0:
+            fac.append(q)
+            while m % q == 0:
+                m //= q
+        q += 1
+    if m > 1:
+        fac.append(m)
+    pts = [R.random_g1(cp, d) for _ in range(3)] + [cp.g1]
+    bad = []
+    for _ in range(4):
+        bad.append(curve_point())
+    for ell in fac:  # a point of exact order ell
+        for _ in range(20):
+            T = R.g1_mul_unreduced(cp, curve_point(), order // ell)
+            if T is not None:
+                bad.append(T)
+                bad.append(R.g1_add(cp, T, pts[0]))  # subgroup point + small-order point
+                break
+    assert len(bad) >= 6
+    for P, want in [(q_, True) for q_ in pts] + [(q_, R.g1_mul_unreduced(cp, q_, cp.r) is None) for q_ in bad]:
+        w = R.g1_wire_uncompressed(cp, P)
+        got = {}
+        for mode in (1, 2):
+            out = ctypes.create_string_buffer(2 * n)
+            st = L.hm_g1_decode(cid, w, 0, mode, out)
+            assert st in (0, 3)
+            got[mode] = st == 0
+        assert got[1] == got[2] == want, (name, P)
