@@ -329,7 +329,7 @@ MLHIP_HD bool fp2_is_largest(const Fp2<C>& a) {
 }
 
 template <class C>
-MLHIP_HD bool g2_in_subgroup(const Affine<Fp2Field<C>>& Q) {
+MLHIP_HD bool g2_in_subgroup_ladder(const Affine<Fp2Field<C>>& Q) {
   typedef Fp2Field<C> F;
   XYZZ<F> acc;
   xyzz_set_inf<F>(acc);
@@ -340,6 +340,42 @@ MLHIP_HD bool g2_in_subgroup(const Affine<Fp2Field<C>>& Q) {
     if ((C::FR[i >> 5] >> (i & 31)) & 1u) xyzz_madd<F>(acc, Q, false);
   }
   return xyzz_is_inf<F>(acc);
+}
+
+// BLS12 curves: Q is in G2  <=>  psi(Q) = [x]Q, psi the untwist-Frobenius-twist endomorphism (the test gnark-crypto
+// uses; M. Scott 2021).  Sound: psi^2 - [t]psi + [p] = 0 on the whole twist, so psi(Q) = [x]Q forces
+// [x^2 - t x + p]Q = [p - x]Q = [((x-1)^2/3) r]Q = O, and the order of Q also divides #E'(Fp2) = h2 r with
+// gcd((x-1)^2/3, h2) = 1 (asserted when the constants are generated), hence divides r.  One 64-bit ladder.
+template <class C>
+MLHIP_HD bool g2_in_subgroup_psi(const Affine<Fp2Field<C>>& Q) {
+  typedef Fp2Field<C> F;
+  int top = 63;
+  while (!((C::X_ABS >> top) & 1)) top--;
+  XYZZ<F> S, d;
+  xyzz_from_affine<F>(S, Q);  // [|x|] Q
+  for (int i = top - 1; i >= 0; i--) {
+    xyzz_dbl<F>(d, S);
+    S = d;
+    if ((C::X_ABS >> i) & 1) xyzz_madd<F>(S, Q, false);
+  }
+  if (xyzz_is_inf<F>(S)) return false;
+  Fp2<C> px, py, k, t, u;
+  fp2_conj<C>(px, Q.x);
+  fp2_from_const<C>(k, C::PSI_X);
+  fp2_mul<C>(px, px, k);
+  fp2_conj<C>(py, Q.y);
+  fp2_from_const<C>(k, C::PSI_Y);
+  fp2_mul<C>(py, py, k);
+  if (C::X_NEG) fp2_neg<C>(py, py);  // [x]Q = -[|x|]Q: compare S with -psi(Q)
+  fp2_mul<C>(t, px, S.zz);
+  fp2_mul<C>(u, py, S.zzz);
+  return fp2_eq<C>(t, S.x) & fp2_eq<C>(u, S.y);
+}
+
+template <class C>
+MLHIP_HD bool g2_in_subgroup(const Affine<Fp2Field<C>>& Q, int mode) {
+  if (!C::IS_BN && mode != 2) return g2_in_subgroup_psi<C>(Q);
+  return g2_in_subgroup_ladder<C>(Q);
 }
 
 // shared header parsing; returns CODEC_OK and the three flags, or CODEC_MALFORMED
@@ -401,7 +437,7 @@ MLHIP_HD int g2_decode(Affine<Fp2Field<C>>& out, const uint8_t* w, bool compress
   Affine<F> Q;
   Q.x = x;
   Q.y = y;
-  if (subgroup_check && !g2_in_subgroup<C>(Q)) return CODEC_NOT_IN_SUBGROUP;
+  if (subgroup_check && !g2_in_subgroup<C>(Q, subgroup_check)) return CODEC_NOT_IN_SUBGROUP;
   out = Q;
   return CODEC_OK;
 }

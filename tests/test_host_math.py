@@ -508,3 +508,40 @@ def test_g1_subgroup_test_by_endomorphism(hostmath, name):
             assert st in (0, 3)
             got[mode] = st == 0
         assert got[1] == got[2] == want, (name, P)
+
+
+@pytest.mark.parametrize("name", ["BLS12-381", "BLS12-377"])
+def test_g2_subgroup_test_by_psi(hostmath, name):
+    """codec.h g2_in_subgroup_psi (psi(Q) = [x]Q) agrees with the plain [r]Q ladder on r-torsion points, random twist
+    points, points of small prime order dividing the G2 cofactor, and sums of the two kinds."""
+    cp = R.CURVES[name]
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("host/psi/" + name)
+    order = R.g2_order(cp)
+    h2 = order // cp.r
+    fac, m, q = [], h2, 2
+    while q < 1 << 16 and m > 1:
+        if m % q == 0:
+            fac.append(q)
+            while m % q == 0:
+                m //= q
+        q += 1
+    good = [R.random_g2(cp, d) for _ in range(2)] + [R.g2_generator(cp)]
+    bad = [R._g2_some_point(cp, 5 + 7 * i) for i in range(3)]
+    for ell in fac[:4]:
+        for i in range(10):
+            T = R.g2_mul_unreduced(cp, R._g2_some_point(cp, 100 + 13 * i + ell), order // ell)
+            if T is not None:
+                bad.append(T)
+                bad.append(R.g2_add(cp, T, good[0]))
+                break
+    for Q, want in [(q_, True) for q_ in good] + [(q_, R.g2_mul_unreduced(cp, q_, cp.r) is None) for q_ in bad]:
+        w = R.g2_wire_uncompressed(cp, Q)
+        got = {}
+        for mode in (1, 2):
+            out = ctypes.create_string_buffer(4 * n)
+            st = L.hm_g2_decode(cid, w, 0, mode, out)
+            assert st in (0, 3)
+            got[mode] = st == 0
+        assert got[1] == got[2] == want, (name, Q)
+    assert any(not w_ for _, w_ in [(q_, R.g2_mul_unreduced(cp, q_, cp.r) is None) for q_ in bad])
