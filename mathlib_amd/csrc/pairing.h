@@ -59,8 +59,15 @@ MLHIP_HD_NOINLINE void g2_double_step(G2Proj<C, E2>& T, Line<C, E2>& l) {
   fp2_halve<C>(A, A);
   fp2_sqr<C>(B, T.y);
   fp2_sqr<C>(Cc, T.z);
-  fp2_from_const<C>(b3, C::B3_TW);
-  fp2_mul<C>(E, Cc, b3);  // 3 b' Z^2
+  if constexpr (C::ID == 1) {
+    // BLS12-381: b' = 4 (1 + u) = 4 xi, so 3 b' Z^2 = 12 xi Z^2 -- additions instead of an Fp2 product
+    fp2_mul_xi<C>(E, Cc);
+    fp2_mul_small<C>(E, E, 12);
+    (void)b3;
+  } else {
+    fp2_from_const<C>(b3, C::B3_TW);
+    fp2_mul<C>(E, Cc, b3);  // 3 b' Z^2
+  }
   fp2_dbl<C>(F, E);
   fp2_add<C>(F, F, E);  // 3E
   fp2_add<C>(G, B, F);
