@@ -493,3 +493,41 @@ def test_plan_pool_reuse_and_release(lib, mlhip):
         assert tot.raw == exp
         if rep == 2:
             assert lib.mlhip_release_cache() == 0
+
+
+def test_concurrent_callers(lib, mlhip):
+    """the entry points are called from many OS threads at once (cgo).  Eight threads run
+    MSMs and pairing batches on different curves concurrently; every result must match its golden."""
+    import threading
+
+    errors = []
+
+    def worker(tid):
+        try:
+            curve = CURVES[tid % 3]
+            g = load_golden(curve)
+            cid = g["curve_id"]
+            fpb, g1b, _, gtb = mlhip.sizes(cid)
+            pts, scs, exp = load_msm1000(curve, fpb)
+            cases = g["pairing"]
+            p1 = b"".join(_h(c["g1"]) for c in cases)
+            p2 = b"".join(_h(c["g2"]) for c in cases)
+            pexp = b"".join(_h(c["fexp"]) for c in cases)
+            for rep in range(4):
+                out = ctypes.create_string_buffer(g1b)
+                rc = lib.mlhip_msm_g1(cid, pts, scs, 0, 1000, (0, 8, 12, 16)[(tid + rep) % 4], out)
+                if rc != 0 or out.raw != exp:
+                    errors.append(("msm", tid, rep, rc))
+                gt = ctypes.create_string_buffer(gtb * len(cases))
+                rc = lib.mlhip_pairing_batch(cid, p1, p2, len(cases), gt)
+                if rc != 0 or gt.raw != pexp:
+                    errors.append(("pairing", tid, rep, rc))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("exception", tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
