@@ -66,7 +66,8 @@ int mlhip_sizes(int curve, size_t* fp, size_t* g1, size_t* g2, size_t* gt);
 
 /* ---- host-buffer entry points (what the cgo shim binds) ------------------------------------- */
 /* out = sum_i [scalars[i]] points[i].  window_c = 0 picks a window from n; BASELINE config 2 uses 16.
- * n = 0 gives the point at infinity (the reference's MultiExp on empty slices). */
+ * n = 0 gives the point at infinity (the reference's MultiExp on empty slices).  Plans and input buffers are pooled
+ * between calls (mlhip_release_cache below); the upload of the points overlaps the sort of the scalars. */
 int mlhip_msm_g1(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
                  void* out_affine);
 int mlhip_msm_g2(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
@@ -161,7 +162,7 @@ int mlhip_g1_from_bytes_device(int curve, const void* d_wire, size_t n, int comp
                                void* d_out_affine, unsigned char* d_status, void* stream);
 int mlhip_g1_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream);
 /* G2 (NewG2FromBytes / NewG2FromCompressed, bls12-381.go:541-569): 2 / 4 fp-sized big-endian values per point in
- * the order X.A1, X.A0 [, Y.A1, Y.A0]; y recovered by a square root in Fp2; subgroup test [r]Q = infinity. */
+ * the order X.A1, X.A0 [, Y.A1, Y.A0]; y recovered by a square root in Fp2; subgroup_check as for G1. */
 int mlhip_g2_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out_affine,
                         unsigned char* status);
 int mlhip_g2_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire);
