@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Randomised soak against the C oracle: MSMs (all curves, G1 and G2, random n / window / scalar widths, duplicated
+and negated points, infinities) and pairing batches, for a given number of seconds.  Prints a progress line every
+20 s; exits non-zero on the first mismatch."""
+import ctypes
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_golden  # noqa: E402
+from mathlib_amd import _lib  # noqa: E402
+from oracle import cref  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+lib = _lib.load()
+rnd = random.Random(seed)
+names = ["BN254", "BLS12-381", "BLS12-377"]
+t0 = last = time.time()
+done = {"msm": 0, "pairing": 0}
+while time.time() - t0 < budget:
+    name = rnd.choice(names)
+    g = load_golden(name)
+    cid = g["curve_id"]
+    fpb, g1b, g2b, gtb = _lib.sizes(cid)
+    r_order = int(g["r"], 16)
+    if rnd.random() < 0.8:
+        group = 2 if rnd.random() < 0.25 else 1
+        sz = g1b if group == 1 else g2b
+        n = rnd.choice([1, 2, 5, 33, 100, 257, 1000, 1025, 3000, 5000, 20000, 70000]) if rnd.random() < 0.7 else rnd.randrange(1, 40000)
+        if group == 2:
+            n = min(n, 8000)
+        c = rnd.choice([0, 4, 6, 8, 9, 12, 13, 15, 16])
+        pts = bytearray(cref.gen_points(cid, group, rnd.getrandbits(40), rnd.getrandbits(40), n))
+        bits = rnd.choice([8, 32, 128, 200, 253])
+        vals = [rnd.getrandbits(bits) % r_order for _ in range(n)]
+        for k in range(n // 4):
+            i, j = rnd.randrange(n), rnd.randrange(n)
+            pts[j * sz : (j + 1) * sz] = pts[i * sz : (i + 1) * sz]
+            vals[j] = vals[i] if k % 2 == 0 else (r_order - vals[i]) % r_order
+        for k in range(n // 50):
+            j = rnd.randrange(n)
+            pts[j * sz : (j + 1) * sz] = bytes(sz)
+        sc = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint64).reshape(n, 4).copy()
+        pts = bytes(pts)
+        exp = cref.msm(cid, group, pts, sc, n, False, 0, 16)
+        out = ctypes.create_string_buffer(sz)
+        fn = lib.mlhip_msm_g1 if group == 1 else lib.mlhip_msm_g2
+        _lib.check(fn(cid, pts, sc.tobytes(), 0, n, c, out))
+        if out.raw != exp:
+            print("MISMATCH msm", name, group, n, c, bits, "seed", seed, flush=True)
+            sys.exit(1)
+        done["msm"] += 1
+    else:
+        n = rnd.choice([1, 3, 64, 65, 500])
+        p1 = cref.gen_points(cid, 1, rnd.getrandbits(40), rnd.getrandbits(40), n)
+        p2 = cref.gen_points(cid, 2, rnd.getrandbits(40), rnd.getrandbits(40), n)
+        exp = cref.pairing_batch(cid, p1, p2, n, 16)
+        out = ctypes.create_string_buffer(gtb * n)
+        _lib.check(lib.mlhip_pairing_batch(cid, p1, p2, n, out))
+        if out.raw != exp:
+            print("MISMATCH pairing", name, n, "seed", seed, flush=True)
+            sys.exit(1)
+        done["pairing"] += 1
+    if time.time() - last > 20:
+        last = time.time()
+        print("soak %.0fs: %s" % (time.time() - t0, done), flush=True)
+print("soak OK after %.0fs: %s (seed %d)" % (time.time() - t0, done, seed), flush=True)
