@@ -46,3 +46,57 @@ func TestHipCompat(t *testing.T) {
 	kq, _ := kilic.NewG2FromBytes(q.Bytes())
 	assert.Equal(t, kilic.FExp(kilic.Pairing(kq, kp)).Bytes(), gotGt.Bytes())
 }
+
+// TestHipDevicePaths forces the single-shot pairings onto the device (they default to the CPU driver, see
+// DevicePairing) and checks the additive API: resident bases, the batched pairing, the bulk wire codec.
+func TestHipDevicePaths(t *testing.T) {
+	hip := NewCurve()
+	gurvy := math.Curves[math.BLS12_381_GURVY]
+	rng, err := gurvy.Rand()
+	assert.NoError(t, err)
+
+	DevicePairing = true
+	defer func() { DevicePairing = false }()
+	r := gurvy.NewRandomZr(rng)
+	p := gurvy.GenG1.Mul(r)
+	q := gurvy.GenG2.Mul(r)
+	want := gurvy.FExp(gurvy.Pairing(q, p))
+	got := hip.FExp(hip.Pairing(math.DriverG2(q), math.DriverG1(p)))
+	assert.Equal(t, want.Bytes(), got.Bytes())
+	// the Miller-loop values themselves may differ between implementations; FExp of a CPU Miller loop must agree too
+	DevicePairing = false
+	cpuMiller := hip.Pairing(math.DriverG2(q), math.DriverG1(p))
+	DevicePairing = true
+	assert.Equal(t, want.Bytes(), hip.FExp(cpuMiller).Bytes())
+
+	const n = 64
+	g1s := make([]driver.G1, n)
+	g2s := make([]driver.G2, n)
+	zrs := make([]driver.Zr, n)
+	for i := 0; i < n; i++ {
+		s := gurvy.NewRandomZr(rng)
+		g1s[i] = math.DriverG1(gurvy.GenG1.Mul(s))
+		g2s[i] = math.DriverG2(gurvy.GenG2.Mul(s))
+		zrs[i] = math.DriverZr(gurvy.NewRandomZr(rng))
+	}
+	batch := hip.PairingBatch(g2s, g1s)
+	for i := 0; i < n; i++ {
+		assert.Equal(t, hip.FExp(hip.Pairing(g2s[i], g1s[i])).Bytes(), batch[i].Bytes())
+	}
+
+	bases := hip.NewBases(g1s)
+	defer bases.Close()
+	assert.Equal(t, hip.Curve.MultiScalarMul(g1s, zrs).Bytes(), bases.MultiScalarMul(zrs).Bytes())
+	assert.Equal(t, hip.Curve.MultiScalarMul(g1s[:7], zrs[:7]).Bytes(), bases.MultiScalarMul(zrs[:7]).Bytes())
+
+	wire := hip.G1sCompressed(g1s)
+	for i := 0; i < n; i++ {
+		assert.Equal(t, g1s[i].Compressed(), wire[i*48:(i+1)*48])
+	}
+	back := hip.NewG1sFromCompressed(wire)
+	for i := 0; i < n; i++ {
+		assert.True(t, back[i].Equals(g1s[i]))
+	}
+	wire[5] ^= 1 // almost surely off the curve or out of the subgroup now
+	assert.Panics(t, func() { hip.NewG1sFromCompressed(wire) })
+}
