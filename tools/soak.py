@@ -33,7 +33,7 @@ while time.time() - t0 < budget:
     if rnd.random() < 0.8:
         group = 2 if rnd.random() < 0.25 else 1
         sz = g1b if group == 1 else g2b
-        n = rnd.choice([1, 2, 5, 33, 100, 257, 1000, 1025, 3000, 5000, 20000, 70000]) if rnd.random() < 0.7 else rnd.randrange(1, 40000)
+        n = rnd.choice([1, 2, 5, 33, 100, 257, 1000, 1025, 3000, 5000, 20000, 70000, 300000]) if rnd.random() < 0.7 else rnd.randrange(1, 40000)
         if group == 2:
             n = min(n, 8000)
         c = rnd.choice([0, 4, 6, 8, 9, 12, 13, 15, 16])
