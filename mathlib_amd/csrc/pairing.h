@@ -222,7 +222,7 @@ struct CycloComp {
 };
 
 template <class C, class E2>
-MLHIP_HD_NOINLINE void cyclo_sqr_compressed(CycloComp<C, E2>& k) {
+MLHIP_HD void cyclo_sqr_compressed(CycloComp<C, E2>& k) {
   E2 t2, t3, t4, t5, t7, t8, s;
   fp2_sqr<C>(t2, k.b1);
   fp2_sqr<C>(t3, k.b0);
