@@ -53,7 +53,7 @@ MLHIP_HD void fp2_halve(Fp2<C>& r, const Fp2<C>& a) {
 
 // T <- 2T, line through T,T
 template <class C, class E2>
-MLHIP_HD_NOINLINE void g2_double_step(G2Proj<C, E2>& T, Line<C, E2>& l) {
+MLHIP_HD void g2_double_step(G2Proj<C, E2>& T, Line<C, E2>& l) {
   E2 A, B, Cc, E, F, G, H, I, J, EE, t, b3;
   fp2_mul<C>(A, T.x, T.y);
   fp2_halve<C>(A, A);
