@@ -295,7 +295,7 @@ MLHIP_HD_NOINLINE void fp6_sqr(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
 
 // r = a * (b0 + b1 v)
 template <class C, class E2>
-MLHIP_HD_NOINLINE void fp6_mul_by_01(Fp6<C, E2>& r, const Fp6<C, E2>& a, const E2& b0, const E2& b1) {
+MLHIP_HD void fp6_mul_by_01(Fp6<C, E2>& r, const Fp6<C, E2>& a, const E2& b0, const E2& b1) {
   E2 t0, t1, t2, x0, x1, x2, s0, s1;
   fp2_mul<C>(t0, a.c0, b0);
   fp2_mul<C>(t1, a.c1, b1);
