@@ -235,8 +235,9 @@ MLHIP_HD void fp6_mul_v(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
   r.c0 = t;
 }
 
+// inlined body (callers that keep the Fp6 operands in registers) and the shared out-of-line copy
 template <class C, class E2>
-MLHIP_HD_NOINLINE void fp6_mul(Fp6<C, E2>& r, const Fp6<C, E2>& a, const Fp6<C, E2>& b) {
+MLHIP_HD void fp6_mul_i(Fp6<C, E2>& r, const Fp6<C, E2>& a, const Fp6<C, E2>& b) {
   E2 t0, t1, t2, s0, s1, x0, x1, x2;
   fp2_mul<C>(t0, a.c0, b.c0);
   fp2_mul<C>(t1, a.c1, b.c1);
@@ -267,6 +268,10 @@ MLHIP_HD_NOINLINE void fp6_mul(Fp6<C, E2>& r, const Fp6<C, E2>& a, const Fp6<C, 
   r.c0 = x0;
   r.c1 = x1;
   r.c2 = x2;
+}
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp6_mul(Fp6<C, E2>& r, const Fp6<C, E2>& a, const Fp6<C, E2>& b) {
+  fp6_mul_i<C>(r, a, b);
 }
 
 template <class C, class E2>
@@ -402,11 +407,11 @@ template <class C, class E2>
 MLHIP_HD_NOINLINE void fp12_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   // complex squaring: c0 = (a0+a1)(a0+v a1) - ab - v ab ; c1 = 2ab
   Fp6<C, E2> ab, s0, s1, t;
-  fp6_mul<C>(ab, a.c0, a.c1);
+  fp6_mul_i<C>(ab, a.c0, a.c1);
   fp6_add<C>(s0, a.c0, a.c1);
   fp6_mul_v<C>(t, a.c1);
   fp6_add<C>(s1, a.c0, t);
-  fp6_mul<C>(t, s0, s1);
+  fp6_mul_i<C>(t, s0, s1);
   fp6_sub<C>(t, t, ab);
   fp6_mul_v<C>(s0, ab);
   fp6_sub<C>(r.c0, t, s0);
