@@ -392,11 +392,11 @@ MLHIP_HD void fp12_conj(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
 template <class C, class E2>
 MLHIP_HD_NOINLINE void fp12_mul(Fp12<C, E2>& r, const Fp12<C, E2>& a, const Fp12<C, E2>& b) {
   Fp6<C, E2> t0, t1, s0, s1, x;
-  fp6_mul<C>(t0, a.c0, b.c0);
-  fp6_mul<C>(t1, a.c1, b.c1);
+  fp6_mul_i<C>(t0, a.c0, b.c0);
+  fp6_mul_i<C>(t1, a.c1, b.c1);
   fp6_add<C>(s0, a.c0, a.c1);
   fp6_add<C>(s1, b.c0, b.c1);
-  fp6_mul<C>(x, s0, s1);
+  fp6_mul_i<C>(x, s0, s1);
   fp6_sub<C>(x, x, t0);
   fp6_sub<C>(r.c1, x, t1);
   fp6_mul_v<C>(t1, t1);
