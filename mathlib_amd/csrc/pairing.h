@@ -258,7 +258,7 @@ MLHIP_HD void cyclo_sqr_compressed(CycloComp<C, E2>& k) {
 
 // numerator and denominator of a1 for one compressed value (both formulas, selected by b0 = 0 / b1 = 0)
 template <class C, class E2>
-MLHIP_HD_NOINLINE void cyclo_a1_fraction(E2& num, E2& den, const CycloComp<C, E2>& k) {
+MLHIP_HD void cyclo_a1_fraction(E2& num, E2& den, const CycloComp<C, E2>& k) {
   E2 n1, n2, t, one;
   fp2_sqr<C>(t, k.d1);
   fp2_mul_xi<C>(n1, t);
@@ -280,7 +280,7 @@ MLHIP_HD_NOINLINE void cyclo_a1_fraction(E2& num, E2& den, const CycloComp<C, E2
 }
 
 template <class C, class E2>
-MLHIP_HD_NOINLINE void cyclo_decompress(Fp12<C, E2>& r, const CycloComp<C, E2>& k, const E2& a1) {
+MLHIP_HD void cyclo_decompress(Fp12<C, E2>& r, const CycloComp<C, E2>& k, const E2& a1) {
   E2 t, u, one;
   fp2_sqr<C>(t, a1);
   fp2_dbl<C>(t, t);
