@@ -638,17 +638,28 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
   XYZZ<F> acc;
   xyzz_set_inf<F>(acc);
   bool started = false;
+  constexpr bool kInline = std::is_same<F, FpField<C>>::value;  // G1: the running point stays in registers
+#pragma unroll 1
   for (int w = 63; w >= 0; w--) {
     if (started) {
+#pragma unroll 1
       for (int d = 0; d < 4; d++) {
         XYZZ<F> t;
-        xyzz_dbl_ool<F>(t, acc);
+        if constexpr (kInline)
+          xyzz_dbl<F>(t, acc);
+        else
+          xyzz_dbl_ool<F>(t, acc);
         acc = t;
       }
     }
     uint32_t nib = (s[w >> 3] >> ((w & 7) * 4)) & 15u;
     if (nib) {
-      xyzz_add_ool<F>(acc, tab[nib - 1]);
+      if constexpr (kInline) {
+        const XYZZ<F> q = tab[nib - 1];
+        xyzz_add<F>(acc, q);
+      } else {
+        xyzz_add_ool<F>(acc, tab[nib - 1]);
+      }
       started = true;
     }
   }
