@@ -153,8 +153,8 @@ int mlhip_release_cache(void);
  * same form: compressed (fp bytes each) or uncompressed (2 x fp bytes).  Every point gets a status byte:
  * 0 ok | 1 malformed (flags, coordinate >= p, bad infinity) | 2 not on the curve | 3 not in the r-torsion
  * subgroup; out_affine[i] is (0,0) unless status[i] == 0.  subgroup_check: 0 skips the test (gnark's SetBytes always
- * does it), 1 runs the fastest exact test (BLS12 curves: phi(P) = [-x^2]P for G1, psi(Q) = [x]Q for G2 -- 64-bit
- * ladders, the criteria gnark uses; otherwise the [r]P ladder), 2 forces the plain [r]P ladder (kept for cross-checking). */
+ * does it), 1 runs the fastest exact test (BLS12 curves: phi(P) = [-x^2]P for G1, psi(Q) = [x]Q for G2; BN254 G2:
+ * [x+1]Q + psi([x]Q) + psi^2([x]Q) = psi^3([2x]Q) -- 64-bit ladders, the criteria gnark uses), 2 forces the plain [r]P ladder (kept for cross-checking). */
 int mlhip_g1_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out_affine,
                         unsigned char* status);
 int mlhip_g1_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire);

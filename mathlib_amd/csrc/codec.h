@@ -372,9 +372,55 @@ MLHIP_HD bool g2_in_subgroup_psi(const Affine<Fp2Field<C>>& Q) {
   return fp2_eq<C>(t, S.x) & fp2_eq<C>(u, S.y);
 }
 
+// psi on an XYZZ point of the twist: conjugate every coordinate, scale X and Y
+template <class C>
+MLHIP_HD void g2_psi_xyzz(XYZZ<Fp2Field<C>>& r, const XYZZ<Fp2Field<C>>& a) {
+  Fp2<C> k, t;
+  fp2_conj<C>(t, a.x);
+  fp2_from_const<C>(k, C::PSI_X);
+  fp2_mul<C>(r.x, t, k);
+  fp2_conj<C>(t, a.y);
+  fp2_from_const<C>(k, C::PSI_Y);
+  fp2_mul<C>(r.y, t, k);
+  fp2_conj<C>(r.zz, a.zz);
+  fp2_conj<C>(r.zzz, a.zzz);
+}
+
+// BN254: Q is in G2  <=>  [x+1]Q + psi([x]Q) + psi^2([x]Q) = psi^3([2x]Q)  (the test gnark-crypto uses; M. Scott
+// 2021).  Complete because psi acts as [p] on G2 and the BN parametrisation makes the combination vanish mod r;
+// sound for this curve because, together with psi^2 - [t]psi + [p] = 0, it forces [N]Q = O for the resultant N of
+// the two polynomials, and gcd(N, #E'(Fp2)) = r (asserted when the constants are generated).  One 63-bit ladder.
+template <class C>
+MLHIP_HD bool g2_in_subgroup_bn(const Affine<Fp2Field<C>>& Q) {
+  typedef Fp2Field<C> F;
+  int top = 63;
+  while (!((C::X_ABS >> top) & 1)) top--;
+  XYZZ<F> a, b, c, res, d;
+  xyzz_from_affine<F>(a, Q);  // [x] Q
+  for (int i = top - 1; i >= 0; i--) {
+    xyzz_dbl<F>(d, a);
+    a = d;
+    if ((C::X_ABS >> i) & 1) xyzz_madd<F>(a, Q, false);
+  }
+  g2_psi_xyzz<C>(b, a);         // psi([x]Q)
+  xyzz_madd<F>(a, Q, false);    // [x+1]Q
+  g2_psi_xyzz<C>(res, b);       // psi^2([x]Q)
+  c = res;
+  xyzz_add<F>(c, b);
+  xyzz_add<F>(c, a);            // lhs
+  g2_psi_xyzz<C>(d, res);       // psi^3([x]Q)
+  xyzz_dbl<F>(res, d);          // psi^3([2x]Q)
+  fp2_neg<C>(c.y, c.y);
+  xyzz_add<F>(res, c);          // rhs - lhs
+  return xyzz_is_inf<F>(res);
+}
+
 template <class C>
 MLHIP_HD bool g2_in_subgroup(const Affine<Fp2Field<C>>& Q, int mode) {
-  if (!C::IS_BN && mode != 2) return g2_in_subgroup_psi<C>(Q);
+  if (mode != 2) {
+    if (C::IS_BN) return g2_in_subgroup_bn<C>(Q);
+    return g2_in_subgroup_psi<C>(Q);
+  }
   return g2_in_subgroup_ladder<C>(Q);
 }
 

@@ -510,7 +510,7 @@ def test_g1_subgroup_test_by_endomorphism(hostmath, name):
         assert got[1] == got[2] == want, (name, P)
 
 
-@pytest.mark.parametrize("name", ["BLS12-381", "BLS12-377"])
+@pytest.mark.parametrize("name", ["BLS12-381", "BLS12-377", "BN254"])
 def test_g2_subgroup_test_by_psi(hostmath, name):
     """codec.h g2_in_subgroup_psi (psi(Q) = [x]Q) agrees with the plain [r]Q ladder on r-torsion points, random twist
     points, points of small prime order dividing the G2 cofactor, and sums of the two kinds."""
