@@ -276,7 +276,14 @@ static __global__ void __launch_bounds__(256) k_fine_sort(const uint32_t* __rest
   const uint32_t idx_mask = (1u << idx_bits) - 1u;
   hist[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t k = threadIdx.x; k < cnt; k += 256) atomicAdd(&hist[tmp[begin + k] >> (idx_bits + 1)], 1u);
+  for (uint32_t k = threadIdx.x; k < cnt; k += 1024) {  // four loads in flight per thread
+    uint32_t e[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[j] = k + 256u * j < cnt ? tmp[begin + k + 256u * j] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (k + 256u * j < cnt) atomicAdd(&hist[e[j] >> (idx_bits + 1)], 1u);
+  }
   __syncthreads();
   // exclusive scan of the F <= 256 fine counts
   uint32_t mine = threadIdx.x < F ? hist[threadIdx.x] : 0u;
@@ -299,11 +306,21 @@ static __global__ void __launch_bounds__(256) k_fine_sort(const uint32_t* __rest
     offsets[g] = begin + excl;
   }
   __syncthreads();
-  for (uint32_t k = threadIdx.x; k < cnt; k += 256) {
-    uint32_t e = tmp[begin + k];
-    uint32_t f = e >> (idx_bits + 1);
-    uint32_t pos = begin + fo[f] + atomicAdd(&hist[f], 1u);
-    sorted[pos] = (e & idx_mask) | (((e >> idx_bits) & 1u) << 31);
+  for (uint32_t k = threadIdx.x; k < cnt; k += 1024) {  // four loads, then four ranks, then four stores in flight
+    uint32_t e[4], pos[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[j] = k + 256u * j < cnt ? tmp[begin + k + 256u * j] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      pos[j] = 0xFFFFFFFFu;
+      if (k + 256u * j < cnt) {
+        uint32_t f = e[j] >> (idx_bits + 1);
+        pos[j] = begin + fo[f] + atomicAdd(&hist[f], 1u);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (pos[j] != 0xFFFFFFFFu) sorted[pos[j]] = (e[j] & idx_mask) | (((e[j] >> idx_bits) & 1u) << 31);
   }
 }
 
