@@ -266,11 +266,12 @@ def main() -> None:
             "matches_gpu_result": bool(ref == res),
         }
         if not args.no_pairing:
-            ns = 512
+            ns = 2048
             t1 = time.perf_counter()
-            cref.pairing_batch(CURVE, hp[: ns * g1b], q[: ns * g2b].cpu().numpy(), ns, threads)
+            cpu_gt = cref.pairing_batch(CURVE, hp[: ns * g1b], q[: ns * g2b].cpu().numpy(), ns, threads)
             dtp = time.perf_counter() - t1
             cpu_baseline["pairings_per_s"] = ns / dtp
+            cpu_baseline["pairings_match_gpu_result"] = bool(cpu_gt == bytes(gt[: ns * gtb].cpu().numpy().tobytes()))
             cpu_baseline["pairing_sample"] = "%d of the 65 536 pairs, %d pthreads, %.2f s" % (ns, threads, dtp)
 
     if rank == 0:
