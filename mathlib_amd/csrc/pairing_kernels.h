@@ -88,7 +88,13 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp(const Affine<FpF
   const size_t i = t >> 1;  // both lanes of a pair share i, so this exit is pair-uniform
   if (i >= n) return;
   typedef Fp2L<C> E2;
-  Fp12<C, E2> f, r;
+  // the Miller accumulator / final-exponentiation input lives in LDS (one padded slot per lane, 18 KB per block:
+  // eight blocks fill a CU's 160 KB) instead of scratch -- the most re-read Fp12 of the kernel; the out-of-line
+  // tower functions reach it through flat addresses.  Miller loop -2.6 %.
+  constexpr int SLOT = sizeof(Fp12<C, E2>) / 4 + 1;  // odd word stride: conflict-free
+  __shared__ uint32_t f_slots[64 * SLOT];
+  Fp12<C, E2>& f = *reinterpret_cast<Fp12<C, E2>*>(&f_slots[threadIdx.x * SLOT]);
+  Fp12<C, E2> r;
   if (WHAT == 1) {
     lp_load_gt<C>(f, in, i);
   } else {
