@@ -26,6 +26,7 @@ struct mlhip_msm_plan {
   int sort_low = 0, sort_idx_bits = 0;  // two-level sort: fine bits per coarse bin (0 = legacy path)
   uint32_t sort_nb = 0;
   uint32_t *d_coarse_count = nullptr, *d_coarse_cursor = nullptr, *d_coarse_off = nullptr;
+  uint16_t* d_blockhist = nullptr;  // per-block coarse histograms (k_coarse_hist -> k_coarse_scatter)
   uint32_t *d_order = nullptr, *d_hist = nullptr, *d_tilesums = nullptr;
   uint32_t *d_counts = nullptr, *d_cursor = nullptr, *d_bigcount = nullptr;  // views into d_zero
   size_t zero_bytes = 0;

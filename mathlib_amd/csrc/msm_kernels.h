@@ -137,7 +137,8 @@ constexpr int SORT_TILE = MLHIP_SORT_TILE;  // scalars per block in the coarse p
 
 template <class C>
 __global__ void __launch_bounds__(256) k_coarse_hist(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
-                                                     int low, uint32_t NB, uint32_t* __restrict__ coarse_count) {
+                                                     int low, uint32_t NB, uint32_t* __restrict__ coarse_count,
+                                                     uint16_t* __restrict__ blockhist) {
   extern __shared__ uint32_t lds_u32[];
   uint32_t* hist = lds_u32;
   for (uint32_t b = threadIdx.x; b < NB; b += 256) hist[b] = 0;
@@ -173,8 +174,11 @@ __global__ void __launch_bounds__(256) k_coarse_hist(const uint32_t* __restrict_
     }
   }
   __syncthreads();
+  // the block's histogram also goes to memory (<= SORT_TILE per bin, one window each): k_coarse_scatter reloads it instead
+  // of recomputing every digit a second time
   for (uint32_t b = threadIdx.x; b < NB; b += 256) {
     uint32_t h = hist[b];
+    blockhist[(size_t)blockIdx.x * NB + b] = (uint16_t)h;
     if (h) atomicAdd(&coarse_count[b], h);
   }
 }
@@ -183,42 +187,15 @@ template <class C>
 __global__ void __launch_bounds__(256) k_coarse_scatter(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
                                                         int low, int idx_bits, uint32_t NB,
                                                         const uint32_t* __restrict__ coarse_off,
-                                                        uint32_t* __restrict__ coarse_cursor, uint32_t* __restrict__ tmp) {
+                                                        uint32_t* __restrict__ coarse_cursor, uint32_t* __restrict__ tmp,
+                                                        const uint16_t* __restrict__ blockhist) {
   extern __shared__ uint32_t lds_u32[];
   uint32_t* hist = lds_u32;       // per-block count, then running rank
   uint32_t* base = lds_u32 + NB;  // global position of this block's slice of each bin
-  for (uint32_t b = threadIdx.x; b < NB; b += 256) hist[b] = 0;
-  __syncthreads();
   const uint32_t cb_shift = (uint32_t)(c - 1 - low);
   const uint32_t half = 1u << (c - 1);
-  // pass 1: count
-  for (int k = 0; k < SORT_TILE / 256; k++) {
-    size_t i = (size_t)blockIdx.x * SORT_TILE + (size_t)k * 256 + threadIdx.x;
-    if (i >= n) break;
-    uint32_t s[8];
-    fr_canonical<C>(s, scalars + 8 * i, mont != 0);
-    uint32_t carry = 0;
-    for (int w = 0; w < W; w++) {
-      int bit = w * c;
-      uint32_t v = 0;
-      if (bit < 256) {
-        int word = bit >> 5, sh = bit & 31;
-        uint64_t two = s[word];
-        if (word + 1 < 8) two |= (uint64_t)s[word + 1] << 32;
-        v = (uint32_t)((two >> sh) & ((1u << c) - 1));
-      }
-      v += carry;
-      uint32_t mag;
-      if (v > half) {
-        mag = (1u << c) - v;
-        carry = 1;
-      } else {
-        mag = v;
-        carry = 0;
-      }
-      if (mag) atomicAdd(&hist[((uint32_t)w << cb_shift) + ((mag - 1) >> low)], 1u);
-    }
-  }
+  // pass 1: this block's counts, computed by k_coarse_hist
+  for (uint32_t b = threadIdx.x; b < NB; b += 256) hist[b] = blockhist[(size_t)blockIdx.x * NB + b];
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < NB; b += 256) {
     uint32_t h = hist[b];
@@ -966,6 +943,11 @@ int plan_alloc(mlhip_msm_plan* p) {
   p->d_coarse_count = p->d_zero + 2 * nbuckets + 4;
   p->d_coarse_cursor = p->d_coarse_count + p->sort_nb;
   HIPCHK(hipMalloc(&p->d_coarse_off, ((size_t)p->sort_nb + 1) * 4));
+  if (p->sort_nb) {
+    static_assert(SORT_TILE < 65536, "a block puts at most one entry per scalar into a coarse bin: the count fits 16 bits");
+    const size_t blocks = (p->max_n + SORT_TILE - 1) / SORT_TILE;
+    HIPCHK(hipMalloc(&p->d_blockhist, blocks * p->sort_nb * sizeof(uint16_t)));
+  }
   HIPCHK(hipMalloc(&p->d_offsets, nbuckets * 4));
   HIPCHK(hipMalloc(&p->d_biglist, nbuckets * 4));
   HIPCHK(hipMalloc(&p->d_order, nbuckets * 4));
@@ -1065,12 +1047,12 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
       const unsigned blocks = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
       const uint32_t NB = p->sort_nb;
       k_coarse_hist<C><<<dim3(blocks), dim3(256), NB * 4, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low, NB,
-                                                              p->d_coarse_count);
+                                                              p->d_coarse_count, p->d_blockhist);
       if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
       launch_scan(p->d_coarse_count, p->d_coarse_off, p->d_tilesums, NB, st);
       k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low,
                                                                  p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
-                                                                 p->d_digits);
+                                                                 p->d_digits, p->d_blockhist);
       k_fine_sort<<<dim3(NB), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->c, p->sort_low,
                                                  p->sort_idx_bits, p->d_counts, p->d_offsets, p->d_sorted);
     } else {
