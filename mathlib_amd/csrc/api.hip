@@ -434,6 +434,7 @@ int mlhip_bases_create(int curve, int group, const void* points, size_t n, int w
     mlhip_bases_destroy(b);
     return rc;
   }
+  b->plan->points_static = true;  // the buffer is ours and never rewritten: convert it on the first MSM only
   *out = b;
   return 0;
 }

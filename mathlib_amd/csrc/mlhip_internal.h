@@ -42,6 +42,10 @@ struct mlhip_msm_plan {
   // host-buffer entry points: points still in host memory, uploaded on `aux` beside the sort (cleared per launch)
   const void* upload_src = nullptr;
   size_t upload_bytes = 0;
+  // resident bases (mlhip_bases_*): the library owns the point buffer, so its carry-free copy is made once
+  bool points_static = false;
+  const void* conv_src = nullptr;
+  size_t conv_n = 0;
   bool pending = false;
   size_t pending_n = 0;
   float ms[6] = {0, 0, 0, 0, 0, 0};

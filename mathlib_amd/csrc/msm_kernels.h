@@ -1079,7 +1079,11 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
       launch_scan(p->d_hist, p->d_hist, p->d_tilesums, (size_t)ORDER_BINS * nblk, st);
       k_order_place<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist, p->d_order);
     }
-    if (p->d_points28) {
+    // resident bases: the carry-free copy of the first conv_n points of this very buffer is already there
+    const bool conv_cached = p->points_static && p->conv_src == d_points && n <= p->conv_n && !p->upload_src;
+    if (p->d_points28 && conv_cached) {
+      HIPCHK(hipEventRecord(p->ev_join, st));  // nothing to wait for
+    } else if (p->d_points28) {
       HIPCHK(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
       if (p->upload_src) {  // host-buffer call: the upload of the points rides the same stream, ahead of the conversion
         HIPCHK(hipMemcpyAsync(const_cast<void*>(d_points), p->upload_src, p->upload_bytes, hipMemcpyHostToDevice, p->aux));
@@ -1094,6 +1098,8 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
                                                                                      (Affine28<C>*)p->d_points28);
       }
       HIPCHK(hipEventRecord(p->ev_join, p->aux));
+      p->conv_src = d_points;
+      p->conv_n = n;
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[2], st));
     constexpr bool kLanePairs = std::is_same<F, Fp2Field<C>>::value;  // G2: two lanes per bucket
