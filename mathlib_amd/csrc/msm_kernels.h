@@ -958,6 +958,10 @@ int plan_alloc(mlhip_msm_plan* p) {
     const size_t tiles = (std::max(nbuckets, hist_n) + SCAN_TILE - 1) / SCAN_TILE;
     HIPCHK(hipMalloc(&p->d_tilesums, (tiles + 1) * 4));
   }
+  if (const char* e = getenv("MLHIP_ACC_BLOCK")) {
+    const int v = atoi(e);
+    if (v == 64 || v == 128 || v == 256) p->acc_block = v;
+  }
   {
     const char* one_lane = getenv("MLHIP_REDUCE_ONE_LANE");  // =1: the one-point-per-lane reduction kernels
     p->reduce_one_lane = one_lane && one_lane[0] == '1';
@@ -1108,23 +1112,23 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
       if constexpr (C::BETA == -1) {
         if (p->d_points28) {
           HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
-          k_accumulate28_lp<C><<<dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+          k_accumulate28_lp<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
               (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
               big_threshold, p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
           done28 = true;
         }
       }
       if (!done28)
-        k_accumulate_lp<C><<<dim3((unsigned)((2 * nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+        k_accumulate_lp<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
             (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
             p->d_bigcount, (X*)p->d_buckets);
     } else if (p->d_points28) {
       HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
-      k_accumulate28<C><<<dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+      k_accumulate28<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
           (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
           p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
     } else {
-      k_accumulate<F><<<dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+      k_accumulate<F><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
           (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
           p->d_bigcount, (X*)p->d_buckets);
     }
