@@ -958,6 +958,10 @@ int plan_alloc(mlhip_msm_plan* p) {
     const size_t tiles = (std::max(nbuckets, hist_n) + SCAN_TILE - 1) / SCAN_TILE;
     HIPCHK(hipMalloc(&p->d_tilesums, (tiles + 1) * 4));
   }
+  if (const char* e = getenv("MLHIP_RED_BLOCK")) {
+    const int v = atoi(e);
+    if (v == 64 || v == 128 || v == 256) p->red_block = v;
+  }
   if (const char* e = getenv("MLHIP_ACC_BLOCK")) {
     const int v = atoi(e);
     if (v == 64 || v == 128 || v == 256) p->acc_block = v;
@@ -1156,7 +1160,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
               (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
         } else {
           // one point per quad of lanes: a group addition is 4 rounds of one multiplication instead of 14 in a row
-          k_chunks_q<C><<<dim3((unsigned)((4 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+          k_chunks_q<C><<<dim3((unsigned)((4 * n_chunks + p->red_block - 1) / p->red_block)), dim3(p->red_block), 0, st>>>((const X*)p->d_buckets, n_chunks,
                                                                                            p->L, (X*)p->d_A, (X*)p->d_W0);
           constexpr int RB = 512;  // 128 quads, 24 KB of LDS per block
           k_masked_sums_q<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
