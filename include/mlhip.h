@@ -137,7 +137,8 @@ int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stri
 /* ---- resident bases (upload-once point table, only the scalars travel per call) ----------
  * For callers that cannot hold device pointers themselves (the Go shim): the points are uploaded once, every
  * mlhip_bases_msm() uploads n x 32 bytes of scalars and returns sum_i [s_i] P_i over the first n bases (n <= the
- * count given at creation).  One MSM at a time per handle; handles are independent of each other and of threads. */
+ * count given at creation).  Calls on one handle from several threads are serialized inside the library (one MSM at a
+ * time per handle); handles are independent of each other. */
 typedef struct mlhip_bases mlhip_bases;
 int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** bases);
 int mlhip_bases_msm(mlhip_bases* bases, const void* scalars, int scalars_mont, size_t n, void* out_affine);

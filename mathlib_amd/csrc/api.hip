@@ -400,6 +400,7 @@ struct mlhip_bases {
   void *d_pts = nullptr, *d_sc = nullptr;
   size_t n = 0, ptsz = 0;
   int device = 0;
+  std::mutex mu;  // one MSM at a time per handle: the plan and the scalar buffer are shared state
 };
 
 int mlhip_bases_destroy(mlhip_bases* b) {
@@ -448,6 +449,7 @@ int mlhip_bases_msm(mlhip_bases* b, const void* scalars, int scalars_mont, size_
   }
   if (!scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
   if (hipSetDevice(b->device) != hipSuccess) return mlhip_rt::fail(MLHIP_EHIP, "hipSetDevice failed");
+  std::lock_guard<std::mutex> lk(b->mu);
   if (hipMemcpy(b->d_sc, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess)
     return mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy of MSM scalars failed");
   return mlhip_msm_run(b->plan, b->d_pts, b->d_sc, scalars_mont, n, nullptr, out_affine, nullptr);

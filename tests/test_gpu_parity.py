@@ -535,3 +535,34 @@ def test_concurrent_callers(lib, mlhip):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+@pytest.mark.gpu
+def test_bases_shared_by_threads(lib, mlhip):
+    """One resident-bases handle used from six threads at once (a Go prover shares its SRS between goroutines):
+    the library serializes the calls; every result equals the golden."""
+    import threading
+
+    curve = "BLS12-381"
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    fpb, g1b, _, _ = mlhip.sizes(cid)
+    pts, scs, exp = load_msm1000(curve, fpb)
+    handle = ctypes.c_void_p()
+    assert lib.mlhip_bases_create(cid, 1, pts, 1000, 0, ctypes.byref(handle)) == 0
+    errors = []
+
+    def worker(tid):
+        for rep in range(6):
+            out = ctypes.create_string_buffer(g1b)
+            rc = lib.mlhip_bases_msm(handle, scs, 0, 1000, out)
+            if rc != 0 or out.raw != exp:
+                errors.append((tid, rep, rc))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert lib.mlhip_bases_destroy(handle) == 0
+    assert not errors, errors[:5]
