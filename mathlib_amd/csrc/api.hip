@@ -215,6 +215,30 @@ void pool_release(PoolEntry* e, bool failed) {
   e->busy = false;
 }
 
+// Number of segments a host-buffer MSM is streamed in (1 = one upload, one pass).  Measured on MI355X / PCIe gen5
+// (tools/perf_hostapi.py): from 2^19 points the transfer is worth hiding; MLHIP_STREAM_SEGMENTS overrides (0/1 = off).
+int stream_segments(int group, size_t n, const mlhip_msm_plan* plan) {
+  if (group != MLHIP_GROUP_G1 || !plan->d_points28 || !plan->aux) return 1;
+  if (const char* e = getenv("MLHIP_STREAM_SEGMENTS")) {
+    int v = atoi(e);
+    if (v < 2) return 1;
+    if (v > MLHIP_MAX_SEGMENTS) v = MLHIP_MAX_SEGMENTS;
+    return n >= (size_t)v ? v : 1;
+  }
+  // segments of 2^18 pairs: at 2^20 the call drops from 5.9 to 4.5 ms, at 2^22 from 21.9 to 12.8 ms (the device-only time)
+  const size_t k = n >> 18;
+  return k < 2 ? 1 : (k > MLHIP_MAX_SEGMENTS ? MLHIP_MAX_SEGMENTS : (int)k);
+}
+
+int tu_plan_stream(mlhip_msm_plan* p, void* d_pts, void* d_sc, const void* points, const void* scalars, int mont, size_t n,
+                   int segments) {
+  switch (p->curve) {
+    case MLHIP_CURVE_BN254: return mlhip_tu_plan_stream_Bn254(p, d_pts, d_sc, points, scalars, mont, n, segments, nullptr);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_plan_stream_Bls381(p, d_pts, d_sc, points, scalars, mont, n, segments, nullptr);
+    default: return mlhip_tu_plan_stream_Bls377(p, d_pts, d_sc, points, scalars, mont, n, segments, nullptr);
+  }
+}
+
 int msm_host_buffers(int curve, int group, const void* points, const void* scalars, int mont, size_t n, int window_c,
                      void* out) {
   Sizes sz;
@@ -233,7 +257,14 @@ int msm_host_buffers(int curve, int group, const void* points, const void* scala
   if (rc) return rc;
   PoolEntry* e = pool_acquire(curve, group, window_c, n, ptsz, rc);
   if (!e) return rc;
+  const int segments = stream_segments(group, n, e->plan);
   do {
+    if (segments > 1) {
+      // large G1 MSMs: upload, sort and accumulate segment by segment, so the PCIe transfer hides under the kernels
+      rc = tu_plan_stream(e->plan, e->d_pts, e->d_sc, points, scalars, mont, n, segments);
+      if (!rc) rc = mlhip_msm_finish(e->plan, out, nullptr);
+      break;
+    }
     // scalars first (the sort needs only them); the points follow on the plan's auxiliary stream while the sort runs
     if (hipMemcpy(e->d_sc, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess) {
       rc = mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy of MSM scalars failed");
@@ -335,7 +366,7 @@ int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->device);
   void* ptrs[] = {p->d_digits, p->d_sorted, p->d_zero, p->d_offsets, p->d_biglist, p->d_buckets, p->d_A, p->d_W0, p->d_out,
-                  p->d_order, p->d_hist, p->d_tilesums, p->d_coarse_off, p->d_points28, p->d_blockhist};
+                  p->d_order, p->d_hist, p->d_tilesums, p->d_coarse_off, p->d_points28, p->d_blockhist, p->d_state28};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (p->h_out) (void)hipHostFree(p->h_out);
@@ -344,6 +375,8 @@ int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
   if (p->done) (void)hipEventDestroy(p->done);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  for (hipEvent_t e : p->ev_seg)
+    if (e) (void)hipEventDestroy(e);
   if (p->aux) (void)hipStreamDestroy(p->aux);
   delete p;
   return 0;
@@ -450,6 +483,15 @@ int mlhip_bases_msm(mlhip_bases* b, const void* scalars, int scalars_mont, size_
   if (!scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
   if (hipSetDevice(b->device) != hipSuccess) return mlhip_rt::fail(MLHIP_EHIP, "hipSetDevice failed");
   std::lock_guard<std::mutex> lk(b->mu);
+  {
+    // after the first MSM (which leaves the converted copy of the bases) large calls stream their scalars
+    const mlhip_msm_plan* p = b->plan;
+    const int segments = stream_segments(p->group, n, p);
+    if (segments > 1 && p->points_static && p->conv_src == b->d_pts && n <= p->conv_n) {
+      int rc = tu_plan_stream(b->plan, b->d_pts, b->d_sc, nullptr, scalars, scalars_mont, n, segments);
+      return rc ? rc : mlhip_msm_finish(b->plan, out_affine, nullptr);
+    }
+  }
   if (hipMemcpy(b->d_sc, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess)
     return mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy of MSM scalars failed");
   return mlhip_msm_run(b->plan, b->d_pts, b->d_sc, scalars_mont, n, nullptr, out_affine, nullptr);

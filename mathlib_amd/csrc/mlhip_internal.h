@@ -17,6 +17,8 @@ int fail(int code, const std::string& msg);
     if (e_ != hipSuccess) return mlhip_rt::fail(MLHIP_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+#define MLHIP_MAX_SEGMENTS 16
+
 struct mlhip_msm_plan {
   int curve, group, device, c, W, L, lgL, nb, nsel;
   size_t max_n;
@@ -48,6 +50,9 @@ struct mlhip_msm_plan {
   bool points_static = false;
   const void* conv_src = nullptr;
   size_t conv_n = 0;
+  // streamed host-buffer MSMs (plan_stream): raw carry-free bucket accumulators between segments, one event per segment
+  void* d_state28 = nullptr;
+  hipEvent_t ev_seg[MLHIP_MAX_SEGMENTS] = {};
   bool pending = false;
   size_t pending_n = 0;
   float ms[6] = {0, 0, 0, 0, 0, 0};
@@ -60,6 +65,8 @@ struct mlhip_msm_plan {
   int mlhip_tu_plan_launch_##NAME(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont,        \
                                   size_t n, hipStream_t st);                                                       \
   int mlhip_tu_plan_finish_##NAME(mlhip_msm_plan* p, void* out_affine, void* out_xyzz);                            \
+  int mlhip_tu_plan_stream_##NAME(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points,         \
+                                  const void* h_scalars, int mont, size_t n, int segments, hipStream_t st);         \
   int mlhip_tu_pairing_##NAME(int what, const void* d_g1, const void* d_g2, size_t ppp, size_t n, const void* d_in, \
                               void* d_out, hipStream_t st);                                                         \
   int mlhip_tu_fp_mul_##NAME(const void* d_a, const void* d_b, size_t n, int repeat, void* d_out, hipStream_t st);   \

@@ -482,6 +482,120 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate_big(const Affine<F>* __res
   }
 }
 
+// ---- segmented accumulation (host-buffer MSMs streamed over PCIe, plan_stream below) --------------------------
+// The n pairs arrive in K segments; every segment is sorted by itself and added INTO the bucket sums of the segments
+// before it, so the upload of segment s+1 runs under the kernels of segment s and the reduction runs once.  Between
+// segments a bucket is kept as its raw carry-free accumulator (4 normalized coordinates; ZZ = 0 limbs <=> infinity),
+// which makes the chain of additions identical to the unsegmented kernel's; the last segment writes the boundary form.
+#define MLHIP_SEG_FIRST 1
+#define MLHIP_SEG_LAST 2
+
+template <class C>
+__global__ void __launch_bounds__(256) k_accumulate28_seg(const Affine28<C>* __restrict__ points,
+                                                          const uint32_t* __restrict__ sorted,
+                                                          const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                          const uint32_t* __restrict__ order, uint32_t big_threshold,
+                                                          uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
+                                                          XYZZ28<C>* __restrict__ state, int flags,
+                                                          XYZZ<FpField<C>>* __restrict__ buckets) {
+  size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n_buckets) return;
+  const size_t g = order[tid];
+  const uint32_t cnt = counts[g];
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  if (cnt > big_threshold) {  // k_accumulate_big_seg adds this segment's entries to the bucket's state
+    uint32_t pos = atomicAdd(big_count, 1u);
+    big_list[pos] = (uint32_t)g;
+    return;
+  }
+  if (cnt == 0 && !first && !last) return;  // nothing to add, nothing to convert
+  XYZZ28<C> acc;
+  bool inf = true;
+  if (!first) {
+    acc = state[g];
+    inf = fp28_all_zero<C>(acc.zz);
+  }
+  const size_t begin = offsets[g], end = begin + cnt;
+  if (cnt != 0) {
+    uint32_t e = sorted[begin];
+    Affine28<C> p = points[e & 0x7fffffffu];
+    for (size_t k = begin; k < end; k++) {
+      uint32_t en = e;
+      Affine28<C> pn = p;
+      if (k + 1 < end) {
+        en = sorted[k + 1];
+        pn = points[en & 0x7fffffffu];
+      }
+      xyzz28_madd<C>(acc, inf, p, (e >> 31) != 0);
+      e = en;
+      p = pn;
+    }
+  }
+  if (last) {
+    XYZZ<FpField<C>> r;
+    xyzz28_to<C>(r, acc, inf);
+    buckets[g] = r;
+  } else {
+    if (inf) {
+#pragma unroll
+      for (int i = 0; i < C::N28; i++) acc.x.l[i] = acc.y.l[i] = acc.zz.l[i] = acc.zzz.l[i] = 0;
+    }
+    state[g] = acc;
+  }
+}
+
+// the long buckets of a segment: workgroup sum in the boundary form, then state <- state + sum (thread 0)
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg(const Affine<FpField<C>>* __restrict__ points,
+                                                              const uint32_t* __restrict__ sorted,
+                                                              const uint32_t* __restrict__ offsets,
+                                                              const uint32_t* __restrict__ counts,
+                                                              const uint32_t* __restrict__ big_list,
+                                                              const uint32_t* __restrict__ big_count,
+                                                              XYZZ28<C>* __restrict__ state, int flags,
+                                                              XYZZ<FpField<C>>* __restrict__ buckets) {
+  typedef FpField<C> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  const uint32_t nbig = *big_count;
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    uint32_t g = big_list[bi];
+    size_t begin = offsets[g];
+    size_t end = begin + counts[g];
+    XYZZ<F> acc;
+    xyzz_set_inf<F>(acc);
+    msm_accumulate_range<F>(acc, points, sorted, begin + threadIdx.x, end, BLOCK);
+    block_tree_sum<F, BLOCK>(sh, acc);
+    if (threadIdx.x == 0) {
+      XYZZ<F> sum = sh[0];
+      if (!first) {
+        XYZZ28<C> s28 = state[g];
+        XYZZ<F> prev;
+        xyzz28_to<C>(prev, s28, fp28_all_zero<C>(s28.zz));
+        xyzz_add_ool<F>(sum, prev);
+      }
+      if (last) {
+        buckets[g] = sum;
+      } else {
+        XYZZ28<C> s28;
+        if (xyzz_is_inf<F>(sum)) {
+#pragma unroll
+          for (int i = 0; i < C::N28; i++) s28.x.l[i] = s28.y.l[i] = s28.zz.l[i] = s28.zzz.l[i] = 0;
+        } else {
+          fp28_from_fp<C>(s28.x, sum.x);
+          fp28_from_fp<C>(s28.y, sum.y);
+          fp28_from_fp<C>(s28.zz, sum.zz);
+          fp28_from_fp<C>(s28.zzz, sum.zzz);
+        }
+        state[g] = s28;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) k_chunks(const XYZZ<F>* __restrict__ buckets, size_t n_chunks, int l_eff,
                                                 XYZZ<F>* __restrict__ A, XYZZ<F>* __restrict__ W0) {
@@ -1026,6 +1140,83 @@ void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
   }
 }
 
+// digits -> entries sorted by (window, bucket) in d_sorted / d_offsets / d_counts, and the bucket order by population
+template <class C>
+int launch_sort(mlhip_msm_plan* p, const void* d_scalars, int mont, size_t n, hipStream_t st, bool prof) {
+  const size_t nbuckets = (size_t)p->W * p->M;
+  if (p->sort_low > 0) {
+    // two-level LDS counting sort (no per-key global atomics)
+    const unsigned blocks = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+    const uint32_t NB = p->sort_nb;
+    k_coarse_hist<C><<<dim3(blocks), dim3(256), NB * 4, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low, NB,
+                                                            p->d_coarse_count, p->d_blockhist);
+    if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
+    launch_scan(p->d_coarse_count, p->d_coarse_off, p->d_tilesums, NB, st);
+    k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low,
+                                                               p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
+                                                               p->d_digits, p->d_blockhist);
+    k_fine_sort<<<dim3(NB), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->c, p->sort_low,
+                                               p->sort_idx_bits, p->d_counts, p->d_offsets, p->d_sorted);
+  } else {
+    // legacy path (very large n or MLHIP_LEGACY_SORT=1): digits array + global-atomic histogram / scatter
+    {
+      size_t blocks = (n + 255) / 256;
+      if (blocks > 65536) blocks = 65536;
+      k_digits<C><<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->M,
+                                                                 p->d_digits, p->d_counts);
+    }
+    if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
+    launch_scan(p->d_counts, p->d_offsets, p->d_tilesums, nbuckets, st);
+    {
+      size_t total_e = (size_t)p->W * n;
+      size_t blocks = (total_e + 255) / 256;
+      if (blocks > 262144) blocks = 262144;
+      k_scatter<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(p->d_digits, n, p->W, p->M, p->d_offsets, p->d_cursor,
+                                                               p->d_sorted);
+    }
+  }
+  {
+    const unsigned nblk = (unsigned)((nbuckets + 255) / 256);
+    k_order_hist<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist);
+    launch_scan(p->d_hist, p->d_hist, p->d_tilesums, (size_t)ORDER_BINS * nblk, st);
+    k_order_place<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist, p->d_order);
+  }
+  return 0;
+}
+
+// bucket sums in d_buckets -> W x nsel partial sums in d_out (two levels: chunks of L buckets, bit-masked sums)
+template <class C, class F>
+int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
+  typedef XYZZ<F> X;
+  constexpr bool kLanePairs = std::is_same<F, Fp2Field<C>>::value;  // G2: two lanes per bucket
+  {
+    size_t n_chunks = (size_t)p->W * p->T;
+    if constexpr (kLanePairs) {
+      k_chunks_lp<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                        p->L, (X*)p->d_A, (X*)p->d_W0);
+      constexpr int RB = 256;  // 128 lane pairs x 384 B = 48 KB of LDS per block
+      k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 2) * sizeof(X), st>>>(
+          (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+    } else {
+      if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created
+        k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                     p->L, (X*)p->d_A, (X*)p->d_W0);
+        constexpr int RB = 256;  // 48 KB of LDS per block
+        k_masked_sums<F, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), RB * sizeof(X), st>>>(
+            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      } else {
+        // one point per quad of lanes: a group addition is 4 rounds of one multiplication instead of 14 in a row
+        k_chunks_q<C><<<dim3((unsigned)((4 * n_chunks + p->red_block - 1) / p->red_block)), dim3(p->red_block), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                         p->L, (X*)p->d_A, (X*)p->d_W0);
+        constexpr int RB = 512;  // 128 quads, 24 KB of LDS per block
+        k_masked_sums_q<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
+            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      }
+    }
+  }
+  return 0;
+}
+
 template <class C, class F>
 int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n, hipStream_t st) {
   typedef Affine<F> A;
@@ -1050,42 +1241,9 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     if (p->d_points28) HIPCHK(hipEventRecord(p->ev_fork, st));
     HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
     if (prof) HIPCHK(hipEventRecord(p->ev[0], st));
-    if (p->sort_low > 0) {
-      // two-level LDS counting sort (no per-key global atomics)
-      const unsigned blocks = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
-      const uint32_t NB = p->sort_nb;
-      k_coarse_hist<C><<<dim3(blocks), dim3(256), NB * 4, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low, NB,
-                                                              p->d_coarse_count, p->d_blockhist);
-      if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
-      launch_scan(p->d_coarse_count, p->d_coarse_off, p->d_tilesums, NB, st);
-      k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low,
-                                                                 p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
-                                                                 p->d_digits, p->d_blockhist);
-      k_fine_sort<<<dim3(NB), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->c, p->sort_low,
-                                                 p->sort_idx_bits, p->d_counts, p->d_offsets, p->d_sorted);
-    } else {
-      // legacy path (very large n or MLHIP_LEGACY_SORT=1): digits array + global-atomic histogram / scatter
-      {
-        size_t blocks = (n + 255) / 256;
-        if (blocks > 65536) blocks = 65536;
-        k_digits<C><<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->M,
-                                                                   p->d_digits, p->d_counts);
-      }
-      if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
-      launch_scan(p->d_counts, p->d_offsets, p->d_tilesums, nbuckets, st);
-      {
-        size_t total_e = (size_t)p->W * n;
-        size_t blocks = (total_e + 255) / 256;
-        if (blocks > 262144) blocks = 262144;
-        k_scatter<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(p->d_digits, n, p->W, p->M, p->d_offsets, p->d_cursor,
-                                                                 p->d_sorted);
-      }
-    }
     {
-      const unsigned nblk = (unsigned)((nbuckets + 255) / 256);
-      k_order_hist<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist);
-      launch_scan(p->d_hist, p->d_hist, p->d_tilesums, (size_t)ORDER_BINS * nblk, st);
-      k_order_place<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist, p->d_order);
+      int rc_sort = launch_sort<C>(p, d_scalars, mont, n, st, prof);
+      if (rc_sort) return rc_sort;
     }
     // resident bases: the carry-free copy of the first conv_n points of this very buffer is already there
     const bool conv_cached = p->points_static && p->conv_src == d_points && n <= p->conv_n && !p->upload_src;
@@ -1144,35 +1302,82 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
                                                                             p->d_bigcount, (X*)p->d_buckets);
     }
     {
-      size_t n_chunks = (size_t)p->W * p->T;
-      if constexpr (kLanePairs) {
-        k_chunks_lp<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
-                                                                                          p->L, (X*)p->d_A, (X*)p->d_W0);
-        constexpr int RB = 256;  // 128 lane pairs x 384 B = 48 KB of LDS per block
-        k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 2) * sizeof(X), st>>>(
-            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
-      } else {
-        if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created
-          k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
-                                                                                       p->L, (X*)p->d_A, (X*)p->d_W0);
-          constexpr int RB = 256;  // 48 KB of LDS per block
-          k_masked_sums<F, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), RB * sizeof(X), st>>>(
-              (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
-        } else {
-          // one point per quad of lanes: a group addition is 4 rounds of one multiplication instead of 14 in a row
-          k_chunks_q<C><<<dim3((unsigned)((4 * n_chunks + p->red_block - 1) / p->red_block)), dim3(p->red_block), 0, st>>>((const X*)p->d_buckets, n_chunks,
-                                                                                           p->L, (X*)p->d_A, (X*)p->d_W0);
-          constexpr int RB = 512;  // 128 quads, 24 KB of LDS per block
-          k_masked_sums_q<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
-              (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
-        }
-      }
+      int rc_red = launch_reduce<C, F>(p, st);
+      if (rc_red) return rc_red;
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[4], st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->W * p->nsel * sizeof(X), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(p->done, st));
   }
+  return 0;
+}
+
+// Host-buffer G1 MSM streamed in K segments (see k_accumulate28_seg): h_points / h_scalars are the caller's pageable
+// buffers, d_points / d_scalars the plan-sized device buffers they are staged through.  Uploads and the point
+// conversion ride the auxiliary stream; the sort and the accumulation of segment s wait for its event on `st`.
+// The host thread blocks inside the pageable copies, which is exactly what overlaps them with the kernels queued before.
+template <class C>
+int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points, const void* h_scalars, int mont,
+                size_t n, int K, hipStream_t st) {
+  typedef FpField<C> F;
+  typedef Affine<F> A;
+  typedef XYZZ<F> X;
+  if (!p->d_points28 || !p->aux) return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM needs the carry-free G1 path");
+  if (n == 0 || K < 2 || K > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "bad segment count");
+  const size_t nbuckets = (size_t)p->W * p->M;
+  if (!p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * sizeof(XYZZ28<C>)));
+  for (int s = 0; s < K; s++)
+    if (!p->ev_seg[s]) HIPCHK(hipEventCreateWithFlags(&p->ev_seg[s], hipEventDisableTiming));
+  // resident bases (h_points == nullptr): only the scalars travel; the carry-free copy must already be there
+  const bool resident = h_points == nullptr;
+  if (resident && !(p->points_static && p->conv_src == d_points && n <= p->conv_n))
+    return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM over resident bases needs their converted copy");
+  p->pending_n = n;
+  p->pending = true;
+  if (!resident) p->conv_src = nullptr;  // the carry-free copy no longer matches any resident buffer
+  const size_t seg = (n + K - 1) / K;
+  const char* hp = (const char*)h_points;
+  const char* hs = (const char*)h_scalars;
+  HIPCHK(hipEventRecord(p->ev_fork, st));  // the staging buffers are free once the work queued before us is done
+  HIPCHK(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
+  int s = 0;
+  for (size_t off = 0; off < n; off += seg, s++) {
+    const size_t len = std::min(seg, n - off);
+    const bool first = off == 0, last = off + len >= n;
+    const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0);
+    char* dsc = (char*)d_scalars + off * 32;
+    A* dpt = (A*)d_points + off;
+    Affine28<C>* d28 = (Affine28<C>*)p->d_points28 + off;
+    HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
+    if (!resident) {
+      HIPCHK(hipMemcpyAsync(dpt, hp + off * sizeof(A), len * sizeof(A), hipMemcpyHostToDevice, p->aux));
+      k_points_to28<C><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, p->aux>>>(dpt, len, d28);
+    }
+    HIPCHK(hipEventRecord(p->ev_seg[s], p->aux));
+    HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));
+    HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
+    {
+      int rc_sort = launch_sort<C>(p, dsc, mont, len, st, false);
+      if (rc_sort) return rc_sort;
+    }
+    uint32_t big_threshold = (uint32_t)std::min<size_t>((len >> (p->c - 1)) * 8, 1u << 30);
+    if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
+    k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+        d28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist, p->d_bigcount,
+        (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
+    constexpr int BB = 256;
+    k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(dpt, p->d_sorted, p->d_offsets, p->d_counts,
+                                                                           p->d_biglist, p->d_bigcount,
+                                                                           (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
+  }
+  {
+    int rc_red = launch_reduce<C, F>(p, st);
+    if (rc_red) return rc_red;
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->W * p->nsel * sizeof(X), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(p->done, st));
   return 0;
 }
 

@@ -216,9 +216,11 @@ def test_g2_wire_round_trips(curve):
         c.NewG2FromBytes(bytes(bad))
 
 
-def test_resident_bases_match_multiscalarmul(curve):
+@pytest.mark.parametrize("segments", ["0", "3"])
+def test_resident_bases_match_multiscalarmul(curve, segments, monkeypatch):
     """the upload-once point table gives the same element as MultiScalarMul, for the full table and
-    for a prefix of it, on repeated calls."""
+    for a prefix of it, on repeated calls -- in one pass and with the scalars streamed in three segments."""
+    monkeypatch.setenv("MLHIP_STREAM_SEGMENTS", segments)
     c = curve
     g = c.GenG1()
     pts = [g.Mul(c.NewRandomZr(c._rng)) for _ in range(40)]

@@ -210,12 +210,16 @@ def test_msm_g2_random_vs_cref(lib, mlhip, curve):
     assert out.raw == exp
 
 
+@pytest.mark.parametrize("segments", [0, 3])
 @pytest.mark.parametrize("curve", CURVES)
-def test_msm_g1_skewed_distributions(lib, mlhip, curve):
+def test_msm_g1_skewed_distributions(lib, mlhip, curve, segments, monkeypatch):
     """BASELINE.md section 3 extra distributions: small scalars, duplicated points, zero scalars, and one
-    hot bucket (all scalars equal) which exercises the workgroup-per-bucket path."""
+    hot bucket (all scalars equal) which exercises the workgroup-per-bucket path.  segments = 3 streams the same
+    inputs in three segments (the hot bucket is then long in every segment and is added into the kept state)."""
     import numpy as np
     from oracle import cref
+
+    monkeypatch.setenv("MLHIP_STREAM_SEGMENTS", str(segments))
 
     g = load_golden(curve)
     cid = g["curve_id"]
@@ -385,7 +389,8 @@ def test_g2_wire_codec_vs_oracle(lib, mlhip, curve):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("curve", CURVES)
 @pytest.mark.parametrize("switch", ["MLHIP_LEGACY_SORT", "MLHIP_ACC32", "MLHIP_REDUCE_ONE_LANE", "MLHIP_NO_PLAN_CACHE",
-                                    "MLHIP_ACC_BLOCK=256", "MLHIP_RED_BLOCK=64", "MLHIP_CHUNK_LOG2=3"])
+                                    "MLHIP_ACC_BLOCK=256", "MLHIP_RED_BLOCK=64", "MLHIP_CHUNK_LOG2=3",
+                                    "MLHIP_STREAM_SEGMENTS=2", "MLHIP_STREAM_SEGMENTS=5"])
 def test_msm_alternate_paths(lib, mlhip, curve, switch, monkeypatch):
     g = load_golden(curve)
     cid = g["curve_id"]

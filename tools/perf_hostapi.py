@@ -37,12 +37,35 @@ torch.cuda.synchronize()
 hp = P.cpu().numpy().tobytes()
 hs = S.cpu().numpy().tobytes()
 out = ctypes.create_string_buffer(g1b)
-res = []
-for rep in range(6):
-    t0 = time.perf_counter()
-    _lib.check(lib.mlhip_msm_g1(cid, hp, hs, 0, n, 16, out))
-    res.append((time.perf_counter() - t0) * 1e3)
 plan = _lib.MsmPlan(cid, 1, n, 16)
 ref = plan.run(P.data_ptr(), S.data_ptr(), n, False, st)
-print("mlhip_msm_g1 host-buffer call, n=2^%d: %s ms (first call includes lazy init); matches resident-plan result: %s" % (
-    n.bit_length() - 1, ", ".join("%.2f" % x for x in res), out.raw == ref))
+# segments: "" = the library's own choice, 0 = one upload and one pass, K = streamed in K segments
+for segs in ("", "0", "2", "4", "8", "16"):
+    if segs:
+        os.environ["MLHIP_STREAM_SEGMENTS"] = segs
+    else:
+        os.environ.pop("MLHIP_STREAM_SEGMENTS", None)
+    res = []
+    for rep in range(7):
+        t0 = time.perf_counter()
+        _lib.check(lib.mlhip_msm_g1(cid, hp, hs, 0, n, 16, out))
+        res.append((time.perf_counter() - t0) * 1e3)
+    print("mlhip_msm_g1 host-buffer call, n=2^%d, segments=%-7s: %s ms; matches resident-plan result: %s" % (
+        n.bit_length() - 1, segs or "default", ", ".join("%.2f" % x for x in res), out.raw == ref), flush=True)
+
+# resident bases: only the scalars travel
+handle = ctypes.c_void_p()
+_lib.check(lib.mlhip_bases_create(cid, 1, hp, n, 16, ctypes.byref(handle)))
+for segs in ("", "0", "2", "4", "8"):
+    if segs:
+        os.environ["MLHIP_STREAM_SEGMENTS"] = segs
+    else:
+        os.environ.pop("MLHIP_STREAM_SEGMENTS", None)
+    res = []
+    for rep in range(7):
+        t0 = time.perf_counter()
+        _lib.check(lib.mlhip_bases_msm(handle, hs, 0, n, out))
+        res.append((time.perf_counter() - t0) * 1e3)
+    print("mlhip_bases_msm, n=2^%d, segments=%-7s: %s ms; matches: %s" % (
+        n.bit_length() - 1, segs or "default", ", ".join("%.2f" % x for x in res), out.raw == ref), flush=True)
+_lib.check(lib.mlhip_bases_destroy(handle))
