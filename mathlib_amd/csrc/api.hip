@@ -218,7 +218,7 @@ void pool_release(PoolEntry* e, bool failed) {
 // Number of segments a host-buffer MSM is streamed in (1 = one upload, one pass).  Measured on MI355X / PCIe gen5
 // (tools/perf_hostapi.py): from 2^19 points the transfer is worth hiding; MLHIP_STREAM_SEGMENTS overrides (0/1 = off).
 int stream_segments(int group, size_t n, const mlhip_msm_plan* plan) {
-  if (group != MLHIP_GROUP_G1 || !plan->d_points28 || !plan->aux) return 1;
+  if (!plan->d_points28 || !plan->aux) return 1;  // G1 on every curve, G2 on BLS12-381 (the carry-free kernels)
   if (const char* e = getenv("MLHIP_STREAM_SEGMENTS")) {
     int v = atoi(e);
     if (v < 2) return 1;
@@ -226,7 +226,8 @@ int stream_segments(int group, size_t n, const mlhip_msm_plan* plan) {
     return n >= (size_t)v ? v : 1;
   }
   // segments of 2^18 pairs: at 2^20 the call drops from 5.9 to 4.5 ms, at 2^22 from 21.9 to 12.8 ms (the device-only time)
-  const size_t k = n >> 18;
+  // G2 (BLS12-381): segments of 2^17 pairs, 14.9 -> 11.4 ms at 2^20
+  const size_t k = n >> (group == MLHIP_GROUP_G1 ? 18 : 17);
   return k < 2 ? 1 : (k > MLHIP_MAX_SEGMENTS ? MLHIP_MAX_SEGMENTS : (int)k);
 }
 

@@ -955,6 +955,142 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   lp_store_xyzz<C>(buckets, g, r, hi);
 }
 
+// ---- segmented G2 accumulation (see k_accumulate28_seg): the state of bucket g is two XYZZ28L, one per lane ------
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_accumulate28_lp_seg(
+    const AffineG2_28<C>* __restrict__ points, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ counts, size_t n_buckets, const uint32_t* __restrict__ order, uint32_t big_threshold,
+    uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count, XYZZ28L<Fp28<C>>* __restrict__ state, int flags,
+    XYZZ<Fp2Field<C>>* __restrict__ buckets) {
+  typedef PairDevice<C> B;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t pair = t >> 1;  // both lanes of a pair share the bucket: every branch below is pair-uniform
+  if (pair >= n_buckets) return;
+  const int hi = (int)(threadIdx.x & 1u);
+  const size_t g = order[pair];
+  const uint32_t cnt = counts[g];
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  if (cnt > big_threshold) {
+    if (!hi) {
+      uint32_t pos = atomicAdd(big_count, 1u);
+      big_list[pos] = (uint32_t)g;
+    }
+    return;
+  }
+  if (cnt == 0 && !first && !last) return;
+  XYZZ28L<Fp28<C>> acc;
+  bool inf = true;
+  if (!first) {
+    acc = state[2 * g + hi];
+    const uint32_t z = fp28_all_zero<C>(acc.zz) ? 1u : 0u;
+    inf = (z & pair_xchg_u32(z)) != 0;  // ZZ = 0 in Fp2: both components
+  }
+  const size_t begin = offsets[g], end = begin + cnt;
+  if (cnt != 0) {
+    uint32_t e = sorted[begin];
+    Affine28L<Fp28<C>> p, pn;
+    p.x = points[e & 0x7fffffffu].c[hi];
+    p.y = points[e & 0x7fffffffu].c[2 + hi];
+    for (size_t k = begin; k < end; k++) {
+      uint32_t en = e;
+      pn = p;
+      if (k + 1 < end) {
+        en = sorted[k + 1];
+        pn.x = points[en & 0x7fffffffu].c[hi];
+        pn.y = points[en & 0x7fffffffu].c[2 + hi];
+      }
+      xyzz28_lp_madd<C, B>(acc, inf, p, (e >> 31) != 0);
+      e = en;
+      p = pn;
+    }
+  }
+  if (last) {
+    XYZZ<Fp2LField<C>> r;
+    if (inf) {
+      xyzz_set_inf<Fp2LField<C>>(r);
+    } else {
+      fp28_to_fp<C>(r.x.v, acc.x);
+      fp28_to_fp<C>(r.y.v, acc.y);
+      fp28_to_fp<C>(r.zz.v, acc.zz);
+      fp28_to_fp<C>(r.zzz.v, acc.zzz);
+    }
+    lp_store_xyzz<C>(buckets, g, r, hi);
+  } else {
+    if (inf) {
+#pragma unroll
+      for (int i = 0; i < C::N28; i++) acc.x.l[i] = acc.y.l[i] = acc.zz.l[i] = acc.zzz.l[i] = 0;
+    }
+    state[2 * g + hi] = acc;
+  }
+}
+
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_g2(const Affine<Fp2Field<C>>* __restrict__ points,
+                                                                 const uint32_t* __restrict__ sorted,
+                                                                 const uint32_t* __restrict__ offsets,
+                                                                 const uint32_t* __restrict__ counts,
+                                                                 const uint32_t* __restrict__ big_list,
+                                                                 const uint32_t* __restrict__ big_count,
+                                                                 XYZZ28L<Fp28<C>>* __restrict__ state, int flags,
+                                                                 XYZZ<Fp2Field<C>>* __restrict__ buckets) {
+  typedef Fp2Field<C> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  const uint32_t nbig = *big_count;
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    uint32_t g = big_list[bi];
+    size_t begin = offsets[g];
+    size_t end = begin + counts[g];
+    XYZZ<F> acc;
+    xyzz_set_inf<F>(acc);
+    msm_accumulate_range<F>(acc, points, sorted, begin + threadIdx.x, end, BLOCK);
+    block_tree_sum<F, BLOCK>(sh, acc);
+    if (threadIdx.x == 0) {
+      XYZZ<F> sum = sh[0];
+      if (!first) {
+        const XYZZ28L<Fp28<C>> lo = state[2 * g], up = state[2 * g + 1];
+        if (!(fp28_all_zero<C>(lo.zz) && fp28_all_zero<C>(up.zz))) {
+          XYZZ<F> prev;
+          fp28_to_fp<C>(prev.x.c0, lo.x);
+          fp28_to_fp<C>(prev.x.c1, up.x);
+          fp28_to_fp<C>(prev.y.c0, lo.y);
+          fp28_to_fp<C>(prev.y.c1, up.y);
+          fp28_to_fp<C>(prev.zz.c0, lo.zz);
+          fp28_to_fp<C>(prev.zz.c1, up.zz);
+          fp28_to_fp<C>(prev.zzz.c0, lo.zzz);
+          fp28_to_fp<C>(prev.zzz.c1, up.zzz);
+          xyzz_add_ool<F>(sum, prev);
+        }
+      }
+      if (last) {
+        buckets[g] = sum;
+      } else {
+        XYZZ28L<Fp28<C>> lo, up;
+        if (xyzz_is_inf<F>(sum)) {
+#pragma unroll
+          for (int i = 0; i < C::N28; i++) {
+            lo.x.l[i] = lo.y.l[i] = lo.zz.l[i] = lo.zzz.l[i] = 0;
+            up.x.l[i] = up.y.l[i] = up.zz.l[i] = up.zzz.l[i] = 0;
+          }
+        } else {
+          fp28_from_fp<C>(lo.x, sum.x.c0);
+          fp28_from_fp<C>(up.x, sum.x.c1);
+          fp28_from_fp<C>(lo.y, sum.y.c0);
+          fp28_from_fp<C>(up.y, sum.y.c1);
+          fp28_from_fp<C>(lo.zz, sum.zz.c0);
+          fp28_from_fp<C>(up.zz, sum.zz.c1);
+          fp28_from_fp<C>(lo.zzz, sum.zzz.c0);
+          fp28_from_fp<C>(up.zzz, sum.zzz.c1);
+        }
+        state[2 * g] = lo;
+        state[2 * g + 1] = up;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <class C>
 __global__ void __launch_bounds__(256) k_chunks_lp(const XYZZ<Fp2Field<C>>* __restrict__ buckets, size_t n_chunks, int l_eff,
                                                    XYZZ<Fp2Field<C>>* __restrict__ A, XYZZ<Fp2Field<C>>* __restrict__ W0) {
@@ -1317,16 +1453,17 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
 // buffers, d_points / d_scalars the plan-sized device buffers they are staged through.  Uploads and the point
 // conversion ride the auxiliary stream; the sort and the accumulation of segment s wait for its event on `st`.
 // The host thread blocks inside the pageable copies, which is exactly what overlaps them with the kernels queued before.
-template <class C>
+template <class C, class F>
 int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points, const void* h_scalars, int mont,
                 size_t n, int K, hipStream_t st) {
-  typedef FpField<C> F;
   typedef Affine<F> A;
   typedef XYZZ<F> X;
-  if (!p->d_points28 || !p->aux) return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM needs the carry-free G1 path");
+  constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
+  if (!p->d_points28 || !p->aux) return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM needs the carry-free accumulation path");
+  constexpr size_t kStateBytes = kG2 ? 2 * sizeof(XYZZ28L<Fp28<C>>) : sizeof(XYZZ28<C>);
   if (n == 0 || K < 2 || K > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "bad segment count");
   const size_t nbuckets = (size_t)p->W * p->M;
-  if (!p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * sizeof(XYZZ28<C>)));
+  if (!p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * kStateBytes));
   for (int s = 0; s < K; s++)
     if (!p->ev_seg[s]) HIPCHK(hipEventCreateWithFlags(&p->ev_seg[s], hipEventDisableTiming));
   // resident bases (h_points == nullptr): only the scalars travel; the carry-free copy must already be there
@@ -1348,11 +1485,15 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
     const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0);
     char* dsc = (char*)d_scalars + off * 32;
     A* dpt = (A*)d_points + off;
-    Affine28<C>* d28 = (Affine28<C>*)p->d_points28 + off;
     HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
     if (!resident) {
       HIPCHK(hipMemcpyAsync(dpt, hp + off * sizeof(A), len * sizeof(A), hipMemcpyHostToDevice, p->aux));
-      k_points_to28<C><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, p->aux>>>(dpt, len, d28);
+      if constexpr (kG2)
+        k_points_to28_g2<C><<<dim3((unsigned)((4 * len + 255) / 256)), dim3(256), 0, p->aux>>>(
+            dpt, len, (AffineG2_28<C>*)p->d_points28 + off);
+      else
+        k_points_to28<C><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, p->aux>>>(dpt, len,
+                                                                                       (Affine28<C>*)p->d_points28 + off);
     }
     HIPCHK(hipEventRecord(p->ev_seg[s], p->aux));
     HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));
@@ -1363,13 +1504,23 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
     }
     uint32_t big_threshold = (uint32_t)std::min<size_t>((len >> (p->c - 1)) * 8, 1u << 30);
     if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
-    k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-        d28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist, p->d_bigcount,
-        (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
-    constexpr int BB = 256;
-    k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(dpt, p->d_sorted, p->d_offsets, p->d_counts,
-                                                                           p->d_biglist, p->d_bigcount,
-                                                                           (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
+    if constexpr (kG2) {
+      k_accumulate28_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+          (const AffineG2_28<C>*)p->d_points28 + off, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+          big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
+      constexpr int BB = 128;
+      k_accumulate_big_seg_g2<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+          dpt, p->d_sorted, p->d_offsets, p->d_counts, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags,
+          (X*)p->d_buckets);
+    } else {
+      k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+          (const Affine28<C>*)p->d_points28 + off, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+          big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
+      constexpr int BB = 256;
+      k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+          dpt, p->d_sorted, p->d_offsets, p->d_counts, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags,
+          (X*)p->d_buckets);
+    }
   }
   {
     int rc_red = launch_reduce<C, F>(p, st);

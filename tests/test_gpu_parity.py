@@ -210,6 +210,39 @@ def test_msm_g2_random_vs_cref(lib, mlhip, curve):
     assert out.raw == exp
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_g2_streamed_segments(lib, mlhip, curve, monkeypatch):
+    """The host-buffer G2 MSM streamed in segments (BLS12-381; the other curves have no carry-free G2 kernel and run
+    in one pass whatever the switch says): duplicates, negated duplicates, infinities and one hot bucket that is long
+    in every segment; same bytes as the C oracle and as the one-pass run."""
+    import numpy as np
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, _, g2b, _ = mlhip.sizes(cid)
+    n = 4000
+    pts = bytearray(cref.gen_points(cid, 2, 9091, 4243, n))
+    for i in range(0, n, 64):  # duplicated points (doubling inside a bucket when the scalars agree)
+        pts[i * g2b : (i + 1) * g2b] = pts[:g2b]
+    for i in range(33, n, 500):  # points at infinity
+        pts[i * g2b : (i + 1) * g2b] = bytes(g2b)
+    pts = bytes(pts)
+    cases = {"random": _rand_scalars(n, 404 + cid, 252)}
+    sc = _rand_scalars(n, 405 + cid, 252)
+    sc[::64] = sc[0]
+    cases["equal_scalars_on_equal_points"] = sc
+    cases["all_equal"] = np.tile(_rand_scalars(1, 406 + cid, 252), (n, 1))
+    for name, sc in cases.items():
+        exp = cref.msm(cid, 2, pts, sc, n, False, 0, 8)
+        for segs in ("0", "2", "7"):
+            monkeypatch.setenv("MLHIP_STREAM_SEGMENTS", segs)
+            for c in (8, 16):
+                out = ctypes.create_string_buffer(g2b)
+                mlhip.check(lib.mlhip_msm_g2(cid, pts, sc.tobytes(), 0, n, c, out))
+                assert out.raw == exp, (curve, name, segs, c)
+
+
 @pytest.mark.parametrize("segments", [0, 3])
 @pytest.mark.parametrize("curve", CURVES)
 def test_msm_g1_skewed_distributions(lib, mlhip, curve, segments, monkeypatch):

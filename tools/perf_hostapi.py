@@ -69,3 +69,26 @@ for segs in ("", "0", "2", "4", "8"):
     print("mlhip_bases_msm, n=2^%d, segments=%-7s: %s ms; matches: %s" % (
         n.bit_length() - 1, segs or "default", ", ".join("%.2f" % x for x in res), out.raw == ref), flush=True)
 _lib.check(lib.mlhip_bases_destroy(handle))
+
+# G2 host-buffer call (BLS12-381: streamed like G1)
+if len(sys.argv) > 2 and sys.argv[2] == "g2":
+    base2 = torch.frombuffer(bytearray(bytes.fromhex(g["g2_gen"])), dtype=torch.uint8).to(dev)
+    P2 = torch.empty(n * g2b, dtype=torch.uint8, device=dev)
+    _lib.check(lib.mlhip_scalar_mul_device(cid, 2, base2.data_ptr(), 0, rnd(n).data_ptr(), 0, n, P2.data_ptr(), st))
+    torch.cuda.synchronize()
+    hp2 = P2.cpu().numpy().tobytes()
+    out2 = ctypes.create_string_buffer(g2b)
+    plan2 = _lib.MsmPlan(cid, 2, n, 16)
+    ref2 = plan2.run(P2.data_ptr(), S.data_ptr(), n, False, st)
+    for segs in ("", "0", "2", "4", "8", "16"):
+        if segs:
+            os.environ["MLHIP_STREAM_SEGMENTS"] = segs
+        else:
+            os.environ.pop("MLHIP_STREAM_SEGMENTS", None)
+        res = []
+        for rep in range(5):
+            t0 = time.perf_counter()
+            _lib.check(lib.mlhip_msm_g2(cid, hp2, hs, 0, n, 16, out2))
+            res.append((time.perf_counter() - t0) * 1e3)
+        print("mlhip_msm_g2 host-buffer call, n=2^%d, segments=%-7s: %s ms; matches resident-plan result: %s" % (
+            n.bit_length() - 1, segs or "default", ", ".join("%.2f" % x for x in res), out2.raw == ref2), flush=True)
