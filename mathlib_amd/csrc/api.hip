@@ -130,6 +130,7 @@ int pairing_host(int curve, int what, const void* g1, const void* g2, size_t ppp
 struct PoolEntry {
   mlhip_msm_plan* plan = nullptr;
   void *d_pts = nullptr, *d_sc = nullptr;
+  hipStream_t stream = nullptr;  // the entry's own non-blocking stream: concurrent callers do not meet on the null stream
   int curve = 0, group = 0, c = 0, device = 0;
   size_t cap = 0;
   bool busy = false, pooled = false;
@@ -145,6 +146,7 @@ void pool_free_entry(PoolEntry* e) {
   if (e->d_pts) (void)hipFree(e->d_pts);
   if (e->d_sc) (void)hipFree(e->d_sc);
   if (e->plan) mlhip_msm_plan_destroy(e->plan);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
 
@@ -182,6 +184,8 @@ PoolEntry* pool_acquire(int curve, int group, int c, size_t n, size_t ptsz, int&
   rc = mlhip_msm_plan_create(curve, group, n, c, &e->plan);
   if (!rc && (hipMalloc(&e->d_pts, n * ptsz) != hipSuccess || hipMalloc(&e->d_sc, n * 32) != hipSuccess))
     rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of MSM inputs failed");
+  if (!rc && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    rc = mlhip_rt::fail(MLHIP_EHIP, "hipStreamCreate failed");
   if (rc) {
     pool_free_entry(e);
     return nullptr;
@@ -232,11 +236,11 @@ int stream_segments(int group, size_t n, const mlhip_msm_plan* plan) {
 }
 
 int tu_plan_stream(mlhip_msm_plan* p, void* d_pts, void* d_sc, const void* points, const void* scalars, int mont, size_t n,
-                   int segments) {
+                   int segments, hipStream_t st) {
   switch (p->curve) {
-    case MLHIP_CURVE_BN254: return mlhip_tu_plan_stream_Bn254(p, d_pts, d_sc, points, scalars, mont, n, segments, nullptr);
-    case MLHIP_CURVE_BLS12_381: return mlhip_tu_plan_stream_Bls381(p, d_pts, d_sc, points, scalars, mont, n, segments, nullptr);
-    default: return mlhip_tu_plan_stream_Bls377(p, d_pts, d_sc, points, scalars, mont, n, segments, nullptr);
+    case MLHIP_CURVE_BN254: return mlhip_tu_plan_stream_Bn254(p, d_pts, d_sc, points, scalars, mont, n, segments, st);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_plan_stream_Bls381(p, d_pts, d_sc, points, scalars, mont, n, segments, st);
+    default: return mlhip_tu_plan_stream_Bls377(p, d_pts, d_sc, points, scalars, mont, n, segments, st);
   }
 }
 
@@ -262,7 +266,7 @@ int msm_host_buffers(int curve, int group, const void* points, const void* scala
   do {
     if (segments > 1) {
       // large G1 MSMs: upload, sort and accumulate segment by segment, so the PCIe transfer hides under the kernels
-      rc = tu_plan_stream(e->plan, e->d_pts, e->d_sc, points, scalars, mont, n, segments);
+      rc = tu_plan_stream(e->plan, e->d_pts, e->d_sc, points, scalars, mont, n, segments, e->stream);
       if (!rc) rc = mlhip_msm_finish(e->plan, out, nullptr);
       break;
     }
@@ -273,7 +277,7 @@ int msm_host_buffers(int curve, int group, const void* points, const void* scala
     }
     e->plan->upload_src = points;
     e->plan->upload_bytes = n * ptsz;
-    rc = mlhip_msm_run(e->plan, e->d_pts, e->d_sc, mont, n, nullptr, out, nullptr);
+    rc = mlhip_msm_run(e->plan, e->d_pts, e->d_sc, mont, n, e->stream, out, nullptr);
     e->plan->upload_src = nullptr;
   } while (0);
   pool_release(e, rc != 0);
@@ -434,6 +438,7 @@ struct mlhip_bases {
   void *d_pts = nullptr, *d_sc = nullptr;
   size_t n = 0, ptsz = 0;
   int device = 0;
+  hipStream_t stream = nullptr;  // own non-blocking stream (see PoolEntry)
   std::mutex mu;  // one MSM at a time per handle: the plan and the scalar buffer are shared state
 };
 
@@ -443,6 +448,7 @@ int mlhip_bases_destroy(mlhip_bases* b) {
   if (b->d_pts) (void)hipFree(b->d_pts);
   if (b->d_sc) (void)hipFree(b->d_sc);
   if (b->plan) mlhip_msm_plan_destroy(b->plan);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return 0;
 }
@@ -465,6 +471,8 @@ int mlhip_bases_create(int curve, int group, const void* points, size_t n, int w
     rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of the bases failed");
   if (!rc && hipMemcpy(b->d_pts, points, n * b->ptsz, hipMemcpyHostToDevice) != hipSuccess)
     rc = mlhip_rt::fail(MLHIP_EHIP, "upload of the bases failed");
+  if (!rc && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess)
+    rc = mlhip_rt::fail(MLHIP_EHIP, "hipStreamCreate failed");
   if (rc) {
     mlhip_bases_destroy(b);
     return rc;
@@ -489,13 +497,13 @@ int mlhip_bases_msm(mlhip_bases* b, const void* scalars, int scalars_mont, size_
     const mlhip_msm_plan* p = b->plan;
     const int segments = stream_segments(p->group, n, p);
     if (segments > 1 && p->points_static && p->conv_src == b->d_pts && n <= p->conv_n) {
-      int rc = tu_plan_stream(b->plan, b->d_pts, b->d_sc, nullptr, scalars, scalars_mont, n, segments);
+      int rc = tu_plan_stream(b->plan, b->d_pts, b->d_sc, nullptr, scalars, scalars_mont, n, segments, b->stream);
       return rc ? rc : mlhip_msm_finish(b->plan, out_affine, nullptr);
     }
   }
   if (hipMemcpy(b->d_sc, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess)
     return mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy of MSM scalars failed");
-  return mlhip_msm_run(b->plan, b->d_pts, b->d_sc, scalars_mont, n, nullptr, out_affine, nullptr);
+  return mlhip_msm_run(b->plan, b->d_pts, b->d_sc, scalars_mont, n, b->stream, out_affine, nullptr);
 }
 
 int mlhip_release_cache(void) {

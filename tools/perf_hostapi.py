@@ -70,6 +70,29 @@ for segs in ("", "0", "2", "4", "8"):
         n.bit_length() - 1, segs or "default", ", ".join("%.2f" % x for x in res), out.raw == ref), flush=True)
 _lib.check(lib.mlhip_bases_destroy(handle))
 
+# several host threads calling at once (goroutines on a shared SRS): wall time per MSM
+import threading
+
+os.environ.pop("MLHIP_STREAM_SEGMENTS", None)
+for nthreads in (1, 2, 4):
+    outs = [ctypes.create_string_buffer(g1b) for _ in range(nthreads)]
+    reps = 6
+
+    def work(i):
+        for _ in range(reps):
+            _lib.check(lib.mlhip_msm_g1(cid, hp, hs, 0, n, 16, outs[i]))
+
+    for warm in range(2):
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = (time.perf_counter() - t0) * 1e3
+    print("mlhip_msm_g1 from %d host threads, n=2^%d: %.2f ms per MSM (%d calls in %.1f ms); all match: %s" % (
+        nthreads, n.bit_length() - 1, dt / (reps * nthreads), reps * nthreads, dt, all(o.raw == ref for o in outs)), flush=True)
+
 # G2 host-buffer call (BLS12-381: streamed like G1)
 if len(sys.argv) > 2 and sys.argv[2] == "g2":
     base2 = torch.frombuffer(bytearray(bytes.fromhex(g["g2_gen"])), dtype=torch.uint8).to(dev)
