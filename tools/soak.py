@@ -23,7 +23,7 @@ lib = _lib.load()
 rnd = random.Random(seed)
 names = ["BN254", "BLS12-381", "BLS12-377"]
 t0 = last = time.time()
-done = {"msm": 0, "pairing": 0}
+done = {"msm": 0, "streamed": 0, "pairing": 0}
 while time.time() - t0 < budget:
     name = rnd.choice(names)
     g = load_golden(name)
@@ -52,11 +52,15 @@ while time.time() - t0 < budget:
         exp = cref.msm(cid, group, pts, sc, n, False, 0, 16)
         out = ctypes.create_string_buffer(sz)
         fn = lib.mlhip_msm_g1 if group == 1 else lib.mlhip_msm_g2
+        # half of the calls stream the pairs in a random number of segments (the library reads the switch per call)
+        segs = rnd.choice([0, 0, 0, 2, 3, 5, 16])
+        os.environ["MLHIP_STREAM_SEGMENTS"] = str(segs)
         _lib.check(fn(cid, pts, sc.tobytes(), 0, n, c, out))
         if out.raw != exp:
-            print("MISMATCH msm", name, group, n, c, bits, "seed", seed, flush=True)
+            print("MISMATCH msm", name, group, n, c, bits, "segments", segs, "seed", seed, flush=True)
             sys.exit(1)
         done["msm"] += 1
+        done["streamed"] += 1 if segs else 0
     else:
         n = rnd.choice([1, 3, 64, 65, 500])
         p1 = cref.gen_points(cid, 1, rnd.getrandbits(40), rnd.getrandbits(40), n)
