@@ -735,7 +735,12 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
-  fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  if (mont < 0) {  // plain 256-bit integers, not reduced mod r (the fixed-base table: [d 2^(8j)]P for ANY P on the curve)
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = scalars[8 * i + k];
+  } else {
+    fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  }
   const Affine<F> P = points[i * point_stride];
   XYZZ<F> tab[15];
   xyzz_from_affine<F>(tab[0], P);
@@ -776,10 +781,102 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
   out[i] = r;
 }
 
+// ---- one base, many scalars (point_stride = 0: [s_i]G for generators, Pedersen bases ...) ------------------------
+// From FIXED_BASE_MIN scalars on, the table T[j][d-1] = [d 2^(8j)]P (32 windows x 255 affine points, built by
+// k_scalar_mul itself from 8160 plain-integer scalars) turns every product into <= 32 mixed additions and no doubling:
+// 2^20 G1 products in 10 ms instead of 70 ms, G2 in 42 ms instead of 326 ms (profiles/r01_perf_scalar_mul.txt).  G1 runs the additions in the carry-free form (ec28.h).
+constexpr int FB_WINDOWS = 32, FB_ROW = 255;
+constexpr size_t FIXED_BASE_MIN = (size_t)1 << 16;  // the table costs one double-and-add wave time (G1 ~4 ms, G2 ~14 ms)
+
+static __global__ void __launch_bounds__(256) k_fb_scalars(uint32_t* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= FB_WINDOWS * FB_ROW) return;
+  const uint32_t j = t / FB_ROW, d = t % FB_ROW + 1;
+#pragma unroll
+  for (int k = 0; k < 8; k++) out[8 * t + k] = 0;
+  out[8 * t + (j >> 2)] = d << ((j & 3) * 8);
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) k_fixed_base_g1(const Affine28<C>* __restrict__ table,
+                                                      const uint32_t* __restrict__ scalars, int mont, size_t n,
+                                                      Affine<FpField<C>>* __restrict__ out) {
+  typedef FpField<C> F;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+  fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  XYZZ28<C> acc;
+  bool inf = true;
+#pragma unroll 1
+  for (int j = 0; j < FB_WINDOWS; j++) {
+    const uint32_t d = (s[j >> 2] >> ((j & 3) * 8)) & 255u;
+    if (d) {
+      const Affine28<C> q = table[j * FB_ROW + d - 1];
+      xyzz28_madd<C>(acc, inf, q, false);
+    }
+  }
+  XYZZ<F> r;
+  xyzz28_to<C>(r, acc, inf);
+  Affine<F> a;
+  xyzz_to_affine<F>(a, r);
+  out[i] = a;
+}
+
+template <class C, class F>
+__global__ void __launch_bounds__(64) k_fixed_base(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ scalars,
+                                                   int mont, size_t n, Affine<F>* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+  fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  XYZZ<F> acc;
+  xyzz_set_inf<F>(acc);
+#pragma unroll 1
+  for (int j = 0; j < FB_WINDOWS; j++) {
+    const uint32_t d = (s[j >> 2] >> ((j & 3) * 8)) & 255u;
+    if (d) xyzz_madd_ool<F>(acc, table[j * FB_ROW + d - 1]);
+  }
+  Affine<F> a;
+  xyzz_to_affine<F>(a, acc);
+  out[i] = a;
+}
+
 template <class C, class F>
 int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_scalars, int mont, size_t n, void* d_out,
                       hipStream_t st) {
   if (n == 0) return 0;
+  size_t fb_min = FIXED_BASE_MIN;  // MLHIP_FIXED_BASE_MIN overrides (0 = never: always the double-and-add kernel)
+  if (const char* e = getenv("MLHIP_FIXED_BASE_MIN")) {
+    const long long v = atoll(e);
+    fb_min = v <= 0 ? SIZE_MAX : (size_t)v;
+  }
+  if (point_stride == 0 && n >= fb_min) {
+    constexpr size_t kEntries = (size_t)FB_WINDOWS * FB_ROW;
+    constexpr bool kG1 = std::is_same<F, FpField<C>>::value;
+    // stream-ordered scratch: [table | its 8160 scalars | (G1) the table in the carry-free form]
+    const size_t tab_bytes = kEntries * sizeof(Affine<F>), sc_bytes = kEntries * 32;
+    const size_t t28_bytes = kG1 ? kEntries * sizeof(Affine28<C>) : 0;
+    char* scratch = nullptr;
+    HIPCHK(hipMallocAsync((void**)&scratch, tab_bytes + sc_bytes + t28_bytes, st));
+    Affine<F>* table = (Affine<F>*)scratch;
+    uint32_t* tsc = (uint32_t*)(scratch + tab_bytes);
+    k_fb_scalars<<<dim3((unsigned)((kEntries + 255) / 256)), dim3(256), 0, st>>>(tsc);
+    k_scalar_mul<C, F><<<dim3((unsigned)((kEntries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
+                                                                                    kEntries, table);
+    if constexpr (kG1) {
+      Affine28<C>* t28 = (Affine28<C>*)(scratch + tab_bytes + sc_bytes);
+      k_points_to28<C><<<dim3((unsigned)((kEntries + 255) / 256)), dim3(256), 0, st>>>(table, kEntries, t28);
+      k_fixed_base_g1<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(t28, (const uint32_t*)d_scalars, mont, n,
+                                                                             (Affine<F>*)d_out);
+    } else {
+      k_fixed_base<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
+                                                                             (Affine<F>*)d_out);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipFreeAsync(scratch, st));
+    return 0;
+  }
   k_scalar_mul<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, point_stride,
                                                                           (const uint32_t*)d_scalars, mont, n,
                                                                           (Affine<F>*)d_out);

@@ -136,6 +136,53 @@ def test_scalar_mul_batch_kernel(curve, mlhip):
         assert out3.raw[i * c.g1_bytes : (i + 1) * c.g1_bytes] == cref.point_mul(c.id, 1, out.raw[i * c.g1_bytes : (i + 1) * c.g1_bytes], ks[i + 1])
 
 
+def test_fixed_base_table_path(curve, mlhip, monkeypatch):
+    """One base, many scalars: the table path (normally from 2^17 scalars on) forced at n = 300, against the oracle and
+    the double-and-add kernel -- scalars with zero bytes, 0, 1, r - 1, a base outside the r-torsion subgroup of G1
+    (the table must not reduce its multiples mod r) and the point at infinity as base."""
+    import ctypes
+
+    from oracle import cref
+    from oracle import pyref as R
+
+    c = curve
+    lib = mlhip.load()
+    n = 300
+    ks = [c._rng(c.r) for _ in range(n - 6)] + [0, 1, c.r - 1, 0xFF00FF << 40, 1 << 248, (1 << 200) + 5]
+    ks = [k % c.r for k in ks]
+    sc = b"".join(k.to_bytes(32, "little") for k in ks)
+    for group, base, size in ((1, c.GenG1().raw, c.g1_bytes), (2, c._gen_g2.raw, c.g2_bytes)):
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MLHIP_FIXED_BASE_MIN", mode)
+            out = ctypes.create_string_buffer(size * n)
+            mlhip.check(lib.mlhip_scalar_mul(c.id, group, base, 0, sc, 0, n, out))
+            outs[mode] = out.raw
+        assert outs["1"] == outs["0"]
+        for i in (0, 3, n - 6, n - 5, n - 4, n - 3, n - 2, n - 1):
+            assert outs["1"][i * size : (i + 1) * size] == cref.point_mul(c.id, group, base, ks[i])
+    # a curve point outside G1 (cofactor > 1 on the BLS curves): x = 1, 2, ... until x^3 + b is a square
+    cp = next(v for v in R.CURVES.values() if v.curve_id == c.id)
+    if cp.family == "BLS12":
+        x = 1
+        while True:
+            y = R.fp_sqrt((x * x * x + cp.b) % cp.p, cp.p)
+            if y is not None and R.g1_mul_unreduced(cp, (x, y), cp.r) is not None:
+                break
+            x += 1
+        base = R.g1_to_mont_bytes(cp, (x, y))
+        monkeypatch.setenv("MLHIP_FIXED_BASE_MIN", "1")
+        out = ctypes.create_string_buffer(c.g1_bytes * n)
+        mlhip.check(lib.mlhip_scalar_mul(c.id, 1, base, 0, sc, 0, n, out))
+        for i in (0, n - 4, n - 2, n - 1):
+            assert out.raw[i * c.g1_bytes : (i + 1) * c.g1_bytes] == R.g1_to_mont_bytes(cp, R.g1_mul_unreduced(cp, (x, y), ks[i]))
+    # infinity as base
+    monkeypatch.setenv("MLHIP_FIXED_BASE_MIN", "1")
+    out = ctypes.create_string_buffer(c.g1_bytes * n)
+    mlhip.check(lib.mlhip_scalar_mul(c.id, 1, bytes(c.g1_bytes), 0, sc, 0, n, out))
+    assert out.raw == bytes(c.g1_bytes * n)
+
+
 def test_runPowTest_gt_exp(curve):
     """math_test.go:390-421: e(g2, g1)^r == e(g2^r, g1) == e(g2, g1^r), through Gt.Exp"""
     c = curve

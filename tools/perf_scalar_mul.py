@@ -1,18 +1,55 @@
 #!/usr/bin/env python3
-"""Batched single-scalar multiplication (G1.Mul for many independent pairs), 2^20 points, one MI355X."""
-import os, sys, time, torch
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
-from conftest import load_golden
-from mathlib_amd import _lib
-lib=_lib.load(); dev=torch.device("cuda",0); st=torch.cuda.current_stream().cuda_stream
-gen=torch.Generator(device=dev); gen.manual_seed(1)
-rnd=lambda k: torch.randint(-(1<<63),(1<<63)-1,(k,4),dtype=torch.int64,generator=gen,device=dev).view(torch.uint8).reshape(k,32).contiguous()
-for name in ("BLS12-381","BN254"):
-    g=load_golden(name); cid=g["curve_id"]; fpb,g1b,g2b,gtb=_lib.sizes(cid); n=1<<20
-    base=torch.frombuffer(bytearray(bytes.fromhex(g["g1_gen"])),dtype=torch.uint8).to(dev)
-    P=torch.empty(n*g1b,dtype=torch.uint8,device=dev); S=rnd(n)
-    for _ in range(3):
-        torch.cuda.synchronize(); t0=time.perf_counter()
-        _lib.check(lib.mlhip_scalar_mul_device(cid,1,base.data_ptr(),0,S.data_ptr(),0,n,P.data_ptr(),st)); torch.cuda.synchronize()
-        dt=time.perf_counter()-t0
-    print(name,"batched G1 scalar mul 2^20: %.1f ms -> %.3e /s"%(dt*1e3,n/dt))
+"""Batched single-scalar multiplication (G1.Mul / G2.Mul for many scalars), one MI355X.
+One common base (stride 0): the fixed-base table path against the double-and-add kernel (MLHIP_FIXED_BASE_MIN=0);
+a base per scalar (stride 1): always double-and-add."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.getcwd())
+sys.path.insert(0, "tests")
+from conftest import load_golden  # noqa: E402
+from mathlib_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream().cuda_stream
+gen = torch.Generator(device=dev)
+gen.manual_seed(1)
+
+
+def rnd(k):
+    return torch.randint(-(1 << 63), (1 << 63) - 1, (k, 4), dtype=torch.int64, generator=gen, device=dev).view(torch.uint8).reshape(k, 32).contiguous()
+
+
+def timed(fn, reps=3):
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+for name in ("BLS12-381", "BN254", "BLS12-377"):
+    g = load_golden(name)
+    cid = g["curve_id"]
+    fpb, g1b, g2b, gtb = _lib.sizes(cid)
+    for group, size, key, lgs in ((1, g1b, "g1_gen", (17, 20)), (2, g2b, "g2_gen", (17, 20))):
+        base = torch.frombuffer(bytearray(bytes.fromhex(g[key])), dtype=torch.uint8).to(dev)
+        for lg in lgs:
+            n = 1 << lg
+            S = rnd(n)
+            P = torch.empty(n * size, dtype=torch.uint8, device=dev)
+            Q = torch.empty(n * size, dtype=torch.uint8, device=dev)
+            os.environ.pop("MLHIP_FIXED_BASE_MIN", None)
+            t_tab = timed(lambda: _lib.check(lib.mlhip_scalar_mul_device(cid, group, base.data_ptr(), 0, S.data_ptr(), 0, n, P.data_ptr(), st)))
+            os.environ["MLHIP_FIXED_BASE_MIN"] = "0"
+            t_dbl = timed(lambda: _lib.check(lib.mlhip_scalar_mul_device(cid, group, base.data_ptr(), 0, S.data_ptr(), 0, n, Q.data_ptr(), st)), reps=2)
+            print("%s G%d one base, 2^%d scalars: table path %.2f ms (%.3e /s) | double-and-add %.2f ms | same bytes: %s" % (
+                name, group, lg, t_tab * 1e3, n / t_tab, t_dbl * 1e3, bool(torch.equal(P, Q))), flush=True)
+    os.environ.pop("MLHIP_FIXED_BASE_MIN", None)
