@@ -237,11 +237,19 @@ int stream_segments(int group, size_t n, const mlhip_msm_plan* plan) {
 
 int tu_plan_stream(mlhip_msm_plan* p, void* d_pts, void* d_sc, const void* points, const void* scalars, int mont, size_t n,
                    int segments, hipStream_t st) {
+  int rc;
   switch (p->curve) {
-    case MLHIP_CURVE_BN254: return mlhip_tu_plan_stream_Bn254(p, d_pts, d_sc, points, scalars, mont, n, segments, st);
-    case MLHIP_CURVE_BLS12_381: return mlhip_tu_plan_stream_Bls381(p, d_pts, d_sc, points, scalars, mont, n, segments, st);
-    default: return mlhip_tu_plan_stream_Bls377(p, d_pts, d_sc, points, scalars, mont, n, segments, st);
+    case MLHIP_CURVE_BN254: rc = mlhip_tu_plan_stream_Bn254(p, d_pts, d_sc, points, scalars, mont, n, segments, st); break;
+    case MLHIP_CURVE_BLS12_381: rc = mlhip_tu_plan_stream_Bls381(p, d_pts, d_sc, points, scalars, mont, n, segments, st); break;
+    default: rc = mlhip_tu_plan_stream_Bls377(p, d_pts, d_sc, points, scalars, mont, n, segments, st); break;
   }
+  if (rc) {
+    // a failure part-way: copies from the caller's buffers may still be queued -- let them drain before the caller gets
+    // its memory back, and leave the plan reusable
+    (void)hipDeviceSynchronize();
+    p->pending = false;
+  }
+  return rc;
 }
 
 int msm_host_buffers(int curve, int group, const void* points, const void* scalars, int mont, size_t n, int window_c,
