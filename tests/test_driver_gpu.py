@@ -199,8 +199,12 @@ def test_runPowTest_gt_exp(curve):
     assert c.FExp(c.Pairing(g2, g1)).Exp(c.NewZrFromInt(0)).IsUnity()
 
 
-def test_gt_exp_batch_vs_oracle(curve, mlhip):
+@pytest.mark.parametrize("one_lane", ["0", "1"])
+def test_gt_exp_batch_vs_oracle(curve, mlhip, one_lane, monkeypatch):
+    """Gt.Exp batch on the lane-pair kernel (default) and on the one-lane kernel, against the Python tower."""
     import ctypes
+
+    monkeypatch.setenv("MLHIP_PAIRING_ONE_LANE", one_lane)
 
     from oracle import pyref as R
 
