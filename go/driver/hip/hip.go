@@ -52,6 +52,11 @@ var WindowC = 0
 // MinDeviceMSM: MultiScalarMul with fewer pairs stays on the embedded gurvy driver.
 var MinDeviceMSM = 32
 
+// MinDevicePairingBatch: PairingBatch with fewer pairs stays on the embedded gurvy driver.  Any batch up to 32 768
+// pairs costs one wave time on the device (about 14 ms on an MI355X, profiles/r01_perf_hostapi_pairing.txt); a CPU
+// core needs about a millisecond per pairing, so a few hundred pairs are where the device starts to win.
+var MinDevicePairingBatch = 256
+
 // DevicePairing: when false (default) the single-shot Pairing / Pairing2 / FExp stay on the embedded gurvy driver
 // and only the batched entry points (PairingBatch) use the GPU.  Mixing is safe: FExp of either Miller loop's
 // output is the same canonical Gt (SURVEY.md section 8c).
@@ -168,6 +173,13 @@ func (c *Curve) PairingBatch(g2s []driver.G2, g1s []driver.G1) []driver.Gt {
 	}
 	if n == 0 {
 		return nil
+	}
+	if n < MinDevicePairingBatch {
+		out := make([]driver.Gt, n)
+		for i := range g1s {
+			out[i] = c.Curve.FExp(c.Curve.Pairing(g2s[i], g1s[i]))
+		}
+		return out
 	}
 	p := make([]bls12381.G1Affine, n)
 	q := make([]bls12381.G2Affine, n)

@@ -57,6 +57,9 @@ func TestHipDevicePaths(t *testing.T) {
 
 	DevicePairing = true
 	defer func() { DevicePairing = false }()
+	minBatch := MinDevicePairingBatch
+	MinDevicePairingBatch = 1 // the 64-pair batch below must reach the device
+	defer func() { MinDevicePairingBatch = minBatch }()
 	r := gurvy.NewRandomZr(rng)
 	p := gurvy.GenG1.Mul(r)
 	q := gurvy.GenG2.Mul(r)
