@@ -149,7 +149,7 @@ int mlhip_bases_create(int curve, int group, const void* points, size_t n, int w
 int mlhip_bases_msm(mlhip_bases* bases, const void* scalars, int scalars_mont, size_t n, void* out_affine);
 int mlhip_bases_destroy(mlhip_bases* bases);
 
-/* The host-buffer MSM entry points above keep up to four plans + input buffers alive between calls (creating and
+/* The host-buffer MSM entry points above keep up to 16 plans + input buffers (at most 32 GB) alive between calls (creating and
  * destroying them costs as much as a 2^20-point MSM); this frees the idle ones.  MLHIP_NO_PLAN_CACHE=1 disables the pool. */
 int mlhip_release_cache(void);
 

@@ -125,7 +125,8 @@ int pairing_host(int curve, int what, const void* g1, const void* g2, size_t ppp
 // The reference's MultiScalarMul takes fresh host slices per call; creating and, above all, destroying a plan
 // (a dozen hipFree's, ~2.5 ms) and the input buffers per call cost as much as the kernels of a 2^20-point MSM.
 // Entries are reused across calls and threads when curve / group / window / device match and the size fits
-// (capacity between n and 4 n).  At most POOL_MAX entries stay allocated (~0.6 GB each at n = 2^20);
+// (capacity between n and 4 n).  At most POOL_MAX entries and POOL_MAX_BYTES of device memory stay allocated (an entry
+// is ~0.6 GB at n = 2^20, ~10 GB at 2^24; many goroutines with small MSMs each find their own entry);
 // MLHIP_NO_PLAN_CACHE=1 disables the pool, mlhip_release_cache() empties it.
 struct PoolEntry {
   mlhip_msm_plan* plan = nullptr;
@@ -135,8 +136,10 @@ struct PoolEntry {
   size_t cap = 0;
   bool busy = false, pooled = false;
   unsigned long stamp = 0;
+  size_t bytes = 0;  // device memory the entry took (free memory before - after its creation)
 };
-constexpr size_t POOL_MAX = 4;
+constexpr size_t POOL_MAX = 16;
+constexpr size_t POOL_MAX_BYTES = (size_t)32 << 30;
 std::mutex g_pool_mu;
 std::vector<PoolEntry*> g_pool;
 unsigned long g_pool_clock = 0;
@@ -153,7 +156,7 @@ void pool_free_entry(PoolEntry* e) {
 PoolEntry* pool_acquire(int curve, int group, int c, size_t n, size_t ptsz, int& rc) {
   const char* off = getenv("MLHIP_NO_PLAN_CACHE");
   const bool use_pool = !(off && off[0] == '1');
-  PoolEntry* victim = nullptr;
+  std::vector<PoolEntry*> victims;
   if (use_pool) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (PoolEntry* e : g_pool)
@@ -163,17 +166,22 @@ PoolEntry* pool_acquire(int curve, int group, int c, size_t n, size_t ptsz, int&
         e->stamp = ++g_pool_clock;
         return e;
       }
-    if (g_pool.size() >= POOL_MAX) {  // evict the least recently used idle entry
+    // evict least recently used idle entries while the pool is full or over its memory budget
+    for (;;) {
+      size_t total = 0;
+      for (PoolEntry* e : g_pool) total += e->bytes;
+      if (g_pool.size() < POOL_MAX && total <= POOL_MAX_BYTES) break;
       size_t vi = g_pool.size();
       for (size_t i = 0; i < g_pool.size(); i++)
         if (!g_pool[i]->busy && (vi == g_pool.size() || g_pool[i]->stamp < g_pool[vi]->stamp)) vi = i;
-      if (vi < g_pool.size()) {
-        victim = g_pool[vi];
-        g_pool.erase(g_pool.begin() + vi);
-      }
+      if (vi == g_pool.size()) break;  // everything is in use
+      victims.push_back(g_pool[vi]);
+      g_pool.erase(g_pool.begin() + vi);
     }
   }
-  if (victim) pool_free_entry(victim);
+  for (PoolEntry* v : victims) pool_free_entry(v);
+  size_t free_before = 0, free_after = 0, total_mem = 0;
+  (void)hipMemGetInfo(&free_before, &total_mem);
   PoolEntry* e = new PoolEntry();
   e->curve = curve;
   e->group = group;
@@ -181,15 +189,28 @@ PoolEntry* pool_acquire(int curve, int group, int c, size_t n, size_t ptsz, int&
   e->device = g_device;
   e->cap = n;
   e->busy = true;
-  rc = mlhip_msm_plan_create(curve, group, n, c, &e->plan);
-  if (!rc && (hipMalloc(&e->d_pts, n * ptsz) != hipSuccess || hipMalloc(&e->d_sc, n * 32) != hipSuccess))
-    rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of MSM inputs failed");
+  for (int attempt = 0;; attempt++) {
+    rc = mlhip_msm_plan_create(curve, group, n, c, &e->plan);
+    if (!rc && (hipMalloc(&e->d_pts, n * ptsz) != hipSuccess || hipMalloc(&e->d_sc, n * 32) != hipSuccess))
+      rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of MSM inputs failed");
+    if (!rc || attempt == 1 || !use_pool) break;
+    // out of device memory with idle entries pooled: give them back and try once more
+    if (e->d_pts) (void)hipFree(e->d_pts);
+    if (e->d_sc) (void)hipFree(e->d_sc);
+    if (e->plan) mlhip_msm_plan_destroy(e->plan);
+    e->d_pts = e->d_sc = nullptr;
+    e->plan = nullptr;
+    (void)hipGetLastError();
+    mlhip_release_cache();
+  }
   if (!rc && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     rc = mlhip_rt::fail(MLHIP_EHIP, "hipStreamCreate failed");
   if (rc) {
     pool_free_entry(e);
     return nullptr;
   }
+  (void)hipMemGetInfo(&free_after, &total_mem);
+  e->bytes = free_before > free_after ? free_before - free_after : 0;
   if (use_pool) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (g_pool.size() < POOL_MAX) {

@@ -537,6 +537,22 @@ def test_plan_pool_reuse_and_release(lib, mlhip):
             assert lib.mlhip_release_cache() == 0
 
 
+def test_plan_pool_eviction(lib, mlhip):
+    """More distinct (curve, window) shapes than the pool holds (16): the least recently used entries are evicted and
+    rebuilt on demand; every call still returns the golden result."""
+    shapes = [(curve, c) for c in (5, 6, 7, 8, 9, 10, 11) for curve in CURVES]  # 21 shapes
+    for rnd in range(2):
+        for curve, c in shapes:
+            g = load_golden(curve)
+            cid = g["curve_id"]
+            fpb, g1b, _, _ = mlhip.sizes(cid)
+            pts, scs, exp = load_msm1000(curve, fpb)
+            out = ctypes.create_string_buffer(g1b)
+            mlhip.check(lib.mlhip_msm_g1(cid, pts, scs, 0, 1000, c, out))
+            assert out.raw == exp, (curve, c, rnd)
+    assert lib.mlhip_release_cache() == 0
+
+
 def test_concurrent_callers(lib, mlhip):
     """the entry points are called from many OS threads at once (cgo).  Eight threads run
     MSMs and pairing batches on different curves concurrently; every result must match its golden."""
