@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <type_traits>
@@ -788,6 +789,14 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
 constexpr int FB_WINDOWS = 32, FB_ROW = 255;
 constexpr size_t FIXED_BASE_MIN = (size_t)1 << 16;  // the table costs one double-and-add wave time (G1 ~4 ms, G2 ~14 ms)
 
+struct FixedBaseScratch {
+  char* buf = nullptr;
+  size_t cap = 0;
+  hipEvent_t last = nullptr;  // recorded after the last kernel that reads the buffer
+};
+static std::mutex g_fb_mu;
+static FixedBaseScratch g_fb[64];  // per device
+
 static __global__ void __launch_bounds__(256) k_fb_scalars(uint32_t* __restrict__ out) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= FB_WINDOWS * FB_ROW) return;
@@ -854,11 +863,28 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
   if (point_stride == 0 && n >= fb_min) {
     constexpr size_t kEntries = (size_t)FB_WINDOWS * FB_ROW;
     constexpr bool kG1 = std::is_same<F, FpField<C>>::value;
-    // stream-ordered scratch: [table | its 8160 scalars | (G1) the table in the carry-free form]
+    // scratch: [table | its 8160 scalars | (G1) the table in the carry-free form] in one persistent buffer per device.
+    // Calls on different streams reuse it in the order they take the lock: each waits for the event the previous
+    // one recorded after its last kernel.  (hipMallocAsync here gave intermittently wrong results on this runtime.)
     const size_t tab_bytes = kEntries * sizeof(Affine<F>), sc_bytes = kEntries * 32;
     const size_t t28_bytes = kG1 ? kEntries * sizeof(Affine28<C>) : 0;
-    char* scratch = nullptr;
-    HIPCHK(hipMallocAsync((void**)&scratch, tab_bytes + sc_bytes + t28_bytes, st));
+    const size_t need = tab_bytes + sc_bytes + t28_bytes;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_fb_mu);
+    FixedBaseScratch& fb = g_fb[dev & 63];
+    if (need > fb.cap) {
+      if (fb.buf) HIPCHK(hipFree(fb.buf));  // waits for the device: no earlier user is still reading it
+      fb.buf = nullptr;
+      fb.cap = 0;
+      HIPCHK(hipMalloc((void**)&fb.buf, need));
+      fb.cap = need;
+    }
+    if (!fb.last)
+      HIPCHK(hipEventCreateWithFlags(&fb.last, hipEventDisableTiming));
+    else
+      HIPCHK(hipStreamWaitEvent(st, fb.last, 0));
+    char* scratch = fb.buf;
     Affine<F>* table = (Affine<F>*)scratch;
     uint32_t* tsc = (uint32_t*)(scratch + tab_bytes);
     k_fb_scalars<<<dim3((unsigned)((kEntries + 255) / 256)), dim3(256), 0, st>>>(tsc);
@@ -874,7 +900,7 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
                                                                              (Affine<F>*)d_out);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipFreeAsync(scratch, st));
+    HIPCHK(hipEventRecord(fb.last, st));
     return 0;
   }
   k_scalar_mul<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, point_stride,
