@@ -6,7 +6,8 @@
 //   k_points_to28 / k_accumulate28      G1: points into the carry-free form (fp28.h), one thread per bucket:
 //                 XYZZ += points[idx] (mixed additions, gathered reads); k_accumulate is the boundary-form variant
 //   k_points_to28_g2 / k_accumulate28_lp / k_accumulate_lp   G2: two lanes per bucket (one Fp2 component each)
-//   k_accumulate_big  buckets longer than the threshold: one workgroup each, LDS tree (degenerate inputs)
+//   k_big_prefix / k_big_slices / k_accumulate_big  buckets longer than the threshold (skewed scalars): slices of 4096
+//                 entries, one workgroup per slice (LDS tree), then the slice sums of each bucket
 //   k_chunks_q / k_masked_sums_q   G1 bucket reduction, one point per quad of lanes (ec_quad.h): per 16 consecutive
 //                 buckets sum and locally weighted sum, then per window the plain / bit-masked sums of the chunk sums
 //                 (k_chunks / k_masked_sums: one lane per point; *_lp: G2 lane pairs)
@@ -459,27 +460,112 @@ __device__ void block_tree_sum(XYZZ<F>* sh, const XYZZ<F>& mine) {
   }
 }
 
+// ---- long buckets (skewed scalars: small values, equal values, plain sums of points) ---------------------------
+// A bucket above the threshold is cut into slices of BIG_SLICE entries; k_big_slices sums every slice with one
+// workgroup (so one bucket holding all n points still fills the GPU: 2^20 entries = 256 slices), the combine kernels
+// (k_accumulate_big and its segment variants) add the slice sums of a bucket and store / fold the result.
+constexpr uint32_t BIG_SLICE = 4096;
+
+// prefix[i] = number of slices of the long buckets before entry i of big_list; prefix[nbig] = total
+static __global__ void __launch_bounds__(1024) k_big_prefix(const uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ big_list,
+                                                            const uint32_t* __restrict__ big_count,
+                                                            uint32_t* __restrict__ prefix) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t base;
+  const uint32_t nbig = *big_count, tid = threadIdx.x;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (uint32_t c0 = 0; c0 < nbig; c0 += 1024) {
+    const uint32_t i = c0 + tid;
+    const uint32_t v = i < nbig ? (counts[big_list[i]] + BIG_SLICE - 1) / BIG_SLICE : 0u;
+    part[tid] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+      const uint32_t t = tid >= d ? part[tid - d] : 0u;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    if (i < nbig) prefix[i] = base + part[tid] - v;
+    __syncthreads();
+    if (tid == 1023) base += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) prefix[nbig] = base;
+}
+
 template <class F, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_accumulate_big(const Affine<F>* __restrict__ points,
-                                                          const uint32_t* __restrict__ sorted,
-                                                          const uint32_t* __restrict__ offsets,
-                                                          const uint32_t* __restrict__ counts,
-                                                          const uint32_t* __restrict__ big_list,
+__global__ void __launch_bounds__(BLOCK) k_big_slices(const Affine<F>* __restrict__ points,
+                                                      const uint32_t* __restrict__ sorted,
+                                                      const uint32_t* __restrict__ offsets,
+                                                      const uint32_t* __restrict__ counts,
+                                                      const uint32_t* __restrict__ big_list,
+                                                      const uint32_t* __restrict__ big_count,
+                                                      const uint32_t* __restrict__ prefix, XYZZ<F>* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  __shared__ uint32_t s_bi;
+  const uint32_t nbig = *big_count;
+  if (nbig == 0) return;
+  const uint32_t total = prefix[nbig];
+  for (uint32_t sid = blockIdx.x; sid < total; sid += gridDim.x) {
+    if (threadIdx.x == 0) {  // the bucket this slice belongs to: last entry with prefix <= sid
+      uint32_t lo = 0, hi = nbig - 1;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (prefix[mid] <= sid)
+          lo = mid;
+        else
+          hi = mid - 1;
+      }
+      s_bi = lo;
+    }
+    __syncthreads();
+    const uint32_t bi = s_bi;
+    const uint32_t g = big_list[bi];
+    const size_t first = offsets[g], last = first + counts[g];
+    const size_t begin = first + (size_t)(sid - prefix[bi]) * BIG_SLICE;
+    const size_t end = begin + BIG_SLICE < last ? begin + BIG_SLICE : last;
+    XYZZ<F> acc;
+    xyzz_set_inf<F>(acc);
+    msm_accumulate_range<F>(acc, points, sorted, begin + threadIdx.x, end, BLOCK);
+    block_tree_sum<F, BLOCK>(sh, acc);
+    if (threadIdx.x == 0) partials[sid] = sh[0];
+    __syncthreads();
+  }
+}
+
+// sum of the slice sums of long bucket number bi, valid on thread 0 (all threads must call)
+template <class F, int BLOCK>
+__device__ void big_bucket_total(XYZZ<F>& sum, XYZZ<F>* sh, const XYZZ<F>* __restrict__ partials,
+                                 const uint32_t* __restrict__ prefix, uint32_t bi) {
+  const uint32_t s0 = prefix[bi], s1 = prefix[bi + 1];
+  if (s1 - s0 == 1) {  // the usual case: a bucket just above the threshold
+    if (threadIdx.x == 0) sum = partials[s0];
+    return;
+  }
+  XYZZ<F> acc;
+  xyzz_set_inf<F>(acc);
+  for (uint32_t k = s0 + threadIdx.x; k < s1; k += BLOCK) xyzz_add_ool<F>(acc, partials[k]);
+  block_tree_sum<F, BLOCK>(sh, acc);
+  if (threadIdx.x == 0) sum = sh[0];
+  __syncthreads();
+}
+
+template <class F, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_accumulate_big(const uint32_t* __restrict__ big_list,
                                                           const uint32_t* __restrict__ big_count,
+                                                          const uint32_t* __restrict__ prefix,
+                                                          const XYZZ<F>* __restrict__ partials,
                                                           XYZZ<F>* __restrict__ buckets) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
   const uint32_t nbig = *big_count;
   for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
-    uint32_t g = big_list[bi];
-    size_t begin = offsets[g];
-    size_t end = begin + counts[g];
-    XYZZ<F> acc;
-    xyzz_set_inf<F>(acc);
-    msm_accumulate_range<F>(acc, points, sorted, begin + threadIdx.x, end, BLOCK);
-    block_tree_sum<F, BLOCK>(sh, acc);
-    if (threadIdx.x == 0) buckets[g] = sh[0];
-    __syncthreads();
+    XYZZ<F> sum;
+    big_bucket_total<F, BLOCK>(sum, sh, partials, prefix, bi);
+    if (threadIdx.x == 0) buckets[big_list[bi]] = sum;
   }
 }
 
@@ -546,14 +632,12 @@ __global__ void __launch_bounds__(256) k_accumulate28_seg(const Affine28<C>* __r
   }
 }
 
-// the long buckets of a segment: workgroup sum in the boundary form, then state <- state + sum (thread 0)
+// the long buckets of a segment: total of the slice sums (boundary form), then state <- state + total (thread 0)
 template <class C, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg(const Affine<FpField<C>>* __restrict__ points,
-                                                              const uint32_t* __restrict__ sorted,
-                                                              const uint32_t* __restrict__ offsets,
-                                                              const uint32_t* __restrict__ counts,
-                                                              const uint32_t* __restrict__ big_list,
+__global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg(const uint32_t* __restrict__ big_list,
                                                               const uint32_t* __restrict__ big_count,
+                                                              const uint32_t* __restrict__ prefix,
+                                                              const XYZZ<FpField<C>>* __restrict__ partials,
                                                               XYZZ28<C>* __restrict__ state, int flags,
                                                               XYZZ<FpField<C>>* __restrict__ buckets) {
   typedef FpField<C> F;
@@ -562,15 +646,10 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg(const Affine<FpFie
   const uint32_t nbig = *big_count;
   const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
   for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
-    uint32_t g = big_list[bi];
-    size_t begin = offsets[g];
-    size_t end = begin + counts[g];
-    XYZZ<F> acc;
-    xyzz_set_inf<F>(acc);
-    msm_accumulate_range<F>(acc, points, sorted, begin + threadIdx.x, end, BLOCK);
-    block_tree_sum<F, BLOCK>(sh, acc);
+    const uint32_t g = big_list[bi];
+    XYZZ<F> sum;
+    big_bucket_total<F, BLOCK>(sum, sh, partials, prefix, bi);
     if (threadIdx.x == 0) {
-      XYZZ<F> sum = sh[0];
       if (!first) {
         XYZZ28<C> s28 = state[g];
         XYZZ<F> prev;
@@ -1148,12 +1227,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 template <class C, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_g2(const Affine<Fp2Field<C>>* __restrict__ points,
-                                                                 const uint32_t* __restrict__ sorted,
-                                                                 const uint32_t* __restrict__ offsets,
-                                                                 const uint32_t* __restrict__ counts,
-                                                                 const uint32_t* __restrict__ big_list,
+__global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_g2(const uint32_t* __restrict__ big_list,
                                                                  const uint32_t* __restrict__ big_count,
+                                                                 const uint32_t* __restrict__ prefix,
+                                                                 const XYZZ<Fp2Field<C>>* __restrict__ partials,
                                                                  XYZZ28L<Fp28<C>>* __restrict__ state, int flags,
                                                                  XYZZ<Fp2Field<C>>* __restrict__ buckets) {
   typedef Fp2Field<C> F;
@@ -1162,15 +1239,10 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_g2(const Affine<Fp
   const uint32_t nbig = *big_count;
   const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
   for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
-    uint32_t g = big_list[bi];
-    size_t begin = offsets[g];
-    size_t end = begin + counts[g];
-    XYZZ<F> acc;
-    xyzz_set_inf<F>(acc);
-    msm_accumulate_range<F>(acc, points, sorted, begin + threadIdx.x, end, BLOCK);
-    block_tree_sum<F, BLOCK>(sh, acc);
+    const uint32_t g = big_list[bi];
+    XYZZ<F> sum;
+    big_bucket_total<F, BLOCK>(sum, sh, partials, prefix, bi);
     if (threadIdx.x == 0) {
-      XYZZ<F> sum = sh[0];
       if (!first) {
         const XYZZ28L<Fp28<C>> lo = state[2 * g], up = state[2 * g + 1];
         if (!(fp28_all_zero<C>(lo.zz) && fp28_all_zero<C>(up.zz))) {
@@ -1323,6 +1395,13 @@ int plan_alloc(mlhip_msm_plan* p) {
   }
   HIPCHK(hipMalloc(&p->d_offsets, nbuckets * 4));
   HIPCHK(hipMalloc(&p->d_biglist, nbuckets * 4));
+  {
+    // long buckets: at most W n / BIG_BUCKET_MIN of them, and W n / BIG_SLICE + one more slice per bucket
+    const size_t entries = (size_t)p->W * p->max_n;
+    const size_t nbig_max = std::min(nbuckets, entries / BIG_BUCKET_MIN + 1);
+    HIPCHK(hipMalloc(&p->d_bigprefix, (nbig_max + 2) * 4));
+    HIPCHK(hipMalloc(&p->d_bigpart, (entries / BIG_SLICE + nbig_max + 2) * p->xyzz_size));
+  }
   HIPCHK(hipMalloc(&p->d_order, nbuckets * 4));
   {
     const size_t nblk = (nbuckets + 255) / 256;
@@ -1397,6 +1476,16 @@ void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
       started = true;
     }
   }
+}
+
+// slice sums of the long buckets listed by the accumulation kernel (nothing to do, two near-empty launches, when
+// there are none)
+template <class F, int BB>
+void launch_big_slices(mlhip_msm_plan* p, const Affine<F>* d_points, hipStream_t st) {
+  k_big_prefix<<<dim3(1), dim3(1024), 0, st>>>(p->d_counts, p->d_biglist, p->d_bigcount, p->d_bigprefix);
+  k_big_slices<F, BB><<<dim3(1024), dim3(BB), BB * sizeof(XYZZ<F>), st>>>(d_points, p->d_sorted, p->d_offsets, p->d_counts,
+                                                                        p->d_biglist, p->d_bigcount, p->d_bigprefix,
+                                                                        (XYZZ<F>*)p->d_bigpart);
 }
 
 // digits -> entries sorted by (window, bucket) in d_sorted / d_offsets / d_counts, and the bucket order by population
@@ -1556,9 +1645,9 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     if (prof) HIPCHK(hipEventRecord(p->ev[3], st));
     {
       constexpr int BB = sizeof(X) <= 192 ? 256 : 128;  // 48 KB of LDS per block
-      k_accumulate_big<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>((const A*)d_points, p->d_sorted,
-                                                                            p->d_offsets, p->d_counts, p->d_biglist,
-                                                                            p->d_bigcount, (X*)p->d_buckets);
+      launch_big_slices<F, BB>(p, (const A*)d_points, st);
+      k_accumulate_big<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
+                                                                            (const X*)p->d_bigpart, (X*)p->d_buckets);
     }
     {
       int rc_red = launch_reduce<C, F>(p, st);
@@ -1632,16 +1721,18 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
           (const AffineG2_28<C>*)p->d_points28 + off, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
           big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
       constexpr int BB = 128;
+      launch_big_slices<F, BB>(p, dpt, st);
       k_accumulate_big_seg_g2<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
-          dpt, p->d_sorted, p->d_offsets, p->d_counts, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags,
+          p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28L<Fp28<C>>*)p->d_state28, flags,
           (X*)p->d_buckets);
     } else {
       k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
           (const Affine28<C>*)p->d_points28 + off, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
           big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
       constexpr int BB = 256;
+      launch_big_slices<F, BB>(p, dpt, st);
       k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
-          dpt, p->d_sorted, p->d_offsets, p->d_counts, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags,
+          p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28, flags,
           (X*)p->d_buckets);
     }
   }

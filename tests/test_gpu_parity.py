@@ -283,6 +283,42 @@ def test_msm_g1_skewed_distributions(lib, mlhip, curve, segments, monkeypatch):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_msm_long_buckets_in_slices(lib, mlhip, curve, monkeypatch):
+    """Buckets far above the slice length (4096 entries): all scalars one (a plain sum of points: one bucket of n
+    entries), scalars below 2^16 with the carry bucket of the next window, G2 with equal scalars -- in one pass and
+    streamed in segments (each segment's long bucket is folded into the kept state)."""
+    import numpy as np
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, g1b, g2b, _ = mlhip.sizes(cid)
+    n = 40000
+    pts = cref.gen_points(cid, 1, 31415, 9265, n)
+    ones = np.zeros((n, 4), dtype=np.uint64)
+    ones[:, 0] = 1
+    small = _rand_scalars(n, 77, 252)
+    small[:, 1:] = 0
+    small[:, 0] &= np.uint64(0xFFFF)
+    for name, sc in (("ones", ones), ("below_2_16", small)):
+        exp = cref.msm(cid, 1, pts, sc, n, False, 0, 8)
+        for segs in ("0", "3"):
+            monkeypatch.setenv("MLHIP_STREAM_SEGMENTS", segs)
+            out = ctypes.create_string_buffer(g1b)
+            mlhip.check(lib.mlhip_msm_g1(cid, pts, sc.tobytes(), 0, n, 16, out))
+            assert out.raw == exp, (curve, name, segs)
+    n2 = 10000
+    pts2 = cref.gen_points(cid, 2, 2718, 2818, n2)
+    sc2 = np.tile(_rand_scalars(1, 78, 252), (n2, 1))
+    exp2 = cref.msm(cid, 2, pts2, sc2, n2, False, 0, 8)
+    for segs in ("0", "2"):
+        monkeypatch.setenv("MLHIP_STREAM_SEGMENTS", segs)
+        out = ctypes.create_string_buffer(g2b)
+        mlhip.check(lib.mlhip_msm_g2(cid, pts2, sc2.tobytes(), 0, n2, 16, out))
+        assert out.raw == exp2, (curve, "g2_all_equal", segs)
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_pairing_batch_random_vs_cref(lib, mlhip, curve):
     from oracle import cref
 
