@@ -474,7 +474,7 @@ int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->device);
   void* ptrs[] = {p->d_digits, p->d_sorted, p->d_zero, p->d_offsets, p->d_biglist, p->d_buckets, p->d_A, p->d_W0, p->d_out,
-                  p->d_order, p->d_hist, p->d_tilesums, p->d_coarse_off, p->d_points28, p->d_blockhist, p->d_state28, p->d_bigprefix, p->d_bigpart};
+                  p->d_order, p->d_hist, p->d_tilesums, p->d_coarse_off, p->d_points28, p->d_blockhist, p->d_state28, p->d_bigprefix, p->d_bigpart, p->d_binprefix};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (p->h_out) (void)hipHostFree(p->h_out);

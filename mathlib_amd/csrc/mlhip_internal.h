@@ -34,6 +34,7 @@ struct mlhip_msm_plan {
   size_t zero_bytes = 0;
   void *d_buckets = nullptr, *d_A = nullptr, *d_W0 = nullptr, *d_out = nullptr;
   void* h_out = nullptr;
+  uint32_t* d_binprefix = nullptr;  // coarse bins sorted by several workgroups: slice prefix
   uint32_t* d_bigprefix = nullptr;  // long buckets: slice counts (prefix) and slice sums
   void* d_bigpart = nullptr;
   void* d_points28 = nullptr;  // G1: the points in the carry-free 28-bit-limb form (ec28.h), rewritten every MSM

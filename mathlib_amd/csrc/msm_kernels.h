@@ -245,13 +245,14 @@ __global__ void __launch_bounds__(256) k_coarse_scatter(const uint32_t* __restri
 
 static __global__ void __launch_bounds__(256) k_fine_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ coarse_off,
                                                    const uint32_t* __restrict__ coarse_count, int c, int low, int idx_bits,
-                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                   uint32_t* __restrict__ sorted) {
+                                                   uint32_t big_bin, uint32_t* __restrict__ counts,
+                                                   uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t fo[256];
   const uint32_t bin = blockIdx.x;
   const uint32_t F = 1u << low;
   const uint32_t begin = coarse_off[bin], cnt = coarse_count[bin];
+  if (cnt > big_bin) return;  // sorted by several workgroups: k_bigbin_hist / k_bigbin_place
   const uint32_t idx_mask = (1u << idx_bits) - 1u;
   hist[threadIdx.x] = 0;
   __syncthreads();
@@ -300,6 +301,143 @@ static __global__ void __launch_bounds__(256) k_fine_sort(const uint32_t* __rest
 #pragma unroll
     for (int j = 0; j < 4; j++)
       if (pos[j] != 0xFFFFFFFFu) sorted[pos[j]] = (e[j] & idx_mask) | (((e[j] >> idx_bits) & 1u) << 31);
+  }
+}
+
+// ---- coarse bins far above the mean (skewed scalars put half of all entries into one bin) ------------------------
+// k_fine_sort gives a bin to ONE workgroup; a bin of 2^20 entries then takes milliseconds.  Bins above `big_bin` are
+// cut into slices of BIGBIN_SLICE entries: k_bigbin_hist counts the fine buckets per slice into the global bucket
+// counts, k_bigbin_place ranks every slice inside the bucket ranges (one global atomic per slice and fine bucket,
+// LDS ranks inside the slice).  Lanes of a wave that hold the same fine bucket -- the usual case in such a bin --
+// share one LDS atomic.
+constexpr uint32_t BIGBIN_SLICE = 16384;
+
+static __global__ void __launch_bounds__(1024) k_bigbin_prefix(const uint32_t* __restrict__ coarse_count, uint32_t NB,
+                                                               uint32_t big_bin, uint32_t* __restrict__ prefix) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t base;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (uint32_t c0 = 0; c0 < NB; c0 += 1024) {
+    const uint32_t i = c0 + tid;
+    const uint32_t cnt = i < NB ? coarse_count[i] : 0u;
+    const uint32_t v = cnt > big_bin ? (cnt + BIGBIN_SLICE - 1) / BIGBIN_SLICE : 0u;
+    part[tid] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+      const uint32_t t = tid >= d ? part[tid - d] : 0u;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    if (i < NB) prefix[i] = base + part[tid] - v;
+    __syncthreads();
+    if (tid == 1023) base += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) prefix[NB] = base;
+}
+
+// rank of this lane's entry among the entries of fine bucket f handled so far by the block (LDS counter cnt[f]);
+// one atomic per wave when all active lanes hold the same f
+__device__ __forceinline__ uint32_t lds_rank(uint32_t* cnt, uint32_t f) {
+  const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+  const unsigned long long active = __ballot(1);
+  const unsigned long long same = __ballot(f == f0);
+  if (same == active) {
+    const uint32_t lane = __lane_id();
+    const uint32_t below = (uint32_t)__popcll(active & ((1ull << lane) - 1ull));
+    uint32_t b = 0;
+    if (below == 0) b = atomicAdd(&cnt[f0], (uint32_t)__popcll(active));
+    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    return b + below;
+  }
+  return atomicAdd(&cnt[f], 1u);
+}
+
+// slice -> (bin, first entry, end) by binary search in the slice prefix; false when the slice id is past the end
+__device__ __forceinline__ bool bigbin_slice(uint32_t sid, const uint32_t* __restrict__ prefix, uint32_t NB,
+                                             const uint32_t* __restrict__ coarse_off,
+                                             const uint32_t* __restrict__ coarse_count, uint32_t& bin, uint32_t& begin,
+                                             uint32_t& end, uint32_t& bin_begin) {
+  uint32_t lo = 0, hi = NB - 1;
+  while (lo < hi) {  // last bin with prefix <= sid (bins without slices share their successor's prefix)
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= sid)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  bin = lo;
+  bin_begin = coarse_off[bin];
+  const uint32_t cnt = coarse_count[bin];
+  begin = bin_begin + (sid - prefix[bin]) * BIGBIN_SLICE;
+  end = begin + BIGBIN_SLICE < bin_begin + cnt ? begin + BIGBIN_SLICE : bin_begin + cnt;
+  return true;
+}
+
+static __global__ void __launch_bounds__(256) k_bigbin_hist(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ coarse_off,
+                                                            const uint32_t* __restrict__ coarse_count,
+                                                            const uint32_t* __restrict__ prefix, uint32_t NB, int low,
+                                                            int idx_bits, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t hist[256];
+  const uint32_t total = prefix[NB];
+  for (uint32_t sid = blockIdx.x; sid < total; sid += gridDim.x) {
+    uint32_t bin, begin, end, bin_begin;
+    bigbin_slice(sid, prefix, NB, coarse_off, coarse_count, bin, begin, end, bin_begin);
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t k = begin + threadIdx.x; k < end; k += 256) (void)lds_rank(hist, tmp[k] >> (idx_bits + 1));
+    __syncthreads();
+    const uint32_t h = hist[threadIdx.x];
+    if (threadIdx.x < (1u << low) && h) atomicAdd(&counts[((size_t)bin << low) + threadIdx.x], h);
+    __syncthreads();
+  }
+}
+
+static __global__ void __launch_bounds__(256) k_bigbin_place(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ coarse_off,
+                                                             const uint32_t* __restrict__ coarse_count,
+                                                             const uint32_t* __restrict__ prefix, uint32_t NB, int low,
+                                                             int idx_bits, const uint32_t* __restrict__ counts,
+                                                             uint32_t* __restrict__ cursor, uint32_t* __restrict__ offsets,
+                                                             uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t hist[256];  // this slice's count per fine bucket, then the running rank
+  __shared__ uint32_t fo[256];    // start of the bucket inside the bin, then this slice's reserved start
+  const uint32_t total = prefix[NB];
+  const uint32_t F = 1u << low;
+  const uint32_t idx_mask = (1u << idx_bits) - 1u;
+  for (uint32_t sid = blockIdx.x; sid < total; sid += gridDim.x) {
+    uint32_t bin, begin, end, bin_begin;
+    bigbin_slice(sid, prefix, NB, coarse_off, coarse_count, bin, begin, end, bin_begin);
+    const size_t g = ((size_t)bin << low) + threadIdx.x;
+    // exclusive scan of the bin's (complete) bucket counts: where each bucket starts
+    const uint32_t mine = threadIdx.x < F ? counts[g] : 0u;
+    fo[threadIdx.x] = mine;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+      const uint32_t x = threadIdx.x >= off ? fo[threadIdx.x - off] : 0;
+      __syncthreads();
+      fo[threadIdx.x] += x;
+      __syncthreads();
+    }
+    const uint32_t start = bin_begin + fo[threadIdx.x] - mine;
+    if (threadIdx.x < F && sid == prefix[bin]) offsets[g] = start;  // the bin's first slice publishes the offsets
+    // this slice's counts, then one reservation per fine bucket
+    for (uint32_t k = begin + threadIdx.x; k < end; k += 256) (void)lds_rank(hist, tmp[k] >> (idx_bits + 1));
+    __syncthreads();
+    const uint32_t h = hist[threadIdx.x];
+    fo[threadIdx.x] = (threadIdx.x < F && h) ? start + atomicAdd(&cursor[g], h) : 0u;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t k = begin + threadIdx.x; k < end; k += 256) {
+      const uint32_t e = tmp[k];
+      const uint32_t f = e >> (idx_bits + 1);
+      const uint32_t pos = fo[f] + lds_rank(hist, f);
+      sorted[pos] = (e & idx_mask) | (((e >> idx_bits) & 1u) << 31);
+    }
+    __syncthreads();
   }
 }
 
@@ -1388,6 +1526,7 @@ int plan_alloc(mlhip_msm_plan* p) {
   p->d_coarse_count = p->d_zero + 2 * nbuckets + 4;
   p->d_coarse_cursor = p->d_coarse_count + p->sort_nb;
   HIPCHK(hipMalloc(&p->d_coarse_off, ((size_t)p->sort_nb + 1) * 4));
+  HIPCHK(hipMalloc(&p->d_binprefix, ((size_t)p->sort_nb + 2) * 4));
   if (p->sort_nb) {
     static_assert(SORT_TILE < 65536, "a block puts at most one entry per scalar into a coarse bin: the count fits 16 bits");
     const size_t blocks = (p->max_n + SORT_TILE - 1) / SORT_TILE;
@@ -1503,8 +1642,16 @@ int launch_sort(mlhip_msm_plan* p, const void* d_scalars, int mont, size_t n, hi
     k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low,
                                                                p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
                                                                p->d_digits, p->d_blockhist);
+    // bins more than 8x the mean (and at least 32768 entries) are sorted by many workgroups
+    const uint32_t big_bin = (uint32_t)std::min<size_t>(std::max<size_t>(32768, 8 * ((size_t)p->W * n / NB)), 0x7fffffffu);
     k_fine_sort<<<dim3(NB), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->c, p->sort_low,
-                                               p->sort_idx_bits, p->d_counts, p->d_offsets, p->d_sorted);
+                                               p->sort_idx_bits, big_bin, p->d_counts, p->d_offsets, p->d_sorted);
+    k_bigbin_prefix<<<dim3(1), dim3(1024), 0, st>>>(p->d_coarse_count, NB, big_bin, p->d_binprefix);
+    k_bigbin_hist<<<dim3(1024), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->d_binprefix, NB,
+                                                   p->sort_low, p->sort_idx_bits, p->d_counts);
+    k_bigbin_place<<<dim3(1024), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->d_binprefix, NB,
+                                                    p->sort_low, p->sort_idx_bits, p->d_counts, p->d_cursor, p->d_offsets,
+                                                    p->d_sorted);
   } else {
     // legacy path (very large n or MLHIP_LEGACY_SORT=1): digits array + global-atomic histogram / scatter
     {

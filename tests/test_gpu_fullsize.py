@@ -67,6 +67,48 @@ def test_msm_2_20_c16_linearity_and_oracle(mlhip):
     assert cref.msm(cid, 1, pts.cpu().numpy(), ss, n, False, 16, threads) == full
 
 
+@pytest.mark.parametrize("shape", ["below_2_32_dups", "ones", "two_values"])
+def test_msm_2_20_skewed_scalars_vs_oracle(mlhip, shape):
+    """BASELINE configs[1], second distribution: all scalars below 2^32 with 1 % duplicated pairs (the carry bucket of
+    the third window holds half of the entries), all scalars one (a plain sum of points), and two scalar values only
+    -- the coarse bins and buckets far above the mean that the multi-workgroup sort and the sliced long-bucket sums
+    exist for.  Checked against the C oracle on the whole input, resident plan and host-buffer (streamed) call."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from oracle import cref
+
+    n = 1 << 20
+    lib, cid, pts, s, k, st = _setup(mlhip, n, seed=5)
+    sc = s.clone().view(torch.int64).reshape(n, 4)
+    if shape == "below_2_32_dups":
+        sc[:, 1:] = 0
+        sc[:, 0] &= 0xFFFFFFFF
+        p2 = pts.clone().reshape(n, 96)
+        p2[::100] = p2[0]
+        sc[::100] = sc[0]
+        pts = p2.reshape(-1).contiguous()
+    elif shape == "ones":
+        sc[:] = 0
+        sc[:, 0] = 1
+    else:
+        sc[::2] = sc[0]
+        sc[1::2] = sc[1]
+    sc8 = sc.view(torch.uint8).reshape(n, 32).contiguous()
+    plan = mlhip.MsmPlan(cid, 1, n, 16)
+    got = plan.run(pts.data_ptr(), sc8.data_ptr(), n, False, st)
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    hp = pts.cpu().numpy()
+    hs = sc8.cpu().numpy().view(np.uint64).reshape(n, 4)
+    exp = cref.msm(cid, 1, hp, hs, n, False, 16, threads)
+    assert got == exp
+    out = ctypes.create_string_buffer(96)
+    mlhip.check(lib.mlhip_msm_g1(cid, hp.tobytes(), hs.tobytes(), 0, n, 16, out))  # streamed in four segments
+    assert out.raw == exp
+
+
 def test_pairing_batch_65536_properties(mlhip):
     """BASELINE configs[2]: 65 536 pairings.  e([k]G1, Q)^1 checked through bilinearity on a strided sample
     against the oracle, and the whole batch against a second run split in two (determinism / indexing)."""
