@@ -45,8 +45,8 @@ import (
 var WindowC = 0
 
 // The GPU is a throughput device.  Measured on one MI355X through this ABI (tools/perf_latency.py): a
-// MultiScalarMul of 2 points takes 0.35 ms, of 2^20 points 6.2 ms; but ONE Miller loop takes 6.4 ms and ONE final
-// exponentiation 16.8 ms, because a single pairing occupies a single lane pair (65 536 of them take 31 ms).
+// MultiScalarMul of 2 points takes 0.35 ms, of 2^20 points 4.6 ms; but ONE Miller loop takes 6.2 ms and ONE final
+// exponentiation 14.2 ms, because a single pairing occupies a single lane pair (65 536 of them take 23 ms).
 // gnark on the CPU does a single pairing in about a millisecond.  Hence:
 //
 // MinDeviceMSM: MultiScalarMul with fewer pairs stays on the embedded gurvy driver.
