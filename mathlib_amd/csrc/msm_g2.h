@@ -1,0 +1,374 @@
+// msm_g2.h -- G2 over lane pairs: accumulation (boundary form and carry-free form), segmented variants, bucket
+// reduction.  Part of msm_kernels.h.
+#pragma once
+// (included by msm_kernels.h after its common headers and constants)
+
+namespace mlhip {
+
+// ---- G2 over lane pairs -----------------------------------------------------------------------------
+// A G2 bucket is owned by two adjacent lanes, one Fp2 component each (fp2_lanes.h): the XYZZ accumulator is
+// 4 x 12 words per lane -- the G1 footprint -- so the mixed addition stays in registers (one Fp2 element per
+// lane needs ~340 live words and spills), and every Fp2 product is one fused dual Montgomery product.
+template <class C>
+struct Fp2LField {
+  using Curve = C;
+  using T = Fp2L<C>;
+  MLHIP_HD static void zero(T& r) { fp2_zero<C>(r); }
+  MLHIP_HD static void one(T& r) { fp2_one<C>(r); }
+  MLHIP_HD static bool is_zero(const T& a) { return fp2_is_zero<C>(a); }
+  MLHIP_HD static bool eq(const T& a, const T& b) { return fp2_eq<C>(a, b); }
+  MLHIP_HD static void add(T& r, const T& a, const T& b) { fp2_add<C>(r, a, b); }
+  MLHIP_HD static void sub(T& r, const T& a, const T& b) { fp2_sub<C>(r, a, b); }
+  MLHIP_HD static void dbl(T& r, const T& a) { fp2_dbl<C>(r, a); }
+  MLHIP_HD static void neg(T& r, const T& a) { fp2_neg<C>(r, a); }
+  MLHIP_HD static void mul(T& r, const T& a, const T& b) { fp2_mul<C>(r, a, b); }
+  MLHIP_HD static void sqr(T& r, const T& a) { fp2_sqr<C>(r, a); }
+  MLHIP_HD static void inv(T& r, const T& a) { fp2_inv<C>(r, a); }
+  MLHIP_HD static void select(T& r, bool c, const T& a, const T& b) { fp2_select<C>(r, c, a, b); }
+};
+
+// component loads / stores between the AoS Fp2 layout in memory and the lane-pair registers
+template <class C>
+__device__ __forceinline__ void lp_load_affine(Affine<Fp2LField<C>>& p, const Affine<Fp2Field<C>>* pts, size_t idx, int hi) {
+  const Fp<C>* q = reinterpret_cast<const Fp<C>*>(pts + idx);
+  p.x.v = q[hi];
+  p.y.v = q[2 + hi];
+}
+template <class C>
+__device__ __forceinline__ void lp_load_xyzz(XYZZ<Fp2LField<C>>& r, const XYZZ<Fp2Field<C>>* src, size_t idx, int hi) {
+  const Fp<C>* q = reinterpret_cast<const Fp<C>*>(src + idx);
+  r.x.v = q[hi];
+  r.y.v = q[2 + hi];
+  r.zz.v = q[4 + hi];
+  r.zzz.v = q[6 + hi];
+}
+template <class C>
+__device__ __forceinline__ void lp_store_xyzz(XYZZ<Fp2Field<C>>* dst, size_t idx, const XYZZ<Fp2LField<C>>& r, int hi) {
+  Fp<C>* q = reinterpret_cast<Fp<C>*>(dst + idx);
+  q[hi] = r.x.v;
+  q[2 + hi] = r.y.v;
+  q[4 + hi] = r.zz.v;
+  q[6 + hi] = r.zzz.v;
+}
+template <class C>
+__device__ __noinline__ void xyzz_add_lp_ool(XYZZ<Fp2LField<C>>& acc, const XYZZ<Fp2LField<C>>& q) {
+  xyzz_add<Fp2LField<C>>(acc, q);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_accumulate_lp(const Affine<Fp2Field<C>>* __restrict__ points,
+                                                       const uint32_t* __restrict__ sorted,
+                                                       const uint32_t* __restrict__ offsets,
+                                                       const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                       const uint32_t* __restrict__ order, uint32_t big_threshold,
+                                                       uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
+                                                       XYZZ<Fp2Field<C>>* __restrict__ buckets) {
+  typedef Fp2LField<C> FL;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t pair = t >> 1;  // both lanes of a pair share the bucket: every branch below is pair-uniform
+  if (pair >= n_buckets) return;
+  const int hi = lane_is_hi() ? 1 : 0;
+  const size_t g = order[pair];
+  const uint32_t cnt = counts[g];
+  if (cnt > big_threshold) {
+    if (!hi) {
+      uint32_t pos = atomicAdd(big_count, 1u);
+      big_list[pos] = (uint32_t)g;
+    }
+    return;
+  }
+  XYZZ<FL> acc;
+  xyzz_set_inf<FL>(acc);
+  const size_t begin = offsets[g], end = begin + cnt;
+  if (begin < end) {
+    uint32_t e = sorted[begin];
+    Affine<FL> p;
+    lp_load_affine<C>(p, points, e & 0x7fffffffu, hi);
+    for (size_t k = begin; k < end; k++) {
+      uint32_t en = e;
+      Affine<FL> pn = p;
+      if (k + 1 < end) {
+        en = sorted[k + 1];
+        lp_load_affine<C>(pn, points, en & 0x7fffffffu, hi);
+      }
+      xyzz_madd<FL>(acc, p, (e >> 31) != 0);
+      e = en;
+      p = pn;
+    }
+  }
+  lp_store_xyzz<C>(buckets, g, acc, hi);
+}
+
+// ---- G2 accumulation in the carry-free form over lane pairs (ec28_lp.h; curves with u^2 = -1) -----------------
+template <class C>
+struct alignas(8) AffineG2_28 {  // x.c0 | x.c1 | y.c0 | y.c1, 56 (40) bytes each
+  Fp28<C> c[4];
+};
+
+template <class C>
+__global__ void __launch_bounds__(256) k_points_to28_g2(const Affine<Fp2Field<C>>* __restrict__ points, size_t n,
+                                                        AffineG2_28<C>* __restrict__ out) {
+  // one coordinate component per thread: 4 threads per point
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 4 * n) return;
+  const Fp<C>* src = reinterpret_cast<const Fp<C>*>(points);
+  Fp28<C> v;
+  fp28_from_fp<C>(v, src[t]);
+  reinterpret_cast<Fp28<C>*>(out)[t] = v;
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_accumulate28_lp(const AffineG2_28<C>* __restrict__ points,
+                                                         const uint32_t* __restrict__ sorted,
+                                                         const uint32_t* __restrict__ offsets,
+                                                         const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                         const uint32_t* __restrict__ order, uint32_t big_threshold,
+                                                         uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
+                                                         XYZZ<Fp2Field<C>>* __restrict__ buckets) {
+  typedef PairDevice<C> B;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t pair = t >> 1;  // both lanes of a pair share the bucket: every branch below is pair-uniform
+  if (pair >= n_buckets) return;
+  const int hi = (int)(threadIdx.x & 1u);
+  const size_t g = order[pair];
+  const uint32_t cnt = counts[g];
+  if (cnt > big_threshold) {  // summed by a whole workgroup in k_accumulate_big (boundary form)
+    if (!hi) {
+      uint32_t pos = atomicAdd(big_count, 1u);
+      big_list[pos] = (uint32_t)g;
+    }
+    return;
+  }
+  XYZZ28L<Fp28<C>> acc;
+  bool inf = true;
+  const size_t begin = offsets[g], end = begin + cnt;
+  if (cnt != 0) {
+    uint32_t e = sorted[begin];
+    Affine28L<Fp28<C>> p, pn;
+    p.x = points[e & 0x7fffffffu].c[hi];
+    p.y = points[e & 0x7fffffffu].c[2 + hi];
+    for (size_t k = begin; k < end; k++) {
+      uint32_t en = e;
+      pn = p;
+      if (k + 1 < end) {  // prefetch the next index and point under this addition
+        en = sorted[k + 1];
+        pn.x = points[en & 0x7fffffffu].c[hi];
+        pn.y = points[en & 0x7fffffffu].c[2 + hi];
+      }
+      xyzz28_lp_madd<C, B>(acc, inf, p, (e >> 31) != 0);
+      e = en;
+      p = pn;
+    }
+  }
+  // back to the boundary form, one Fp2 component per lane
+  XYZZ<Fp2LField<C>> r;
+  if (inf) {
+    xyzz_set_inf<Fp2LField<C>>(r);
+  } else {
+    fp28_to_fp<C>(r.x.v, acc.x);
+    fp28_to_fp<C>(r.y.v, acc.y);
+    fp28_to_fp<C>(r.zz.v, acc.zz);
+    fp28_to_fp<C>(r.zzz.v, acc.zzz);
+  }
+  lp_store_xyzz<C>(buckets, g, r, hi);
+}
+
+// ---- segmented G2 accumulation (see k_accumulate28_seg): the state of bucket g is two XYZZ28L, one per lane ------
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_accumulate28_lp_seg(
+    const AffineG2_28<C>* __restrict__ points, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ counts, size_t n_buckets, const uint32_t* __restrict__ order, uint32_t big_threshold,
+    uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count, XYZZ28L<Fp28<C>>* __restrict__ state, int flags,
+    XYZZ<Fp2Field<C>>* __restrict__ buckets) {
+  typedef PairDevice<C> B;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t pair = t >> 1;  // both lanes of a pair share the bucket: every branch below is pair-uniform
+  if (pair >= n_buckets) return;
+  const int hi = (int)(threadIdx.x & 1u);
+  const size_t g = order[pair];
+  const uint32_t cnt = counts[g];
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  if (cnt > big_threshold) {
+    if (!hi) {
+      uint32_t pos = atomicAdd(big_count, 1u);
+      big_list[pos] = (uint32_t)g;
+    }
+    return;
+  }
+  if (cnt == 0 && !first && !last) return;
+  XYZZ28L<Fp28<C>> acc;
+  bool inf = true;
+  if (!first) {
+    acc = state[2 * g + hi];
+    const uint32_t z = fp28_all_zero<C>(acc.zz) ? 1u : 0u;
+    inf = (z & pair_xchg_u32(z)) != 0;  // ZZ = 0 in Fp2: both components
+  }
+  const size_t begin = offsets[g], end = begin + cnt;
+  if (cnt != 0) {
+    uint32_t e = sorted[begin];
+    Affine28L<Fp28<C>> p, pn;
+    p.x = points[e & 0x7fffffffu].c[hi];
+    p.y = points[e & 0x7fffffffu].c[2 + hi];
+    for (size_t k = begin; k < end; k++) {
+      uint32_t en = e;
+      pn = p;
+      if (k + 1 < end) {
+        en = sorted[k + 1];
+        pn.x = points[en & 0x7fffffffu].c[hi];
+        pn.y = points[en & 0x7fffffffu].c[2 + hi];
+      }
+      xyzz28_lp_madd<C, B>(acc, inf, p, (e >> 31) != 0);
+      e = en;
+      p = pn;
+    }
+  }
+  if (last) {
+    XYZZ<Fp2LField<C>> r;
+    if (inf) {
+      xyzz_set_inf<Fp2LField<C>>(r);
+    } else {
+      fp28_to_fp<C>(r.x.v, acc.x);
+      fp28_to_fp<C>(r.y.v, acc.y);
+      fp28_to_fp<C>(r.zz.v, acc.zz);
+      fp28_to_fp<C>(r.zzz.v, acc.zzz);
+    }
+    lp_store_xyzz<C>(buckets, g, r, hi);
+  } else {
+    if (inf) {
+#pragma unroll
+      for (int i = 0; i < C::N28; i++) acc.x.l[i] = acc.y.l[i] = acc.zz.l[i] = acc.zzz.l[i] = 0;
+    }
+    state[2 * g + hi] = acc;
+  }
+}
+
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_g2(const uint32_t* __restrict__ big_list,
+                                                                 const uint32_t* __restrict__ big_count,
+                                                                 const uint32_t* __restrict__ prefix,
+                                                                 const XYZZ<Fp2Field<C>>* __restrict__ partials,
+                                                                 XYZZ28L<Fp28<C>>* __restrict__ state, int flags,
+                                                                 XYZZ<Fp2Field<C>>* __restrict__ buckets) {
+  typedef Fp2Field<C> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  const uint32_t nbig = *big_count;
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    const uint32_t g = big_list[bi];
+    XYZZ<F> sum;
+    big_bucket_total<F, BLOCK>(sum, sh, partials, prefix, bi);
+    if (threadIdx.x == 0) {
+      if (!first) {
+        const XYZZ28L<Fp28<C>> lo = state[2 * g], up = state[2 * g + 1];
+        if (!(fp28_all_zero<C>(lo.zz) && fp28_all_zero<C>(up.zz))) {
+          XYZZ<F> prev;
+          fp28_to_fp<C>(prev.x.c0, lo.x);
+          fp28_to_fp<C>(prev.x.c1, up.x);
+          fp28_to_fp<C>(prev.y.c0, lo.y);
+          fp28_to_fp<C>(prev.y.c1, up.y);
+          fp28_to_fp<C>(prev.zz.c0, lo.zz);
+          fp28_to_fp<C>(prev.zz.c1, up.zz);
+          fp28_to_fp<C>(prev.zzz.c0, lo.zzz);
+          fp28_to_fp<C>(prev.zzz.c1, up.zzz);
+          xyzz_add_ool<F>(sum, prev);
+        }
+      }
+      if (last) {
+        buckets[g] = sum;
+      } else {
+        XYZZ28L<Fp28<C>> lo, up;
+        if (xyzz_is_inf<F>(sum)) {
+#pragma unroll
+          for (int i = 0; i < C::N28; i++) {
+            lo.x.l[i] = lo.y.l[i] = lo.zz.l[i] = lo.zzz.l[i] = 0;
+            up.x.l[i] = up.y.l[i] = up.zz.l[i] = up.zzz.l[i] = 0;
+          }
+        } else {
+          fp28_from_fp<C>(lo.x, sum.x.c0);
+          fp28_from_fp<C>(up.x, sum.x.c1);
+          fp28_from_fp<C>(lo.y, sum.y.c0);
+          fp28_from_fp<C>(up.y, sum.y.c1);
+          fp28_from_fp<C>(lo.zz, sum.zz.c0);
+          fp28_from_fp<C>(up.zz, sum.zz.c1);
+          fp28_from_fp<C>(lo.zzz, sum.zzz.c0);
+          fp28_from_fp<C>(up.zzz, sum.zzz.c1);
+        }
+        state[2 * g] = lo;
+        state[2 * g + 1] = up;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_chunks_lp(const XYZZ<Fp2Field<C>>* __restrict__ buckets, size_t n_chunks, int l_eff,
+                                                   XYZZ<Fp2Field<C>>* __restrict__ A, XYZZ<Fp2Field<C>>* __restrict__ W0) {
+  typedef Fp2LField<C> FL;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t g = t >> 1;
+  if (g >= n_chunks) return;
+  const int hi = lane_is_hi() ? 1 : 0;
+  XYZZ<FL> acc, w0, b;
+  xyzz_set_inf<FL>(acc);
+  xyzz_set_inf<FL>(w0);
+  for (int i = l_eff - 1; i >= 1; i--) {
+    lp_load_xyzz<C>(b, buckets, g * (size_t)l_eff + i, hi);
+    xyzz_add_lp_ool<C>(acc, b);
+    xyzz_add_lp_ool<C>(w0, acc);
+  }
+  lp_load_xyzz<C>(b, buckets, g * (size_t)l_eff, hi);
+  xyzz_add_lp_ool<C>(acc, b);
+  lp_store_xyzz<C>(A, g, acc, hi);
+  lp_store_xyzz<C>(W0, g, w0, hi);
+}
+
+// same selection scheme as k_masked_sums; BLOCK threads = BLOCK/2 lane pairs, LDS tree over pairs
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_masked_sums_lp(const XYZZ<Fp2Field<C>>* __restrict__ A,
+                                                          const XYZZ<Fp2Field<C>>* __restrict__ W0, uint32_t T, int nsel,
+                                                          XYZZ<Fp2Field<C>>* __restrict__ out) {
+  typedef Fp2LField<C> FL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<Fp2Field<C>>* sh = reinterpret_cast<XYZZ<Fp2Field<C>>*>(smem);
+  constexpr uint32_t PAIRS = BLOCK / 2;
+  const uint32_t pid = threadIdx.x >> 1;
+  const int hi = lane_is_hi() ? 1 : 0;
+  const uint32_t w = blockIdx.x / nsel;
+  const int sel = blockIdx.x % nsel;
+  const XYZZ<Fp2Field<C>>* src = (sel < 2 ? W0 : A) + (size_t)w * T;
+  XYZZ<FL> acc, b;
+  xyzz_set_inf<FL>(acc);
+  if (sel < 4) {
+    const uint32_t half = (T + 1) / 2;
+    const uint32_t lo = (sel & 1) ? half : 0u, hi_t = (sel & 1) ? T : half;
+    for (uint32_t t = lo + pid; t < hi_t; t += PAIRS) {
+      lp_load_xyzz<C>(b, src, t, hi);
+      xyzz_add_lp_ool<C>(acc, b);
+    }
+  } else {
+    const int k = sel - 4;
+    const uint32_t lowmask = (1u << k) - 1u;
+    for (uint32_t j = pid; j < T / 2; j += PAIRS) {
+      uint32_t t = ((j >> k) << (k + 1)) | (1u << k) | (j & lowmask);
+      lp_load_xyzz<C>(b, src, t, hi);
+      xyzz_add_lp_ool<C>(acc, b);
+    }
+  }
+  lp_store_xyzz<C>(sh, pid, acc, hi);
+  __syncthreads();
+  for (uint32_t s = PAIRS / 2; s > 0; s >>= 1) {
+    if (pid < s) {  // pair-uniform
+      XYZZ<FL> a;
+      lp_load_xyzz<C>(a, sh, pid, hi);
+      lp_load_xyzz<C>(b, sh, pid + s, hi);
+      xyzz_add_lp_ool<C>(a, b);
+      lp_store_xyzz<C>(sh, pid, a, hi);
+    }
+    __syncthreads();
+  }
+  if (pid == 0) lp_store_xyzz<C>(out, blockIdx.x, [&] { XYZZ<FL> a; lp_load_xyzz<C>(a, sh, 0, hi); return a; }(), hi);
+}
+
+}  // namespace mlhip

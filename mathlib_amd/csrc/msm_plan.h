@@ -1,0 +1,434 @@
+// msm_plan.h -- host side of the MSM: plan allocation, the launch sequences (one pass and streamed in segments), the
+// host tail.  Part of msm_kernels.h.
+#pragma once
+// (included by msm_kernels.h after its common headers and constants)
+
+namespace mlhip {
+
+template <class F>
+int plan_alloc(mlhip_msm_plan* p) {
+  const size_t nbuckets = (size_t)p->W * p->M;
+  p->pt_size = sizeof(Affine<F>);
+  p->xyzz_size = sizeof(XYZZ<F>);
+  HIPCHK(hipMalloc(&p->d_digits, (size_t)p->W * p->max_n * 4));
+  HIPCHK(hipMalloc(&p->d_sorted, (size_t)p->W * p->max_n * 4));
+  {
+    // sort parameters: packed entry = fine bits | sign | index must fit 32 bits, coarse bins must fit LDS
+    int idx_bits = 1;
+    while (((size_t)1 << idx_bits) < p->max_n) idx_bits++;
+    int low = p->c - 1 < 8 ? p->c - 1 : 8;
+    if (low > 31 - idx_bits) low = 31 - idx_bits;
+    const char* legacy = getenv("MLHIP_LEGACY_SORT");
+    uint32_t nb = low >= 1 ? (uint32_t)p->W << (p->c - 1 - low) : 0;
+    if (low < 1 || nb > 4096 || (legacy && legacy[0] == '1')) {
+      p->sort_low = 0;
+      p->sort_nb = 0;
+    } else {
+      p->sort_low = low;
+      p->sort_nb = nb;
+    }
+    p->sort_idx_bits = idx_bits;
+  }
+  // zeroed every run: [counts | cursor | bigcount(4) | coarse_count | coarse_cursor]
+  p->zero_bytes = (2 * nbuckets + 4 + 2 * (size_t)p->sort_nb) * 4;
+  HIPCHK(hipMalloc(&p->d_zero, p->zero_bytes));
+  p->d_counts = p->d_zero;
+  p->d_cursor = p->d_zero + nbuckets;
+  p->d_bigcount = p->d_zero + 2 * nbuckets;
+  p->d_coarse_count = p->d_zero + 2 * nbuckets + 4;
+  p->d_coarse_cursor = p->d_coarse_count + p->sort_nb;
+  HIPCHK(hipMalloc(&p->d_coarse_off, ((size_t)p->sort_nb + 1) * 4));
+  HIPCHK(hipMalloc(&p->d_binprefix, ((size_t)p->sort_nb + 2) * 4));
+  if (p->sort_nb) {
+    static_assert(SORT_TILE < 65536, "a block puts at most one entry per scalar into a coarse bin: the count fits 16 bits");
+    const size_t blocks = (p->max_n + SORT_TILE - 1) / SORT_TILE;
+    HIPCHK(hipMalloc(&p->d_blockhist, blocks * p->sort_nb * sizeof(uint16_t)));
+  }
+  HIPCHK(hipMalloc(&p->d_offsets, nbuckets * 4));
+  HIPCHK(hipMalloc(&p->d_biglist, nbuckets * 4));
+  {
+    // long buckets: at most W n / BIG_BUCKET_MIN of them, and W n / BIG_SLICE + one more slice per bucket
+    const size_t entries = (size_t)p->W * p->max_n;
+    const size_t nbig_max = std::min(nbuckets, entries / BIG_BUCKET_MIN + 1);
+    HIPCHK(hipMalloc(&p->d_bigprefix, (nbig_max + 2) * 4));
+    HIPCHK(hipMalloc(&p->d_bigpart, (entries / BIG_SLICE + nbig_max + 2) * p->xyzz_size));
+  }
+  HIPCHK(hipMalloc(&p->d_order, nbuckets * 4));
+  {
+    const size_t nblk = (nbuckets + 255) / 256;
+    const size_t hist_n = (size_t)ORDER_BINS * nblk;
+    HIPCHK(hipMalloc(&p->d_hist, hist_n * 4));
+    const size_t tiles = (std::max(nbuckets, hist_n) + SCAN_TILE - 1) / SCAN_TILE;
+    HIPCHK(hipMalloc(&p->d_tilesums, (tiles + 1) * 4));
+  }
+  if (const char* e = getenv("MLHIP_RED_BLOCK")) {
+    const int v = atoi(e);
+    if (v == 64 || v == 128 || v == 256) p->red_block = v;
+  }
+  if (const char* e = getenv("MLHIP_ACC_BLOCK")) {
+    const int v = atoi(e);
+    if (v == 64 || v == 128 || v == 256) p->acc_block = v;
+  }
+  {
+    const char* one_lane = getenv("MLHIP_REDUCE_ONE_LANE");  // =1: the one-point-per-lane reduction kernels
+    p->reduce_one_lane = one_lane && one_lane[0] == '1';
+  }
+  if constexpr (std::is_same<F, FpField<typename F::Curve>>::value) {
+    // G1 accumulation runs in the carry-free form (fp28.h): -24 % time for the 12-limb fields, -7 % for BN254.
+    // MLHIP_ACC32=1 selects the boundary-form kernel (kept as the second implementation the tests compare with).
+    const char* acc32 = getenv("MLHIP_ACC32");
+    const bool want28 = !(acc32 && acc32[0] == '1');
+    if (want28) HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(Affine28<typename F::Curve>)));
+  }
+  if constexpr (std::is_same<F, Fp2Field<typename F::Curve>>::value && F::Curve::BETA == -1 && F::Curve::N28 == 14) {
+    // G2 in the carry-free form: BLS12-381 only (-14 % accumulation time); u^2 = -5 does not fit the weight budget
+    // (BLS12-377) and the 10-limb BN254 form gains nothing over its 8 saturated limbs on lane pairs
+    const char* acc32 = getenv("MLHIP_ACC32");
+    if (!(acc32 && acc32[0] == '1')) HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(AffineG2_28<typename F::Curve>)));
+  }
+  HIPCHK(hipMalloc(&p->d_buckets, nbuckets * p->xyzz_size));
+  HIPCHK(hipMalloc(&p->d_A, (size_t)p->W * p->T * p->xyzz_size));
+  HIPCHK(hipMalloc(&p->d_W0, (size_t)p->W * p->T * p->xyzz_size));
+  HIPCHK(hipMalloc(&p->d_out, (size_t)p->W * p->nsel * p->xyzz_size));
+  HIPCHK(hipHostMalloc(&p->h_out, (size_t)p->W * p->nsel * p->xyzz_size, hipHostMallocDefault));
+  for (int i = 0; i < 5; i++) HIPCHK(hipEventCreate(&p->ev[i]));
+  HIPCHK(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+  if (p->d_points28) {
+    HIPCHK(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+  }
+  return 0;
+}
+
+// Horner over bit positions: total = sum_w 2^(cw) [ out[w][0..3] summed + L * sum_k 2^k out[w][4+k] ]
+template <class F>
+void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
+  const XYZZ<F>* o = reinterpret_cast<const XYZZ<F>*>(p->h_out);
+  const int npos = p->W * p->c;
+  std::vector<XYZZ<F>> slot(npos);
+  for (int i = 0; i < npos; i++) xyzz_set_inf<F>(slot[i]);
+  for (int w = 0; w < p->W; w++) {
+    XYZZ<F> s = o[w * p->nsel + 0];
+    for (int h = 1; h < 4; h++) xyzz_add<F>(s, o[w * p->nsel + h]);
+    slot[w * p->c] = s;
+    for (int k = 0; k < p->nb; k++) slot[w * p->c + p->lgL + k] = o[w * p->nsel + 4 + k];
+  }
+  xyzz_set_inf<F>(total);
+  bool started = false;
+  for (int i = npos - 1; i >= 0; i--) {
+    if (started) {
+      XYZZ<F> d;
+      xyzz_dbl<F>(d, total);
+      total = d;
+    }
+    if (!xyzz_is_inf<F>(slot[i])) {
+      xyzz_add<F>(total, slot[i]);
+      started = true;
+    }
+  }
+}
+
+// slice sums of the long buckets listed by the accumulation kernel (nothing to do, two near-empty launches, when
+// there are none)
+template <class F, int BB>
+void launch_big_slices(mlhip_msm_plan* p, const Affine<F>* d_points, hipStream_t st) {
+  k_big_prefix<<<dim3(1), dim3(1024), 0, st>>>(p->d_counts, p->d_biglist, p->d_bigcount, p->d_bigprefix);
+  k_big_slices<F, BB><<<dim3(1024), dim3(BB), BB * sizeof(XYZZ<F>), st>>>(d_points, p->d_sorted, p->d_offsets, p->d_counts,
+                                                                        p->d_biglist, p->d_bigcount, p->d_bigprefix,
+                                                                        (XYZZ<F>*)p->d_bigpart);
+}
+
+// digits -> entries sorted by (window, bucket) in d_sorted / d_offsets / d_counts, and the bucket order by population
+template <class C>
+int launch_sort(mlhip_msm_plan* p, const void* d_scalars, int mont, size_t n, hipStream_t st, bool prof) {
+  const size_t nbuckets = (size_t)p->W * p->M;
+  if (p->sort_low > 0) {
+    // two-level LDS counting sort (no per-key global atomics)
+    const unsigned blocks = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+    const uint32_t NB = p->sort_nb;
+    k_coarse_hist<C><<<dim3(blocks), dim3(256), NB * 4, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low, NB,
+                                                            p->d_coarse_count, p->d_blockhist);
+    if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
+    launch_scan(p->d_coarse_count, p->d_coarse_off, p->d_tilesums, NB, st);
+    k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low,
+                                                               p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
+                                                               p->d_digits, p->d_blockhist);
+    // bins more than 8x the mean (and at least 32768 entries) are sorted by many workgroups
+    const uint32_t big_bin = (uint32_t)std::min<size_t>(std::max<size_t>(32768, 8 * ((size_t)p->W * n / NB)), 0x7fffffffu);
+    k_fine_sort<<<dim3(NB), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->c, p->sort_low,
+                                               p->sort_idx_bits, big_bin, p->d_counts, p->d_offsets, p->d_sorted);
+    k_bigbin_prefix<<<dim3(1), dim3(1024), 0, st>>>(p->d_coarse_count, NB, big_bin, p->d_binprefix);
+    k_bigbin_hist<<<dim3(1024), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->d_binprefix, NB,
+                                                   p->sort_low, p->sort_idx_bits, p->d_counts);
+    k_bigbin_place<<<dim3(1024), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->d_binprefix, NB,
+                                                    p->sort_low, p->sort_idx_bits, p->d_counts, p->d_cursor, p->d_offsets,
+                                                    p->d_sorted);
+  } else {
+    // legacy path (very large n or MLHIP_LEGACY_SORT=1): digits array + global-atomic histogram / scatter
+    {
+      size_t blocks = (n + 255) / 256;
+      if (blocks > 65536) blocks = 65536;
+      k_digits<C><<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->M,
+                                                                 p->d_digits, p->d_counts);
+    }
+    if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
+    launch_scan(p->d_counts, p->d_offsets, p->d_tilesums, nbuckets, st);
+    {
+      size_t total_e = (size_t)p->W * n;
+      size_t blocks = (total_e + 255) / 256;
+      if (blocks > 262144) blocks = 262144;
+      k_scatter<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(p->d_digits, n, p->W, p->M, p->d_offsets, p->d_cursor,
+                                                               p->d_sorted);
+    }
+  }
+  {
+    const unsigned nblk = (unsigned)((nbuckets + 255) / 256);
+    k_order_hist<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist);
+    launch_scan(p->d_hist, p->d_hist, p->d_tilesums, (size_t)ORDER_BINS * nblk, st);
+    k_order_place<<<dim3(nblk), dim3(256), 0, st>>>(p->d_counts, nbuckets, p->d_hist, p->d_order);
+  }
+  return 0;
+}
+
+// bucket sums in d_buckets -> W x nsel partial sums in d_out (two levels: chunks of L buckets, bit-masked sums)
+template <class C, class F>
+int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
+  typedef XYZZ<F> X;
+  constexpr bool kLanePairs = std::is_same<F, Fp2Field<C>>::value;  // G2: two lanes per bucket
+  {
+    size_t n_chunks = (size_t)p->W * p->T;
+    if constexpr (kLanePairs) {
+      k_chunks_lp<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                        p->L, (X*)p->d_A, (X*)p->d_W0);
+      constexpr int RB = 256;  // 128 lane pairs x 384 B = 48 KB of LDS per block
+      k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 2) * sizeof(X), st>>>(
+          (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+    } else {
+      if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created
+        k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                     p->L, (X*)p->d_A, (X*)p->d_W0);
+        constexpr int RB = 256;  // 48 KB of LDS per block
+        k_masked_sums<F, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), RB * sizeof(X), st>>>(
+            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      } else {
+        // one point per quad of lanes: a group addition is 4 rounds of one multiplication instead of 14 in a row
+        k_chunks_q<C><<<dim3((unsigned)((4 * n_chunks + p->red_block - 1) / p->red_block)), dim3(p->red_block), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                         p->L, (X*)p->d_A, (X*)p->d_W0);
+        constexpr int RB = 512;  // 128 quads, 24 KB of LDS per block
+        k_masked_sums_q<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
+            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      }
+    }
+  }
+  return 0;
+}
+
+template <class C, class F>
+int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n, hipStream_t st) {
+  typedef Affine<F> A;
+  typedef XYZZ<F> X;
+  p->pending_n = n;
+  p->pending = true;
+  if (n != 0) {
+    const size_t nbuckets = (size_t)p->W * p->M;
+    const bool prof = p->profiling;
+    // Buckets far longer than the mean (degenerate inputs: equal scalars, tiny scalars) are handed to a whole
+    // workgroup each; the threshold scales with the mean length n / 2^(c-1) so that large n, and the sparser top
+    // window (2-4x the mean for these group orders), stay on the one-thread-per-bucket path.
+    uint32_t big_threshold = (uint32_t)std::min<size_t>((n >> (p->c - 1)) * 8, 1u << 30);
+    if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
+    if (p->upload_src && !p->d_points28) {  // no auxiliary stream on this path: plain upload first
+      HIPCHK(hipMemcpy(const_cast<void*>(d_points), p->upload_src, p->upload_bytes, hipMemcpyHostToDevice));
+      p->upload_src = nullptr;
+    }
+    // the conversion of the points is independent of the sort: it runs on the auxiliary stream beside the
+    // (LDS-atomic bound) sort kernels.  The fork is recorded now (after the previous MSM's work on `st`); the work
+    // itself is queued after the sort launches so that a host-blocking upload cannot delay them.
+    if (p->d_points28) HIPCHK(hipEventRecord(p->ev_fork, st));
+    HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
+    if (prof) HIPCHK(hipEventRecord(p->ev[0], st));
+    {
+      int rc_sort = launch_sort<C>(p, d_scalars, mont, n, st, prof);
+      if (rc_sort) return rc_sort;
+    }
+    // resident bases: the carry-free copy of the first conv_n points of this very buffer is already there
+    const bool conv_cached = p->points_static && p->conv_src == d_points && n <= p->conv_n && !p->upload_src;
+    if (p->d_points28 && conv_cached) {
+      HIPCHK(hipEventRecord(p->ev_join, st));  // nothing to wait for
+    } else if (p->d_points28) {
+      HIPCHK(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
+      if (p->upload_src) {  // host-buffer call: the upload of the points rides the same stream, ahead of the conversion
+        HIPCHK(hipMemcpyAsync(const_cast<void*>(d_points), p->upload_src, p->upload_bytes, hipMemcpyHostToDevice, p->aux));
+        p->upload_src = nullptr;
+      }
+      if constexpr (std::is_same<F, Fp2Field<C>>::value) {
+        if constexpr (C::BETA == -1)
+          k_points_to28_g2<C><<<dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, p->aux>>>(
+              (const A*)d_points, n, (AffineG2_28<C>*)p->d_points28);
+      } else {
+        k_points_to28<C><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->aux>>>((const A*)d_points, n,
+                                                                                     (Affine28<C>*)p->d_points28);
+      }
+      HIPCHK(hipEventRecord(p->ev_join, p->aux));
+      p->conv_src = d_points;
+      p->conv_n = n;
+    }
+    if (prof) HIPCHK(hipEventRecord(p->ev[2], st));
+    constexpr bool kLanePairs = std::is_same<F, Fp2Field<C>>::value;  // G2: two lanes per bucket
+    if constexpr (kLanePairs) {
+      bool done28 = false;
+      if constexpr (C::BETA == -1) {
+        if (p->d_points28) {
+          HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
+          k_accumulate28_lp<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+              (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+              big_threshold, p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
+          done28 = true;
+        }
+      }
+      if (!done28)
+        k_accumulate_lp<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+            (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
+            p->d_bigcount, (X*)p->d_buckets);
+    } else if (p->d_points28) {
+      HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
+      k_accumulate28<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+          (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
+          p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
+    } else {
+      k_accumulate<F><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+          (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
+          p->d_bigcount, (X*)p->d_buckets);
+    }
+    if (prof) HIPCHK(hipEventRecord(p->ev[3], st));
+    {
+      constexpr int BB = sizeof(X) <= 192 ? 256 : 128;  // 48 KB of LDS per block
+      launch_big_slices<F, BB>(p, (const A*)d_points, st);
+      k_accumulate_big<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
+                                                                            (const X*)p->d_bigpart, (X*)p->d_buckets);
+    }
+    {
+      int rc_red = launch_reduce<C, F>(p, st);
+      if (rc_red) return rc_red;
+    }
+    if (prof) HIPCHK(hipEventRecord(p->ev[4], st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->W * p->nsel * sizeof(X), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(p->done, st));
+  }
+  return 0;
+}
+
+// Host-buffer G1 MSM streamed in K segments (see k_accumulate28_seg): h_points / h_scalars are the caller's pageable
+// buffers, d_points / d_scalars the plan-sized device buffers they are staged through.  Uploads and the point
+// conversion ride the auxiliary stream; the sort and the accumulation of segment s wait for its event on `st`.
+// The host thread blocks inside the pageable copies, which is exactly what overlaps them with the kernels queued before.
+template <class C, class F>
+int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points, const void* h_scalars, int mont,
+                size_t n, int K, hipStream_t st) {
+  typedef Affine<F> A;
+  typedef XYZZ<F> X;
+  constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
+  if (!p->d_points28 || !p->aux) return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM needs the carry-free accumulation path");
+  constexpr size_t kStateBytes = kG2 ? 2 * sizeof(XYZZ28L<Fp28<C>>) : sizeof(XYZZ28<C>);
+  if (n == 0 || K < 2 || K > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "bad segment count");
+  const size_t nbuckets = (size_t)p->W * p->M;
+  if (!p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * kStateBytes));
+  for (int s = 0; s < K; s++)
+    if (!p->ev_seg[s]) HIPCHK(hipEventCreateWithFlags(&p->ev_seg[s], hipEventDisableTiming));
+  // resident bases (h_points == nullptr): only the scalars travel; the carry-free copy must already be there
+  const bool resident = h_points == nullptr;
+  if (resident && !(p->points_static && p->conv_src == d_points && n <= p->conv_n))
+    return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM over resident bases needs their converted copy");
+  p->pending_n = n;
+  p->pending = true;
+  if (!resident) p->conv_src = nullptr;  // the carry-free copy no longer matches any resident buffer
+  const size_t seg = (n + K - 1) / K;
+  const char* hp = (const char*)h_points;
+  const char* hs = (const char*)h_scalars;
+  HIPCHK(hipEventRecord(p->ev_fork, st));  // the staging buffers are free once the work queued before us is done
+  HIPCHK(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
+  int s = 0;
+  for (size_t off = 0; off < n; off += seg, s++) {
+    const size_t len = std::min(seg, n - off);
+    const bool first = off == 0, last = off + len >= n;
+    const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0);
+    char* dsc = (char*)d_scalars + off * 32;
+    A* dpt = (A*)d_points + off;
+    HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
+    if (!resident) {
+      HIPCHK(hipMemcpyAsync(dpt, hp + off * sizeof(A), len * sizeof(A), hipMemcpyHostToDevice, p->aux));
+      if constexpr (kG2)
+        k_points_to28_g2<C><<<dim3((unsigned)((4 * len + 255) / 256)), dim3(256), 0, p->aux>>>(
+            dpt, len, (AffineG2_28<C>*)p->d_points28 + off);
+      else
+        k_points_to28<C><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, p->aux>>>(dpt, len,
+                                                                                       (Affine28<C>*)p->d_points28 + off);
+    }
+    HIPCHK(hipEventRecord(p->ev_seg[s], p->aux));
+    HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));
+    HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
+    {
+      int rc_sort = launch_sort<C>(p, dsc, mont, len, st, false);
+      if (rc_sort) return rc_sort;
+    }
+    uint32_t big_threshold = (uint32_t)std::min<size_t>((len >> (p->c - 1)) * 8, 1u << 30);
+    if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
+    if constexpr (kG2) {
+      k_accumulate28_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+          (const AffineG2_28<C>*)p->d_points28 + off, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+          big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
+      constexpr int BB = 128;
+      launch_big_slices<F, BB>(p, dpt, st);
+      k_accumulate_big_seg_g2<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+          p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28L<Fp28<C>>*)p->d_state28, flags,
+          (X*)p->d_buckets);
+    } else {
+      k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+          (const Affine28<C>*)p->d_points28 + off, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+          big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
+      constexpr int BB = 256;
+      launch_big_slices<F, BB>(p, dpt, st);
+      k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+          p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28, flags,
+          (X*)p->d_buckets);
+    }
+  }
+  {
+    int rc_red = launch_reduce<C, F>(p, st);
+    if (rc_red) return rc_red;
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->W * p->nsel * sizeof(X), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(p->done, st));
+  return 0;
+}
+
+template <class C, class F>
+int plan_finish(mlhip_msm_plan* p, void* out_affine, void* out_xyzz) {
+  typedef Affine<F> A;
+  typedef XYZZ<F> X;
+  X total;
+  if (!p->pending) return mlhip_rt::fail(MLHIP_EINVAL, "mlhip_msm_finish without a pending mlhip_msm_launch");
+  p->pending = false;
+  if (p->pending_n == 0) {
+    xyzz_set_inf<F>(total);
+  } else {
+    HIPCHK(hipEventSynchronize(p->done));
+    auto t0 = std::chrono::steady_clock::now();
+    host_tail<F>(p, total);
+    if (p->profiling) {
+      for (int i = 0; i < 4; i++) HIPCHK(hipEventElapsedTime(&p->ms[i], p->ev[i], p->ev[i + 1]));
+      HIPCHK(hipEventElapsedTime(&p->ms[4], p->ev[0], p->ev[4]));
+      p->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
+  A r;
+  xyzz_to_affine<F>(r, total);
+  memcpy(out_affine, &r, sizeof(A));
+  if (out_xyzz) memcpy(out_xyzz, &total, sizeof(X));
+  return 0;
+}
+
+}  // namespace mlhip

@@ -1,0 +1,137 @@
+// msm_reduce.h -- G1 bucket reduction: chunk sums and bit-masked sums, one point per lane and one point per quad of
+// lanes (ec_quad.h).  Part of msm_kernels.h.
+#pragma once
+// (included by msm_kernels.h after its common headers and constants)
+
+namespace mlhip {
+
+template <class F>
+__global__ void __launch_bounds__(256) k_chunks(const XYZZ<F>* __restrict__ buckets, size_t n_chunks, int l_eff,
+                                                XYZZ<F>* __restrict__ A, XYZZ<F>* __restrict__ W0) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_chunks) return;
+  msm_chunk_body<F>(g, buckets, A, W0, l_eff, [](XYZZ<F>& a, const XYZZ<F>& q) { xyzz_add_ool<F>(a, q); });
+}
+
+// block (w, sel): sel 0,1 -> the two halves of sum_t W0[w][t]; sel 2,3 -> the two halves of sum_t A[w][t];
+// sel 4+k -> sum over t with bit k set of A[w][t].  Every block therefore sums T/2 elements (equal depth).
+template <class F, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_masked_sums(const XYZZ<F>* __restrict__ A, const XYZZ<F>* __restrict__ W0,
+                                                       uint32_t T, int nsel, XYZZ<F>* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  const uint32_t w = blockIdx.x / nsel;
+  const int sel = blockIdx.x % nsel;
+  const XYZZ<F>* src = (sel < 2 ? W0 : A) + (size_t)w * T;
+  XYZZ<F> acc;
+  xyzz_set_inf<F>(acc);
+  if (sel < 4) {
+    const uint32_t half = (T + 1) / 2;
+    const uint32_t lo = (sel & 1) ? half : 0u, hi = (sel & 1) ? T : half;
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += BLOCK) xyzz_add_ool<F>(acc, src[t]);
+  } else {
+    const int k = sel - 4;
+    const uint32_t lowmask = (1u << k) - 1u;
+    for (uint32_t j = threadIdx.x; j < T / 2; j += BLOCK) {
+      uint32_t t = ((j >> k) << (k + 1)) | (1u << k) | (j & lowmask);
+      xyzz_add_ool<F>(acc, src[t]);
+    }
+  }
+  block_tree_sum<F, BLOCK>(sh, acc);
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+// ---- the same two reduction levels with one point per QUAD of lanes (ec_quad.h): 3.5x shallower chains -------
+template <class C>
+__device__ __forceinline__ void quad_load(Fp<C>& v, const XYZZ<FpField<C>>* arr, size_t idx) {
+  v = reinterpret_cast<const Fp<C>*>(arr + idx)[threadIdx.x & 3u];
+}
+template <class C>
+__device__ __forceinline__ void quad_store(XYZZ<FpField<C>>* arr, size_t idx, const Fp<C>& v) {
+  reinterpret_cast<Fp<C>*>(arr + idx)[threadIdx.x & 3u] = v;
+}
+template <class C>
+__device__ __forceinline__ void quad_set_inf(Fp<C>& v) {  // (1, 1, 0, 0)
+  Fp<C> one, zero;
+  fp_one<C>(one);
+  fp_zero<C>(zero);
+  fp_select<C>(v, (threadIdx.x & 2u) != 0, zero, one);
+}
+
+// quad g of window w owns buckets [g L, (g+1) L): A = sum B_b, W0 = sum_i i B_{gL+i} (msm_chunk_body's order)
+template <class C>
+__global__ void __launch_bounds__(256) k_chunks_q(const XYZZ<FpField<C>>* __restrict__ buckets, size_t n_chunks, int l_eff,
+                                                  XYZZ<FpField<C>>* __restrict__ A, XYZZ<FpField<C>>* __restrict__ W0) {
+  typedef QuadDevice<C> B;
+  const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (g >= n_chunks) return;  // quad-uniform
+  const XYZZ<FpField<C>>* b = buckets + g * (size_t)l_eff;
+  Fp<C> acc, w0, cur, x, y;
+  quad_set_inf<C>(acc);
+  quad_set_inf<C>(w0);
+  quad_load<C>(cur, b, l_eff - 1);
+  const int steps = 2 * (l_eff - 1) + 1;  // acc += b[i]; w0 += acc; ... ; acc += b[0]
+#pragma unroll 1
+  for (int s = 0; s < steps; s++) {
+    const bool odd = (s & 1) != 0;
+    const int i = l_eff - 1 - (s >> 1);
+    fp_select<C>(x, odd, w0, acc);
+    fp_select<C>(y, odd, acc, cur);
+    if (!odd && i > 0) quad_load<C>(cur, b, i - 1);  // the next bucket arrives under this addition
+    quad_xyzz_add<C, B>(x, y);
+    fp_select<C>(w0, odd, x, w0);
+    fp_select<C>(acc, odd, acc, x);
+  }
+  quad_store<C>(A, g, acc);
+  quad_store<C>(W0, g, w0);
+}
+
+// same selections as k_masked_sums; BLOCK / 4 quads per block
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_masked_sums_q(const XYZZ<FpField<C>>* __restrict__ A,
+                                                         const XYZZ<FpField<C>>* __restrict__ W0, uint32_t T, int nsel,
+                                                         XYZZ<FpField<C>>* __restrict__ out) {
+  typedef QuadDevice<C> B;
+  typedef XYZZ<FpField<C>> X;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  X* sh = reinterpret_cast<X*>(smem);
+  constexpr uint32_t NQ = BLOCK / 4;
+  const uint32_t quad = threadIdx.x >> 2;
+  const uint32_t w = blockIdx.x / nsel;
+  const int sel = blockIdx.x % nsel;
+  const X* src = (sel < 2 ? W0 : A) + (size_t)w * T;
+  Fp<C> acc, v;
+  quad_set_inf<C>(acc);
+  // element j of this block's list -> index t into src (plain halves or "bit k set")
+  uint32_t count, lo = 0;
+  int k = 0;
+  if (sel < 4) {
+    const uint32_t half = (T + 1) / 2;
+    lo = (sel & 1) ? half : 0u;
+    count = ((sel & 1) ? T : half) - lo;
+  } else {
+    k = sel - 4;
+    count = T / 2;
+  }
+  const uint32_t lowmask = (1u << k) - 1u;
+#pragma unroll 1
+  for (uint32_t j = quad; j < count; j += NQ) {
+    const uint32_t t = sel < 4 ? lo + j : (((j >> k) << (k + 1)) | (1u << k) | (j & lowmask));
+    quad_load<C>(v, src, t);
+    quad_xyzz_add<C, B>(acc, v);
+  }
+  quad_store<C>(sh, quad, acc);
+  __syncthreads();
+#pragma unroll 1
+  for (uint32_t s = NQ / 2; s > 0; s >>= 1) {
+    if (quad < s) {  // quad-uniform
+      quad_load<C>(v, sh, quad + s);
+      quad_xyzz_add<C, B>(acc, v);
+      quad_store<C>(sh, quad, acc);
+    }
+    __syncthreads();
+  }
+  if (quad == 0) quad_store<C>(out, blockIdx.x, acc);
+}
+
+}  // namespace mlhip
