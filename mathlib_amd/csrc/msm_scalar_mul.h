@@ -64,9 +64,9 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
 // ---- one base, many scalars (point_stride = 0: [s_i]G for generators, Pedersen bases ...) ------------------------
 // From FIXED_BASE_MIN scalars on, the table T[j][d-1] = [d 2^(8j)]P (32 windows x 255 affine points, built by
 // k_scalar_mul itself from 8160 plain-integer scalars) turns every product into <= 32 mixed additions and no doubling:
-// 2^20 G1 products in 10 ms instead of 70 ms, G2 in 42 ms instead of 326 ms (profiles/r01_perf_scalar_mul.txt).  G1 runs the additions in the carry-free form (ec28.h).
+// 2^20 G1 products in 10 ms instead of 70 ms, G2 in 26 ms instead of 209 ms (profiles/r01_perf_scalar_mul.txt).  G1 runs the additions in the carry-free form (ec28.h).
 constexpr int FB_WINDOWS = 32, FB_ROW = 255;
-constexpr size_t FIXED_BASE_MIN = (size_t)1 << 16;  // the table costs one double-and-add wave time (G1 ~4 ms, G2 ~14 ms)
+constexpr size_t FIXED_BASE_MIN = (size_t)1 << 16;  // the table costs one double-and-add wave time (G1 ~4 ms, G2 ~7 ms)
 
 struct FixedBaseScratch {
   char* buf = nullptr;
@@ -130,10 +130,95 @@ __global__ void __launch_bounds__(64) k_fixed_base(const Affine<F>* __restrict__
   out[i] = a;
 }
 
+// ---- the same two kernels for G2 over lane pairs (two adjacent lanes per product, one Fp2 component each): the one-lane
+// Fp2 forms above keep ~340 live words per lane and run out of registers; MLHIP_SCALAR_MUL_ONE_LANE=1 selects them
+template <class C>
+__global__ void __launch_bounds__(64) k_scalar_mul_lp(const Affine<Fp2Field<C>>* __restrict__ points, size_t point_stride,
+                                                      const uint32_t* __restrict__ scalars, int mont, size_t n,
+                                                      Affine<Fp2Field<C>>* __restrict__ out) {
+  typedef Fp2LField<C> FL;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = t >> 1;  // both lanes of a pair share i and the scalar: every branch below is pair-uniform
+  if (i >= n) return;
+  const int hi = (int)(threadIdx.x & 1u);
+  uint32_t s[8];
+  if (mont < 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = scalars[8 * i + k];
+  } else {
+    fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  }
+  Affine<FL> P;
+  lp_load_affine<C>(P, points, i * point_stride, hi);
+  XYZZ<FL> tab[15];
+  xyzz_from_affine<FL>(tab[0], P);
+#pragma unroll 1
+  for (int k = 1; k < 15; k++) {
+    tab[k] = tab[k - 1];
+    xyzz_madd<FL>(tab[k], P, false);
+  }
+  XYZZ<FL> acc;
+  xyzz_set_inf<FL>(acc);
+  bool started = false;
+#pragma unroll 1
+  for (int w = 63; w >= 0; w--) {
+    if (started) {
+#pragma unroll 1
+      for (int d = 0; d < 4; d++) {
+        XYZZ<FL> d2;
+        xyzz_dbl<FL>(d2, acc);
+        acc = d2;
+      }
+    }
+    const uint32_t nib = (s[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (nib) {
+      xyzz_add_lp_ool<C>(acc, tab[nib - 1]);
+      started = true;
+    }
+  }
+  Affine<FL> r;
+  xyzz_to_affine<FL>(r, acc);
+  Fp<C>* o = reinterpret_cast<Fp<C>*>(out + i);
+  o[hi] = r.x.v;
+  o[2 + hi] = r.y.v;
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) k_fixed_base_lp(const Affine<Fp2Field<C>>* __restrict__ table,
+                                                      const uint32_t* __restrict__ scalars, int mont, size_t n,
+                                                      Affine<Fp2Field<C>>* __restrict__ out) {
+  typedef Fp2LField<C> FL;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = t >> 1;
+  if (i >= n) return;
+  const int hi = (int)(threadIdx.x & 1u);
+  uint32_t s[8];
+  fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  XYZZ<FL> acc;
+  xyzz_set_inf<FL>(acc);
+#pragma unroll 1
+  for (int j = 0; j < FB_WINDOWS; j++) {
+    const uint32_t d = (s[j >> 2] >> ((j & 3) * 8)) & 255u;
+    if (d) {
+      Affine<FL> q;
+      lp_load_affine<C>(q, table, (size_t)j * FB_ROW + d - 1, hi);
+      xyzz_madd<FL>(acc, q, false);
+    }
+  }
+  Affine<FL> r;
+  xyzz_to_affine<FL>(r, acc);
+  Fp<C>* o = reinterpret_cast<Fp<C>*>(out + i);
+  o[hi] = r.x.v;
+  o[2 + hi] = r.y.v;
+}
+
 template <class C, class F>
 int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_scalars, int mont, size_t n, void* d_out,
                       hipStream_t st) {
   if (n == 0) return 0;
+  const char* ol = getenv("MLHIP_SCALAR_MUL_ONE_LANE");
+  const bool one_lane = ol && ol[0] == '1';
+  (void)one_lane;
   size_t fb_min = FIXED_BASE_MIN;  // MLHIP_FIXED_BASE_MIN overrides (0 = never: always the double-and-add kernel)
   if (const char* e = getenv("MLHIP_FIXED_BASE_MIN")) {
     const long long v = atoll(e);
@@ -167,20 +252,42 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
     Affine<F>* table = (Affine<F>*)scratch;
     uint32_t* tsc = (uint32_t*)(scratch + tab_bytes);
     k_fb_scalars<<<dim3((unsigned)((kEntries + 255) / 256)), dim3(256), 0, st>>>(tsc);
-    k_scalar_mul<C, F><<<dim3((unsigned)((kEntries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
-                                                                                    kEntries, table);
+    if constexpr (!kG1) {
+      if (!one_lane)
+        k_scalar_mul_lp<C><<<dim3((unsigned)((2 * kEntries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc,
+                                                                                         -1, kEntries, table);
+      else
+        k_scalar_mul<C, F><<<dim3((unsigned)((kEntries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
+                                                                                        kEntries, table);
+    } else {
+      k_scalar_mul<C, F><<<dim3((unsigned)((kEntries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
+                                                                                      kEntries, table);
+    }
     if constexpr (kG1) {
       Affine28<C>* t28 = (Affine28<C>*)(scratch + tab_bytes + sc_bytes);
       k_points_to28<C><<<dim3((unsigned)((kEntries + 255) / 256)), dim3(256), 0, st>>>(table, kEntries, t28);
       k_fixed_base_g1<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(t28, (const uint32_t*)d_scalars, mont, n,
                                                                              (Affine<F>*)d_out);
     } else {
-      k_fixed_base<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
+      if (!one_lane)
+        k_fixed_base_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
+                                                                                  (Affine<F>*)d_out);
+      else
+        k_fixed_base<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
                                                                              (Affine<F>*)d_out);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(fb.last, st));
     return 0;
+  }
+  if constexpr (!std::is_same<F, FpField<C>>::value) {
+    if (!one_lane) {
+      k_scalar_mul_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, point_stride,
+                                                                                (const uint32_t*)d_scalars, mont, n,
+                                                                                (Affine<F>*)d_out);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
   }
   k_scalar_mul<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, point_stride,
                                                                           (const uint32_t*)d_scalars, mont, n,

@@ -110,9 +110,13 @@ def test_MultiScalarMulG2(curve):
     assert c.MultiScalarMulG2(g2s, zrs).Equals(acc)
 
 
-def test_scalar_mul_batch_kernel(curve, mlhip):
-    """batched G1.Mul / G2.Mul (mlhip_scalar_mul) against the n = 1 MSM path and the oracle"""
+@pytest.mark.parametrize("one_lane", ["0", "1"])
+def test_scalar_mul_batch_kernel(curve, mlhip, one_lane, monkeypatch):
+    """batched G1.Mul / G2.Mul (mlhip_scalar_mul) against the n = 1 MSM path and the oracle; G2 on the lane-pair kernel
+    (default) and on the one-lane kernel"""
     import ctypes
+
+    monkeypatch.setenv("MLHIP_SCALAR_MUL_ONE_LANE", one_lane)
 
     from oracle import cref
 
