@@ -57,6 +57,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pairing", action="store_true")
+    ap.add_argument("--host-paths", action="store_true", help="also time the PCIe-inclusive entry points (SURVEY 8d protocol b and c: scalars from the host with resident bases, everything from the host) and report them in extra")
     ap.add_argument("--skewed", action="store_true", help="also time the skewed-scalar MSM (all scalars < 2^32, 1 %% duplicates) and report it in extra; off by default so that the rocprofv3 kernel averages of the plain command cover the timed steps only")
     ap.add_argument("--pipelined-extra", action="store_true", help="also time the steps two-deep on two streams (extra only)")
     ap.add_argument("--sequential", action="store_true", help="one MSM in flight at a time (default: the K steps are issued two-deep through launch/finish on two plans and streams)")
@@ -238,6 +239,32 @@ def main() -> None:
             dt = (time.perf_counter() - t1) * 1e3
             best_sk = dt if best_sk is None or dt < best_sk else best_sk
         extra["skewed_scalars_below_2^32_1pct_duplicates_ms_per_msm"] = best_sk
+    # ---- PCIe-inclusive protocols (never the headline): (b) resident bases, scalars from host memory per call;
+    # (c) points and scalars from host memory per call -- the reference-shaped MultiScalarMul on host slices
+    if args.host_paths and rank == 0:
+        import ctypes
+
+        hp = points.cpu().numpy().tobytes()
+        hs = scalars.cpu().numpy().tobytes()
+        out_h = ctypes.create_string_buffer(g1b)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.mlhip_bases_create(CURVE, _lib.GROUP_G1, hp, n, 16, ctypes.byref(handle)))
+        tb, tc = [], []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            _lib.check(lib.mlhip_bases_msm(handle, hs, 0, n, out_h))
+            tb.append((time.perf_counter() - t1) * 1e3)
+        same_b = out_h.raw == res
+        _lib.check(lib.mlhip_bases_destroy(handle))
+        for _ in range(5):
+            t1 = time.perf_counter()
+            _lib.check(lib.mlhip_msm_g1(CURVE, hp, hs, 0, n, 16, out_h))
+            tc.append((time.perf_counter() - t1) * 1e3)
+        extra["pcie_inclusive"] = {
+            "scalars_from_host_resident_bases_ms": min(tb[1:]),
+            "points_and_scalars_from_host_ms": min(tc[1:]),
+            "match_resident_result": bool(same_b and out_h.raw == res),
+        }
     # ---- batched pairing (BASELINE configs[2]): 65 536 x (Miller loop + final exponentiation)
     if not args.no_pairing:
         npair = N_PAIRINGS
