@@ -113,6 +113,66 @@ __device__ void block_tree_sum(XYZZ<F>* sh, const XYZZ<F>& mine) {
   }
 }
 
+// one XYZZ per quad of lanes (ec_quad.h): lane q of a quad holds coordinate q (X, Y, ZZ, ZZZ)
+template <class C>
+__device__ __forceinline__ void quad_load(Fp<C>& v, const XYZZ<FpField<C>>* arr, size_t idx) {
+  v = reinterpret_cast<const Fp<C>*>(arr + idx)[threadIdx.x & 3u];
+}
+template <class C>
+__device__ __forceinline__ void quad_store(XYZZ<FpField<C>>* arr, size_t idx, const Fp<C>& v) {
+  reinterpret_cast<Fp<C>*>(arr + idx)[threadIdx.x & 3u] = v;
+}
+template <class C>
+__device__ __forceinline__ void quad_set_inf(Fp<C>& v) {  // (1, 1, 0, 0)
+  Fp<C> one, zero;
+  fp_one<C>(one);
+  fp_zero<C>(zero);
+  fp_select<C>(v, (threadIdx.x & 2u) != 0, zero, one);
+}
+
+// quad g of window w owns buckets [g L, (g+1) L): A = sum B_b, W0 = sum_i i B_{gL+i} (msm_chunk_body's order)
+
+// The same tree for G1 with one point per QUAD of lanes: a group addition is 4 rounds of one field product per lane
+// instead of 14 in a row, so the 8 dependent levels cost ~3x less (the tree is pure latency: one workgroup, one
+// slice).  BLOCK / 4 quads first fold four entries each, then halve.
+template <class C, int BLOCK>
+__device__ void block_tree_sum_q(XYZZ<FpField<C>>* sh, const XYZZ<FpField<C>>& mine) {
+  typedef QuadDevice<C> B;
+  constexpr uint32_t NQ = BLOCK / 4;
+  const uint32_t quad = threadIdx.x >> 2;
+  sh[threadIdx.x] = mine;
+  __syncthreads();
+  Fp<C> acc, v;
+  quad_load<C>(acc, sh, quad);
+#pragma unroll 1
+  for (uint32_t j = 1; j < 4; j++) {
+    quad_load<C>(v, sh, quad + j * NQ);
+    quad_xyzz_add<C, B>(acc, v);
+  }
+  __syncthreads();  // every entry has been read
+  quad_store<C>(sh, quad, acc);
+  __syncthreads();
+#pragma unroll 1
+  for (uint32_t s = NQ / 2; s > 0; s >>= 1) {
+    if (quad < s) {  // quad-uniform
+      quad_load<C>(v, sh, quad + s);
+      quad_xyzz_add<C, B>(acc, v);
+      quad_store<C>(sh, quad, acc);
+    }
+    __syncthreads();
+  }
+}
+
+// the tree the long-bucket kernels use: quads for G1, one lane per point for G2
+template <class F, int BLOCK>
+__device__ __forceinline__ void block_tree_sum_auto(XYZZ<F>* sh, const XYZZ<F>& mine) {
+  if constexpr (std::is_same<F, FpField<typename F::Curve>>::value)
+    block_tree_sum_q<typename F::Curve, BLOCK>(sh, mine);
+  else
+    block_tree_sum<F, BLOCK>(sh, mine);
+}
+
+
 // ---- long buckets (skewed scalars: small values, equal values, plain sums of points) ---------------------------
 // A bucket above the threshold is cut into slices of BIG_SLICE entries; k_big_slices sums every slice with one
 // workgroup (so one bucket holding all n points still fills the GPU: 2^20 entries = 256 slices), the combine kernels
@@ -183,7 +243,7 @@ __global__ void __launch_bounds__(BLOCK) k_big_slices(const Affine<F>* __restric
     XYZZ<F> acc;
     xyzz_set_inf<F>(acc);
     msm_accumulate_range<F>(acc, points, sorted, begin + threadIdx.x, end, BLOCK);
-    block_tree_sum<F, BLOCK>(sh, acc);
+    block_tree_sum_auto<F, BLOCK>(sh, acc);
     if (threadIdx.x == 0) partials[sid] = sh[0];
     __syncthreads();
   }
@@ -201,7 +261,7 @@ __device__ void big_bucket_total(XYZZ<F>& sum, XYZZ<F>* sh, const XYZZ<F>* __res
   XYZZ<F> acc;
   xyzz_set_inf<F>(acc);
   for (uint32_t k = s0 + threadIdx.x; k < s1; k += BLOCK) xyzz_add_ool<F>(acc, partials[k]);
-  block_tree_sum<F, BLOCK>(sh, acc);
+  block_tree_sum_auto<F, BLOCK>(sh, acc);
   if (threadIdx.x == 0) sum = sh[0];
   __syncthreads();
 }

@@ -43,23 +43,6 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums(const XYZZ<F>* __restrict
 
 // ---- the same two reduction levels with one point per QUAD of lanes (ec_quad.h): 3.5x shallower chains -------
 template <class C>
-__device__ __forceinline__ void quad_load(Fp<C>& v, const XYZZ<FpField<C>>* arr, size_t idx) {
-  v = reinterpret_cast<const Fp<C>*>(arr + idx)[threadIdx.x & 3u];
-}
-template <class C>
-__device__ __forceinline__ void quad_store(XYZZ<FpField<C>>* arr, size_t idx, const Fp<C>& v) {
-  reinterpret_cast<Fp<C>*>(arr + idx)[threadIdx.x & 3u] = v;
-}
-template <class C>
-__device__ __forceinline__ void quad_set_inf(Fp<C>& v) {  // (1, 1, 0, 0)
-  Fp<C> one, zero;
-  fp_one<C>(one);
-  fp_zero<C>(zero);
-  fp_select<C>(v, (threadIdx.x & 2u) != 0, zero, one);
-}
-
-// quad g of window w owns buckets [g L, (g+1) L): A = sum B_b, W0 = sum_i i B_{gL+i} (msm_chunk_body's order)
-template <class C>
 __global__ void __launch_bounds__(256) k_chunks_q(const XYZZ<FpField<C>>* __restrict__ buckets, size_t n_chunks, int l_eff,
                                                   XYZZ<FpField<C>>* __restrict__ A, XYZZ<FpField<C>>* __restrict__ W0) {
   typedef QuadDevice<C> B;
