@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) k_accumulate28(const Affine28<C>* __restr
   if (tid >= n_buckets) return;
   const size_t g = order[tid];
   uint32_t cnt = counts[g];
-  if (cnt > big_threshold) {  // summed by a whole workgroup in k_accumulate_big (boundary form)
+  if (cnt > big_threshold) {  // summed in slices by k_big_slices / k_accumulate_big (boundary form)
     uint32_t pos = atomicAdd(big_count, 1u);
     big_list[pos] = (uint32_t)g;
     return;

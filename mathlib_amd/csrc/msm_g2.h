@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int hi = (int)(threadIdx.x & 1u);
   const size_t g = order[pair];
   const uint32_t cnt = counts[g];
-  if (cnt > big_threshold) {  // summed by a whole workgroup in k_accumulate_big (boundary form)
+  if (cnt > big_threshold) {  // summed in slices by k_big_slices / k_accumulate_big (boundary form)
     if (!hi) {
       uint32_t pos = atomicAdd(big_count, 1u);
       big_list[pos] = (uint32_t)g;

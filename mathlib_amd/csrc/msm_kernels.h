@@ -33,7 +33,7 @@
 
 namespace mlhip {
 
-constexpr uint32_t BIG_BUCKET_MIN = 256;  // a bucket is summed by a whole workgroup above max(this, 8 x the mean length)
+constexpr uint32_t BIG_BUCKET_MIN = 256;  // a bucket goes to the sliced long-bucket path above max(this, 8 x the mean length)
 constexpr int CHUNK_L = 8;            // buckets per level-1 reduction thread
 
 }  // namespace mlhip
