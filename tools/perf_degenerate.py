@@ -42,7 +42,13 @@ two = rnd(n).clone()
 two[:, 1:] = 0
 two[:, 0] &= 1
 cases["bits (0/1)"] = two
-plan = _lib.MsmPlan(cid, 1, n, 16)
+group = 2 if (len(sys.argv) > 2 and sys.argv[2] == "g2") else 1
+if group == 2:
+    base2 = torch.frombuffer(bytearray(bytes.fromhex(g["g2_gen"])), dtype=torch.uint8).to(dev)
+    P = torch.empty(n * g2b, dtype=torch.uint8, device=dev)
+    _lib.check(lib.mlhip_scalar_mul_device(cid, 2, base2.data_ptr(), 0, rnd(n).data_ptr(), 0, n, P.data_ptr(), st))
+    print("G2:")
+plan = _lib.MsmPlan(cid, group, n, 16)
 plan.set_profiling(True)
 for name, S in cases.items():
     best = 1e9
