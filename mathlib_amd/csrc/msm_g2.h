@@ -99,6 +99,75 @@ __global__ void __launch_bounds__(256) k_accumulate_lp(const Affine<Fp2Field<C>>
   lp_store_xyzz<C>(buckets, g, acc, hi);
 }
 
+// ---- slice sums of long G2 buckets over lane pairs (k_big_slices is the one-lane form: ~340 live words per lane) ------
+// BLOCK / 2 pairs stride over the slice's entries with the lane-pair mixed addition, then an LDS tree of lane-pair
+// additions; slice bookkeeping as in k_big_slices (msm_accumulate.h).
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_big_slices_lp(const Affine<Fp2Field<C>>* __restrict__ points,
+                                                         const uint32_t* __restrict__ sorted,
+                                                         const uint32_t* __restrict__ offsets,
+                                                         const uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ big_list,
+                                                         const uint32_t* __restrict__ big_count,
+                                                         const uint32_t* __restrict__ prefix,
+                                                         XYZZ<Fp2Field<C>>* __restrict__ partials) {
+  typedef Fp2LField<C> FL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<Fp2Field<C>>* sh = reinterpret_cast<XYZZ<Fp2Field<C>>*>(smem);
+  __shared__ uint32_t s_bi;
+  constexpr uint32_t PAIRS = BLOCK / 2;
+  const uint32_t pid = threadIdx.x >> 1;
+  const int hi = lane_is_hi() ? 1 : 0;
+  const uint32_t nbig = *big_count;
+  if (nbig == 0) return;
+  const uint32_t total = prefix[nbig];
+  for (uint32_t sid = blockIdx.x; sid < total; sid += gridDim.x) {
+    if (threadIdx.x == 0) {
+      uint32_t lo = 0, up = nbig - 1;
+      while (lo < up) {
+        const uint32_t mid = (lo + up + 1) >> 1;
+        if (prefix[mid] <= sid)
+          lo = mid;
+        else
+          up = mid - 1;
+      }
+      s_bi = lo;
+    }
+    __syncthreads();
+    const uint32_t bi = s_bi;
+    const uint32_t g = big_list[bi];
+    const size_t first = offsets[g], last = first + counts[g];
+    const size_t begin = first + (size_t)(sid - prefix[bi]) * BIG_SLICE;
+    const size_t end = begin + BIG_SLICE < last ? begin + BIG_SLICE : last;
+    XYZZ<FL> acc, b;
+    xyzz_set_inf<FL>(acc);
+    for (size_t k = begin + pid; k < end; k += PAIRS) {  // pair-uniform bounds
+      const uint32_t e = sorted[k];
+      Affine<FL> q;
+      lp_load_affine<C>(q, points, e & 0x7fffffffu, hi);
+      xyzz_madd<FL>(acc, q, (e >> 31) != 0);
+    }
+    lp_store_xyzz<C>(sh, pid, acc, hi);
+    __syncthreads();
+    for (uint32_t s2 = PAIRS / 2; s2 > 0; s2 >>= 1) {
+      if (pid < s2) {  // pair-uniform
+        XYZZ<FL> a;
+        lp_load_xyzz<C>(a, sh, pid, hi);
+        lp_load_xyzz<C>(b, sh, pid + s2, hi);
+        xyzz_add_lp_ool<C>(a, b);
+        lp_store_xyzz<C>(sh, pid, a, hi);
+      }
+      __syncthreads();
+    }
+    if (pid == 0) {
+      XYZZ<FL> a;
+      lp_load_xyzz<C>(a, sh, 0, hi);
+      lp_store_xyzz<C>(partials, sid, a, hi);
+    }
+    __syncthreads();
+  }
+}
+
 // ---- G2 accumulation in the carry-free form over lane pairs (ec28_lp.h; curves with u^2 = -1) -----------------
 template <class C>
 struct alignas(8) AffineG2_28 {  // x.c0 | x.c1 | y.c0 | y.c1, 56 (40) bytes each

@@ -133,10 +133,18 @@ void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
 // there are none)
 template <class F, int BB>
 void launch_big_slices(mlhip_msm_plan* p, const Affine<F>* d_points, hipStream_t st) {
+  typedef typename F::Curve C;
   k_big_prefix<<<dim3(1), dim3(1024), 0, st>>>(p->d_counts, p->d_biglist, p->d_bigcount, p->d_bigprefix);
-  k_big_slices<F, BB><<<dim3(1024), dim3(BB), BB * sizeof(XYZZ<F>), st>>>(d_points, p->d_sorted, p->d_offsets, p->d_counts,
-                                                                        p->d_biglist, p->d_bigcount, p->d_bigprefix,
-                                                                        (XYZZ<F>*)p->d_bigpart);
+  if constexpr (std::is_same<F, Fp2Field<C>>::value) {
+    // G2: 128 lane pairs per slice (48 KB of LDS)
+    k_big_slices_lp<C, 256><<<dim3(1024), dim3(256), 128 * sizeof(XYZZ<F>), st>>>(d_points, p->d_sorted, p->d_offsets,
+                                                                                  p->d_counts, p->d_biglist, p->d_bigcount,
+                                                                                  p->d_bigprefix, (XYZZ<F>*)p->d_bigpart);
+  } else {
+    k_big_slices<F, BB><<<dim3(1024), dim3(BB), BB * sizeof(XYZZ<F>), st>>>(d_points, p->d_sorted, p->d_offsets, p->d_counts,
+                                                                          p->d_biglist, p->d_bigcount, p->d_bigprefix,
+                                                                          (XYZZ<F>*)p->d_bigpart);
+  }
 }
 
 // digits -> entries sorted by (window, bucket) in d_sorted / d_offsets / d_counts, and the bucket order by population
