@@ -67,10 +67,10 @@ int mlhip_sizes(int curve, size_t* fp, size_t* g1, size_t* g2, size_t* gt);
 /* ---- host-buffer entry points (what the cgo shim binds) ------------------------------------- */
 /* out = sum_i [scalars[i]] points[i].  window_c = 0 picks a window from n; BASELINE config 2 uses 16.
  * n = 0 gives the point at infinity (the reference's MultiExp on empty slices).  Plans and input buffers are pooled
- * between calls (mlhip_release_cache below).  G1 calls of 2^19 pairs and more (BLS12-381 G2: 2^18) are streamed over
- * PCIe in segments of 2^18 (2^17) pairs: upload of one segment under the kernels of the one before;
- * MLHIP_STREAM_SEGMENTS=K fixes the count, 0 = one pass.  Smaller calls, and G2 on the other curves, upload the points
- * beside the sort of the scalars. */
+ * between calls (mlhip_release_cache below).  G1 calls of 2^19 pairs and more (G2: 2^18) are streamed over PCIe in
+ * segments of 2^18 (2^17) pairs: upload of one segment under the kernels of the one before;
+ * MLHIP_STREAM_SEGMENTS=K fixes the count, 0 = one pass.  Smaller calls upload the points beside the sort of the
+ * scalars. */
 int mlhip_msm_g1(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
                  void* out_affine);
 int mlhip_msm_g2(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,

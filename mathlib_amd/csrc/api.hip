@@ -317,7 +317,8 @@ void pool_release(PoolEntry* e, bool failed) {
 // Number of segments a host-buffer MSM is streamed in (1 = one upload, one pass).  Measured on MI355X / PCIe gen5
 // (tools/perf_hostapi.py): from 2^19 points the transfer is worth hiding; MLHIP_STREAM_SEGMENTS overrides (0/1 = off).
 int stream_segments(int group, size_t n, const mlhip_msm_plan* plan) {
-  if (!plan->d_points28 || !plan->aux) return 1;  // G1 on every curve, G2 on BLS12-381 (the carry-free kernels)
+  // G1 needs the carry-free kernels (always there unless MLHIP_ACC32=1); G2 streams on every curve
+  if (!plan->aux || (group == MLHIP_GROUP_G1 && !plan->d_points28)) return 1;
   if (const char* e = getenv("MLHIP_STREAM_SEGMENTS")) {
     int v = atoi(e);
     if (v < 2) return 1;

@@ -93,7 +93,7 @@ int plan_alloc(mlhip_msm_plan* p) {
   HIPCHK(hipHostMalloc(&p->h_out, (size_t)p->W * p->nsel * p->xyzz_size, hipHostMallocDefault));
   for (int i = 0; i < 5; i++) HIPCHK(hipEventCreate(&p->ev[i]));
   HIPCHK(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
-  if (p->d_points28) {
+  {  // the auxiliary stream: point conversion beside the sort, and the uploads of a streamed host-buffer MSM
     HIPCHK(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
@@ -338,16 +338,19 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
   typedef Affine<F> A;
   typedef XYZZ<F> X;
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
-  if (!p->d_points28 || !p->aux) return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM needs the carry-free accumulation path");
+  // G2 on the curves without the carry-free lane-pair kernel keeps its bucket state in the boundary form
+  constexpr bool kBoundary = kG2 && !(C::BETA == -1 && C::N28 == 14);
+  if (!p->aux || (!kBoundary && !p->d_points28))
+    return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM needs the auxiliary stream (and, for G1, the carry-free path)");
   constexpr size_t kStateBytes = kG2 ? 2 * sizeof(XYZZ28L<Fp28<C>>) : sizeof(XYZZ28<C>);
   if (n == 0 || K < 2 || K > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "bad segment count");
   const size_t nbuckets = (size_t)p->W * p->M;
-  if (!p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * kStateBytes));
+  if (!kBoundary && !p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * kStateBytes));
   for (int s = 0; s < K; s++)
     if (!p->ev_seg[s]) HIPCHK(hipEventCreateWithFlags(&p->ev_seg[s], hipEventDisableTiming));
   // resident bases (h_points == nullptr): only the scalars travel; the carry-free copy must already be there
   const bool resident = h_points == nullptr;
-  if (resident && !(p->points_static && p->conv_src == d_points && n <= p->conv_n))
+  if (resident && !kBoundary && !(p->points_static && p->conv_src == d_points && n <= p->conv_n))
     return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM over resident bases needs their converted copy");
   p->pending_n = n;
   p->pending = true;
@@ -367,7 +370,9 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
     HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
     if (!resident) {
       HIPCHK(hipMemcpyAsync(dpt, hp + off * sizeof(A), len * sizeof(A), hipMemcpyHostToDevice, p->aux));
-      if constexpr (kG2)
+      if constexpr (kBoundary) {
+        // the boundary-form kernel reads the uploaded points as they are
+      } else if constexpr (kG2)
         k_points_to28_g2<C><<<dim3((unsigned)((4 * len + 255) / 256)), dim3(256), 0, p->aux>>>(
             dpt, len, (AffineG2_28<C>*)p->d_points28 + off);
       else
@@ -383,7 +388,15 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
     }
     uint32_t big_threshold = (uint32_t)std::min<size_t>((len >> (p->c - 1)) * 8, 1u << 30);
     if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
-    if constexpr (kG2) {
+    if constexpr (kBoundary) {
+      k_accumulate_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+          dpt, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist, p->d_bigcount, flags,
+          (X*)p->d_buckets);
+      constexpr int BB = 128;
+      launch_big_slices<F, BB>(p, dpt, st);
+      k_accumulate_big_fold<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
+                                                                             (const X*)p->d_bigpart, flags, (X*)p->d_buckets);
+    } else if constexpr (kG2) {
       k_accumulate28_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
           (const AffineG2_28<C>*)p->d_points28 + off, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
           big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);

@@ -15,8 +15,8 @@ int mlhip_tu_plan_finish_Bls377(mlhip_msm_plan* p, void* out_affine, void* out_x
 }
 int mlhip_tu_plan_stream_Bls377(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points,
                             const void* h_scalars, int mont, size_t n, int segments, hipStream_t st) {
-  if (p->group != MLHIP_GROUP_G1) return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM: no carry-free G2 path on this curve");
-  return plan_stream<Bls377, FpField<Bls377>>(p, d_points, d_scalars, h_points, h_scalars, mont, n, segments, st);
+  if (p->group == MLHIP_GROUP_G1) return plan_stream<Bls377, FpField<Bls377>>(p, d_points, d_scalars, h_points, h_scalars, mont, n, segments, st);
+  return plan_stream<Bls377, Fp2Field<Bls377>>(p, d_points, d_scalars, h_points, h_scalars, mont, n, segments, st);
 }
 int mlhip_tu_scalar_mul_Bls377(int group, const void* d_points, size_t point_stride, const void* d_scalars, int mont,
                               size_t n, void* d_out, hipStream_t st) {

@@ -16,7 +16,7 @@ from mathlib_amd import _lib  # noqa: E402
 
 lib = _lib.load()
 n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
-g = load_golden("BLS12-381")
+g = load_golden(os.environ.get("MLHIP_PERF_CURVE", "BLS12-381"))
 cid = g["curve_id"]
 fpb, g1b, g2b, gtb = _lib.sizes(cid)
 dev = torch.device("cuda", 0)
