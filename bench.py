@@ -1,20 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on its configs[1]: BLS12-381 2^20-point G1 MSM (Pippenger, c = 16)
-per MI355X, with the batched-pairing rate reported beside it.
+"""bench.py -- BASELINE.json's metric (G1 scalar-muls/sec + pairings/sec) on BASELINE.json's configs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--config 2|3|4|5] --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one MSM over the rank's resident (point, scalar) shard: kernels, D2H of the window sums,
-host Horner tail, and for N > 1 the all-gather of the per-rank partial sums over RCCL plus the local
-EC addition.  The timed steps run one at a time (so the per-kernel HIP-event times behind `roofline` are
-unshared); the throughput of the same steps issued two-deep through mlhip_msm_launch / mlhip_msm_finish
-on two streams is reported as an extra, not as `value`.  Points and scalars are in HBM before the timed region starts.  Weak scaling: every rank
-holds 2^20 pairs, `value` = N * 2^20 * K / (max over ranks of the K-step time).
+--config (SURVEY.md 8d numbering; default 2, the configuration BASELINE.json's metric is quoted on):
+  2  BLS12-381 2^20-point G1 MSM per GPU, Pippenger c = 16          (BASELINE configs[1], weak scaling)
+  3  BLS12-381 batch of 65 536 optimal-ate pairings + FExp per GPU  (BASELINE configs[2], weak scaling)
+  4  BLS12-381 2^24-point G1 + G2 MSM (shared scalars), the pairs sharded contiguously over the N ranks
+                                                                    (BASELINE configs[3], strong scaling)
+  5  BLS12-377 2^22-point G1 MSM sharded over the N ranks           (BASELINE configs[4], strong scaling)
+At N = 1 configs 4 and 5 run whole on one GPU.
 
-Inputs are synthetic and produced by the product itself: P_i = [k_i]G from the batched scalar-mul
-kernel, k_i and the MSM scalars from torch's generator (seeded per rank).  The oracle (oracle/cref) is
-used ONLY for the `cpu_baseline` leg: the same workload timed on the host cores of rank 0 at N = 1.
+One "step" = one pass of the hot path over the rank's resident shard: the MSM kernels, D2H of the window sums, the
+host Horner tail and, for N > 1, ONE all-gather of the per-rank partial sums over RCCL plus the local EC addition
+(config 4: the G1 and the G2 MSM of the step are both in flight, their partials share the all-gather).  Timed
+protocol: W warm-up steps, then exactly K steps, ONE step in flight at a time, bracketed by barrier +
+synchronize; `value` = units of all ranks / max over ranks of the K-step time -- protocol (a), inputs resident in HBM
+when the timed region starts.  `extra` carries median / min of the K per-step times and, measured after the timed
+region without any flag: protocol (b) (resident bases, scalars from host memory per call: mlhip_bases_msm), protocol
+(c) (points and scalars from host memory: mlhip_msm_g1, what the reference's MultiScalarMul maps to), the
+skewed-scalar MSM (all scalars < 2^32, 1 % duplicated pairs), the same steps issued two-deep on two plans and streams,
+and (config 2) the 65 536-pairing batch.  The PCIe-inclusive rates are never `value`.  --kernels-only skips every
+extra and the CPU baseline, so that a rocprofv3 run of it averages exactly the timed steps' kernels.
+
+`roofline` is for the dominant kernel (the bucket accumulation; the fused pairing kernel for config 3): algorithmic
+bytes of one launch / its average duration, from HIP events recorded on the stream the kernel is launched on, in the
+timed steps themselves (config 4: in a separate pass with one MSM in flight, so the times are unshared).
+
+Inputs are synthetic and produced by the product itself: P_i = [k_i]G from the batched scalar-mul kernel, k_i and the
+MSM scalars from torch's generator (seeded per config and global pair index, so a shard is the same data whatever N is).
+The oracle (oracle/cref) is used ONLY for the `cpu_baseline` leg, after the timed region, on rank 0 at N = 1.
 """
 from __future__ import annotations
 
@@ -22,6 +38,7 @@ import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,15 +50,28 @@ sys.path.insert(0, ROOT)
 from mathlib_amd import _lib, dist as mdist  # noqa: E402
 from mathlib_amd.driver import Curve  # noqa: E402
 
-CURVE = _lib.CURVE_BLS12_381
-N_PER_GPU = 1 << 20
+G1, G2 = _lib.GROUP_G1, _lib.GROUP_G2
 WINDOW_C = 16
 N_PAIRINGS = 1 << 16
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-MSM_BYTES_PER_UNIT = 128  # 96 B affine point + 32 B scalar
-PAIRING_BYTES_PER_UNIT = 864  # 96 + 192 in, 576 out
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 INT_MAC_PEAK = 3.19e13  # measured v_mad_u64_u32 lane-ops/s, profiles/r01_ubench_int.txt
-MACS_PER_FP_MUL = 288  # 2 * 12^2 32x32->64 multiply-accumulates per 384-bit Montgomery product
+PAIRING_BYTES_PER_UNIT = 864  # 96 + 192 in, 576 out (SURVEY.md 8d)
+
+CONFIGS = {
+    2: dict(curve=_lib.CURVE_BLS12_381, curve_name="BLS12-381", log_n=20, groups=(G1,), scaling="weak",
+            workload="BLS12-381 2^20-point G1 MSM per GPU, Pippenger c=16 (BASELINE configs[1]); inputs resident in HBM"),
+    3: dict(curve=_lib.CURVE_BLS12_381, curve_name="BLS12-381", log_n=16, groups=(), scaling="weak",
+            workload="BLS12-381 batch of 65 536 optimal-ate pairings + FExp per GPU (BASELINE configs[2]); inputs resident in HBM"),
+    4: dict(curve=_lib.CURVE_BLS12_381, curve_name="BLS12-381", log_n=24, groups=(G1, G2), scaling="strong",
+            workload="BLS12-381 2^24-point G1 + G2 MSM (shared scalars) sharded over the ranks, Pippenger c=16 (BASELINE configs[3]); inputs resident in HBM"),
+    5: dict(curve=_lib.CURVE_BLS12_377, curve_name="BLS12-377", log_n=22, groups=(G1,), scaling="strong",
+            workload="BLS12-377 2^22-point G1 MSM sharded over the ranks, Pippenger c=16 (BASELINE configs[4]); inputs resident in HBM"),
+}
+# algorithmic bytes per scalar-mul: affine point + 32-byte scalar
+MSM_BYTES = {(0, G1): 96, (1, G1): 128, (2, G1): 128, (0, G2): 160, (1, G2): 224, (2, G2): 224}
+# gnark-crypto's BLS12-377 G2 generator is not in the reference tree; any r-torsion point serves as the base of the
+# synthetic points: the golden file's generator (tests/golden/bls12_377.json, produced by oracle/pyref.py) is read at
+# run time only for config runs on that curve's G2, which no BASELINE config asks for.
 
 
 def rand_scalars(n: int, gen: torch.Generator, device) -> torch.Tensor:
@@ -50,20 +80,42 @@ def rand_scalars(n: int, gen: torch.Generator, device) -> torch.Tensor:
     return lo.view(torch.uint8).reshape(n, 32).contiguous()
 
 
+def seeded_scalars(n_total: int, lo: int, hi: int, seed: int, dev) -> torch.Tensor:
+    """rows [lo, hi) of a stream of n_total rows, generated in blocks of 2^18 rows each seeded by its block index
+    (so a shard holds the same rows whatever the number of ranks)"""
+    blk = 1 << 18
+    out = []
+    gen = torch.Generator(device=dev)
+    for b in range(lo // blk, (hi + blk - 1) // blk):
+        gen.manual_seed(seed * 1000003 + b)
+        rows = rand_scalars(min(blk, n_total - b * blk), gen, dev)
+        a, z = max(lo, b * blk) - b * blk, min(hi, (b + 1) * blk) - b * blk
+        out.append(rows[a:z])
+    return torch.cat(out).contiguous() if out else torch.empty((0, 32), dtype=torch.uint8, device=dev)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--log-n", type=int, default=0, help="override the config's size (rehearsals only: the line is marked reduced and is not a measurement of the config)")
+    ap.add_argument("--kernels-only", action="store_true", help="timed steps only: no extras, no pairing batch, no CPU baseline (rocprofv3 passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pairing", action="store_true")
-    ap.add_argument("--host-paths", action="store_true", help="also time the PCIe-inclusive entry points (SURVEY 8d protocol b and c: scalars from the host with resident bases, everything from the host) and report them in extra")
-    ap.add_argument("--skewed", action="store_true", help="also time the skewed-scalar MSM (all scalars < 2^32, 1 %% duplicates) and report it in extra; off by default so that the rocprofv3 kernel averages of the plain command cover the timed steps only")
-    ap.add_argument("--pipelined-extra", action="store_true", help="also time the steps two-deep on two streams (extra only)")
-    ap.add_argument("--sequential", action="store_true", help="one MSM in flight at a time (default: the K steps are issued two-deep through launch/finish on two plans and streams)")
-    ap.add_argument("--pipelined", action="store_true", help="accepted for compatibility: two in flight is the default")
+    ap.add_argument("--no-extras", action="store_true", help="skip protocol (b)/(c), the skewed run and the two-deep run")
+    ap.add_argument("--pipelined", action="store_true", help="issue the timed steps two-deep (launch of step i+1 before finish of step i); default: one step in flight")
+    # accepted for compatibility with round-1 command lines
+    ap.add_argument("--sequential", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--host-paths", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--skewed", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pipelined-extra", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.kernels_only:
+        args.no_cpu_baseline = args.no_pairing = args.no_extras = True
 
+    cfg = CONFIGS[args.config]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -89,260 +141,402 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    # ---- synthetic inputs, resident in HBM
-    fpb, g1b, g2b, gtb = _lib.sizes(CURVE)
-    curve = Curve(CURVE)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x6D6C686970 + rank)
-    n = N_PER_GPU
-    k = rand_scalars(n, gen, dev)
-    base = torch.frombuffer(bytearray(curve.GenG1().raw), dtype=torch.uint8).to(dev)
-    points = torch.empty(n * g1b, dtype=torch.uint8, device=dev)
-    _lib.check(lib.mlhip_scalar_mul_device(CURVE, _lib.GROUP_G1, base.data_ptr(), 0, k.data_ptr(), 0, n, points.data_ptr(), stream))
-    scalars = rand_scalars(n, gen, dev)
-    torch.cuda.synchronize()
-
-    # two plans on two streams (the second one only for the pipelined extra)
-    plans = [_lib.MsmPlan(CURVE, _lib.GROUP_G1, n, WINDOW_C) for _ in range(2)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-    for pl in plans:
-        pl.set_profiling(True)
-    phase = {}
-
-    def finalize(j: int, record: bool) -> bytes:
-        part = plans[j].finish()
-        if record:
-            for kname, v in plans[j].timings().items():
-                phase[kname] = phase.get(kname, 0.0) + v
-        return mdist.combine_partials(CURVE, _lib.GROUP_G1, part, dev)
-
-    def run_steps(k: int, record: bool) -> bytes:
-        pending, res = None, None
-        for i in range(k):
-            j = i & 1
-            plans[j].launch(points.data_ptr(), scalars.data_ptr(), n, False, streams[j].cuda_stream)
-            if pending is not None:
-                res = finalize(pending, record)
-            pending = j
-        if pending is not None:
-            res = finalize(pending, record)
-        return res
-
     def barrier():
         if world > 1:
             import torch.distributed as dist
 
             dist.barrier()
 
-    def run_sequential(k: int, record: bool) -> bytes:
-        res = None
-        for _ in range(k):
-            plans[0].launch(points.data_ptr(), scalars.data_ptr(), n, False, streams[0].cuda_stream)
-            res = finalize(0, record)
-        return res
-
-    # ---- timed region: the K steps, two in flight (step i+1 is launched before step i is finished: its sort
-    # kernels run under the host tail and the latency-bound end of the previous reduction); --sequential keeps one in
-    # flight.  Per-kernel HIP events stay on the stream each kernel is launched on.
-    timed = run_sequential if args.sequential else run_steps
-    timed(args.warmup, False)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = timed(args.steps, True)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if rehearsal else dev)
+        t = torch.tensor([x], dtype=torch.float64, device=torch.device("cpu") if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # ---- extra (not the headline): the same K steps issued two-deep through launch/finish on two streams
-    pipelined = None
-    if args.pipelined_extra and args.sequential:
-        saved = dict(phase)
-        run_steps(2, False)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_steps(args.steps, False)
-        torch.cuda.synchronize()
-        pipelined = n * args.steps / (time.perf_counter() - t1)
-        phase.clear()
-        phase.update(saved)
-    steps = max(args.steps, 1)
-    phase = {kname: v / steps for kname, v in phase.items()}
-    value = world * n * args.steps / elapsed
+        return float(t.item())
 
-    # ---- roofline of the dominant kernel (the bucket accumulation): algorithmic bytes / its HIP-event duration
-    acc_ms = phase.get("accumulate", 0.0)
-    acc32 = os.environ.get("MLHIP_ACC32", "") == "1"
-    acc_kernel = "k_accumulate<FpField<Bls381>>" if acc32 else "k_accumulate28<Bls381>"
-    # multiplier instructions per mixed addition: 10 x 288 v_mad_u64_u32 (+ as many v_addc) in the boundary form;
-    # 8 x 196 + 2 x 105 product and 9 x 210 reduction v_mad_i64_i32 + 9 x 14 v_mul_lo_u32 in the carry-free form
-    v_mad_per_madd = 10 * MACS_PER_FP_MUL if acc32 else (8 * 196 + 2 * 105 + 9 * 210 + 9 * 14)
-    achieved = (MSM_BYTES_PER_UNIT * n) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json): the
-    # counters cannot be read from inside this process, so this is the per-launch figure of the same workload
-    traffic, traffic_note = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pm = json.load(f)
-        kk = next(v for k_, v in pm["kernels"].items() if k_.startswith(acc_kernel.split("<")[0] + "<") and "Fp2" not in k_)
-        traffic = (kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024.0
-        traffic_note = "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01_pmc_traffic.json, uncorrected (gather pattern, Infinity-Cache hits included): every point row is re-read once per window (16 x 112 B x n), plus the 96 MiB bucket array written once"
-    except Exception:
-        pass
-    roofline = {
-        "bound": "hbm",
-        "kernel": acc_kernel,
-        "achieved": achieved,
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic,
-        "traffic_note": traffic_note,
-        "avg_kernel_ms": acc_ms,
-        "phase_ms": phase,
-        # the path is integer-ALU bound, not HBM bound: W = 16 mixed additions per scalar, each V_MAD_PER_MADD
-        # multiplier instructions => fraction of the measured v_mad issue peak (profiles/r01_ubench_int.txt).  The
-        # kernel is power limited: its effective clock is ~1.9-2.2 GHz, not 2.4 (profiles/r01_pmc_clocks.txt).
-        "int_alu": {
-            "form": "carry-free 28-bit limbs (fp28.h)" if not acc32 else "saturated 32-bit limbs (fp.h)",
-            "fp_mul_per_s": (n * 16 * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
-            "v_mad_per_mixed_add": v_mad_per_madd,
-            "v_mad_frac_of_measured_peak": ((n * 16 * v_mad_per_madd) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
-        },
-    }
+    CURVE = cfg["curve"]
+    fpb, g1b, g2b, gtb = _lib.sizes(CURVE)
+    curve = Curve(CURVE)
+    log_n = args.log_n or cfg["log_n"]
+    reduced = bool(args.log_n) and args.log_n != cfg["log_n"]
+    n_cfg = 1 << log_n
+    if cfg["scaling"] == "weak":
+        n_total, lo, hi = n_cfg * world, n_cfg * rank, n_cfg * (rank + 1)
+    else:
+        n_total = n_cfg
+        lo, hi = mdist.shard_bounds(n_total, rank, world)
+    n = hi - lo
+    seed = 0x6D6C68 + args.config
+
+    # ---- synthetic inputs of this rank's shard, resident in HBM: P_i = [k_i]G (G1 and, config 3/4, Q_i = [k'_i]G2)
+    def gen_points(group: int, k: torch.Tensor) -> torch.Tensor:
+        if group == G1:
+            raw = curve.GenG1().raw
+        elif CURVE == _lib.CURVE_BLS12_377:
+            with open(os.path.join(ROOT, "tests", "golden", "bls12_377.json")) as f:
+                raw = bytes.fromhex(json.load(f)["g2_gen"])
+        else:
+            raw = curve.GenG2().raw
+        base = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        out = torch.empty(k.shape[0] * (g1b if group == G1 else g2b), dtype=torch.uint8, device=dev)
+        _lib.check(lib.mlhip_scalar_mul_device(CURVE, group, base.data_ptr(), 0, k.data_ptr(), 0, k.shape[0], out.data_ptr(), stream))
+        torch.cuda.synchronize()
+        return out
+
+    groups = cfg["groups"]
+    points = {}
+    if G1 in groups or args.config in (2, 3):
+        points[G1] = gen_points(G1, seeded_scalars(n_total, lo, hi, seed * 3 + 1, dev))
+    if G2 in groups:
+        points[G2] = gen_points(G2, seeded_scalars(n_total, lo, hi, seed * 3 + 2, dev))
+    scalars = seeded_scalars(n_total, lo, hi, seed * 3, dev)
+    torch.cuda.synchronize()
 
     extra = {}
-    if pipelined is not None:
-        extra["msm_pipelined_depth2_scalar_muls_per_s_per_gpu"] = pipelined
-    # ---- skewed scalars (BASELINE configs[1], second distribution: all scalars < 2^32 and 1 % duplicated pairs):
-    # the carry bucket of the third window then holds half of the entries; reported beside the headline, never as it
-    if args.skewed:
-        sk = scalars.clone().view(torch.int64).reshape(n, 4)
-        sk[:, 1:] = 0
-        sk[:, 0] &= 0xFFFFFFFF
-        sk[::100] = sk[0]
-        sk = sk.view(torch.uint8).reshape(n, 32).contiguous()
-        pts_sk = points.clone().reshape(n, g1b)
-        pts_sk[::100] = pts_sk[0]
-        pts_sk = pts_sk.reshape(-1).contiguous()
-        best_sk = None
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            plans[0].launch(pts_sk.data_ptr(), sk.data_ptr(), n, False, streams[0].cuda_stream)
-            plans[0].finish()
-            dt = (time.perf_counter() - t1) * 1e3
-            best_sk = dt if best_sk is None or dt < best_sk else best_sk
-        extra["skewed_scalars_below_2^32_1pct_duplicates_ms_per_msm"] = best_sk
-    # ---- PCIe-inclusive protocols (never the headline): (b) resident bases, scalars from host memory per call;
-    # (c) points and scalars from host memory per call -- the reference-shaped MultiScalarMul on host slices
-    if args.host_paths and rank == 0:
-        import ctypes
+    phase = {}
+    step_ms = []
+    res = {}
 
-        hp = points.cpu().numpy().tobytes()
-        hs = scalars.cpu().numpy().tobytes()
-        out_h = ctypes.create_string_buffer(g1b)
-        handle = ctypes.c_void_p()
-        _lib.check(lib.mlhip_bases_create(CURVE, _lib.GROUP_G1, hp, n, 16, ctypes.byref(handle)))
-        tb, tc = [], []
-        for _ in range(5):
-            t1 = time.perf_counter()
-            _lib.check(lib.mlhip_bases_msm(handle, hs, 0, n, out_h))
-            tb.append((time.perf_counter() - t1) * 1e3)
-        same_b = out_h.raw == res
-        _lib.check(lib.mlhip_bases_destroy(handle))
-        for _ in range(5):
-            t1 = time.perf_counter()
-            _lib.check(lib.mlhip_msm_g1(CURVE, hp, hs, 0, n, 16, out_h))
-            tc.append((time.perf_counter() - t1) * 1e3)
-        extra["pcie_inclusive"] = {
-            "scalars_from_host_resident_bases_ms": min(tb[1:]),
-            "points_and_scalars_from_host_ms": min(tc[1:]),
-            "match_resident_result": bool(same_b and out_h.raw == res),
-        }
-    # ---- batched pairing (BASELINE configs[2]): 65 536 x (Miller loop + final exponentiation)
-    if not args.no_pairing:
-        npair = N_PAIRINGS
-        g2base = torch.frombuffer(bytearray(curve.GenG2().raw), dtype=torch.uint8).to(dev)
-        q = torch.empty(npair * g2b, dtype=torch.uint8, device=dev)
-        _lib.check(lib.mlhip_scalar_mul_device(CURVE, _lib.GROUP_G2, g2base.data_ptr(), 0, scalars.data_ptr(), 0, npair, q.data_ptr(), stream))
+    # =============================================================== config 3: the pairing batch is the step
+    def pairing_setup():
+        npair = min(N_PAIRINGS if not reduced else n_cfg, n) if args.config == 3 else min(N_PAIRINGS, n)
+        q = gen_points(G2, scalars[:npair].contiguous())
         gt = torch.empty(npair * gtb, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        best = None
-        for _ in range(3):
-            ev0.record()
-            _lib.check(lib.mlhip_pairing_batch_device(CURVE, points.data_ptr(), q.data_ptr(), npair, gt.data_ptr(), stream))
-            ev1.record()
-            torch.cuda.synchronize()
-            ms = ev0.elapsed_time(ev1)
-            best = ms if best is None or ms < best else best
-        extra["pairings_per_s_per_gpu"] = npair / (best * 1e-3)
-        extra["pairing_batch"] = npair
-        extra["pairing_kernel_ms"] = best
-        extra["pairing_roofline"] = {
-            "bound": "hbm",
-            "achieved": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        }
+        return npair, q, gt
 
-    # ---- CPU baseline: the oracle's C restatement on the same workload, host cores of this box
+    if args.config == 3:
+        npair, q, gt = pairing_setup()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+        def pairing_step(i, record):
+            if record:
+                ev[i][0].record()
+            _lib.check(lib.mlhip_pairing_batch_device(CURVE, points[G1].data_ptr(), q.data_ptr(), npair, gt.data_ptr(), stream))
+            if record:
+                ev[i][1].record()
+            torch.cuda.synchronize()
+
+        for i in range(args.warmup):
+            pairing_step(i, False)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            t1 = time.perf_counter()
+            pairing_step(i, True)
+            step_ms.append((time.perf_counter() - t1) * 1e3)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        kernel_ms = statistics.mean(a.elapsed_time(b) for a, b in ev) if ev else 0.0
+        units_per_step = npair * world
+        achieved = PAIRING_BYTES_PER_UNIT * npair / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+        roofline = {
+            "bound": "hbm", "kernel": "k_pairing_lp<Bls381,2,1> (fused Miller loop + final exponentiation, one pairing per lane pair)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "avg_kernel_ms": kernel_ms,
+            "note": "864 algorithmic bytes per pairing; the kernel is integer-issue bound (DESIGN.md section 4)",
+        }
+        pm = _pmc("k_pairing_lp")
+        if pm:
+            roofline["traffic"] = pm[0]
+            roofline["traffic_note"] = pm[1]
+        unit, metric = "pairings/s", "pairings/sec (BLS12-381, Miller loop + final exponentiation, batch of 65 536 per GPU)"
+        res_check = None
+    else:
+        # =========================================================== MSM configs
+        # one plan + stream per (slot, group); slot 1 only for the two-deep runs
+        nslots = 2
+        plans = {(s, g): _lib.MsmPlan(CURVE, g, n, WINDOW_C) for s in range(nslots) for g in groups}
+        streams = {(s, g): torch.cuda.Stream(device=dev) for s in range(nslots) for g in groups}
+        for pl in plans.values():
+            pl.set_profiling(True)
+
+        def launch(slot):
+            for g in groups:
+                plans[(slot, g)].launch(points[g].data_ptr(), scalars.data_ptr(), n, False, streams[(slot, g)].cuda_stream)
+
+        def finish(slot, record):
+            parts = []
+            for g in groups:
+                parts.append((g, plans[(slot, g)].finish()))
+                if record:
+                    for kname, v in plans[(slot, g)].timings().items():
+                        phase[(g, kname)] = phase.get((g, kname), 0.0) + v
+            totals = mdist.combine_many(CURVE, parts, dev)  # one all-gather (RCCL) + local EC adds; identity at N = 1
+            return dict(zip(groups, totals))
+
+        def run_sequential(k, record):
+            out = None
+            for _ in range(k):
+                t1 = time.perf_counter()
+                launch(0)
+                out = finish(0, record)
+                if record:
+                    step_ms.append((time.perf_counter() - t1) * 1e3)
+            return out
+
+        def run_two_deep(k, record):
+            pending, out = None, None
+            t1 = time.perf_counter()
+            for i in range(k):
+                launch(i & 1)
+                if pending is not None:
+                    out = finish(pending, record)
+                    if record:
+                        t2 = time.perf_counter()
+                        step_ms.append((t2 - t1) * 1e3)
+                        t1 = t2
+                pending = i & 1
+            if pending is not None:
+                out = finish(pending, record)
+                if record:
+                    step_ms.append((time.perf_counter() - t1) * 1e3)
+            return out
+
+        timed = run_two_deep if args.pipelined else run_sequential
+        timed(args.warmup, False)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = timed(args.steps, True)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        steps_n = max(args.steps, 1)
+        # per-kernel times: unshared only when one MSM is in flight -- config 4 (G1 and G2 of a step overlap) and
+        # --pipelined take them from a separate pass, one MSM at a time
+        if len(groups) > 1 or args.pipelined:
+            phase.clear()
+            reps = 3
+            for _ in range(reps):
+                for g in groups:
+                    plans[(0, g)].launch(points[g].data_ptr(), scalars.data_ptr(), n, False, streams[(0, g)].cuda_stream)
+                    plans[(0, g)].finish()
+                    for kname, v in plans[(0, g)].timings().items():
+                        phase[(g, kname)] = phase.get((g, kname), 0.0) + v
+            phase_avg = {k_: v / reps for k_, v in phase.items()}
+        else:
+            phase_avg = {k_: v / steps_n for k_, v in phase.items()}
+        units_per_step = n_total
+        dom = G2 if G2 in groups else G1  # the dominant kernel of the step
+        acc_ms = phase_avg.get((dom, "accumulate"), 0.0)
+        acc32 = os.environ.get("MLHIP_ACC32", "") == "1"
+        cname = {0: "Bn254", 1: "Bls381", 2: "Bls377"}[CURVE]
+        if dom == G1:
+            acc_kernel = ("k_accumulate<FpField<%s>>" if acc32 else "k_accumulate28<%s>") % cname
+        else:
+            acc_kernel = ("k_accumulate28_lp<%s>" if (CURVE == 1 and not acc32) else "k_accumulate_lp<%s>") % cname
+        bytes_unit = MSM_BYTES[(CURVE, dom)]
+        achieved = bytes_unit * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "kernel": acc_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": acc_ms,
+            "algorithmic_bytes_per_launch": bytes_unit * n,
+            "phase_ms": {("g1_" if g == G1 else "g2_") + k_: v for (g, k_), v in sorted(phase_avg.items())},
+        }
+        pm = _pmc(acc_kernel.split("<")[0] + "<" + cname) if args.config == 2 else None
+        if pm:
+            roofline["traffic"], roofline["traffic_note"] = pm
+        if dom == G1 and not acc32 and fpb == 48:
+            # the path is integer-ALU bound, not HBM bound: W = 16 mixed additions per scalar, each 8 x 196 + 2 x 105
+            # product and 9 x 210 reduction v_mad_i64_i32 + 9 x 14 v_mul_lo_u32 in the carry-free form => fraction of
+            # the measured v_mad issue peak (profiles/r01_ubench_int.txt); the kernel is power limited (~1.9 GHz)
+            v_mad = 8 * 196 + 2 * 105 + 9 * 210 + 9 * 14
+            roofline["int_alu"] = {
+                "form": "carry-free 28-bit limbs (fp28.h)",
+                "fp_mul_per_s": (n * 16 * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
+                "v_mad_per_mixed_add": v_mad,
+                "v_mad_frac_of_measured_peak": ((n * 16 * v_mad) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
+            }
+        if len(groups) > 1:
+            g1_ms = phase_avg.get((G1, "accumulate"), 0.0)
+            roofline["g1_kernel"] = {"kernel": "k_accumulate28<%s>" % cname, "avg_kernel_ms": g1_ms,
+                                     "achieved": MSM_BYTES[(CURVE, G1)] * n / (g1_ms * 1e-3) / 1e9 if g1_ms else 0.0}
+        unit = "scalar-muls/s"
+        if len(groups) > 1:
+            metric = "(point, scalar) pairs/sec through the G1 MSM and the G2 MSM of a step (BLS12-381 2^24 pairs, shared scalars): each pair is one G1 and one G2 scalar-mul"
+        else:
+            metric = "G1 scalar-muls/sec (%s 2^%d-point MSM%s)" % (cfg["curve_name"], log_n, " per GPU" if cfg["scaling"] == "weak" else ", sharded over the ranks")
+        if args.config == 2:
+            metric += ", pairings/sec reported in extra"
+        res_check = res
+
+        # ---- extras, after the timed region (never the headline) -------------------------------------------------
+        if not args.no_extras:
+            # the same steps two-deep through launch / finish on two plans and streams (a prover issues MSMs back to back)
+            other = run_sequential if args.pipelined else run_two_deep
+            saved_steps, saved_phase = list(step_ms), dict(phase)
+            other(2, False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            other(args.steps, False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            step_ms[:] = saved_steps
+            phase.clear()
+            phase.update(saved_phase)
+            extra["one_step_in_flight_units_per_s_per_gpu" if args.pipelined else "two_steps_in_flight_units_per_s_per_gpu"] = n * args.steps / dt
+            # skewed scalars (SURVEY 8d, config 2's second distribution): all scalars < 2^32 and 1 % duplicated pairs
+            g0 = groups[0]
+            ptsz = g1b if g0 == G1 else g2b
+            sk = scalars.clone().view(torch.int64).reshape(n, 4)
+            sk[:, 1:] = 0
+            sk[:, 0] &= 0xFFFFFFFF
+            sk[::100] = sk[0]
+            sk = sk.view(torch.uint8).reshape(n, 32).contiguous()
+            pts_sk = points[g0].clone().reshape(n, ptsz)
+            pts_sk[::100] = pts_sk[0]
+            pts_sk = pts_sk.reshape(-1).contiguous()
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                plans[(0, g0)].launch(pts_sk.data_ptr(), sk.data_ptr(), n, False, streams[(0, g0)].cuda_stream)
+                plans[(0, g0)].finish()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            extra["skewed_scalars_below_2^32_1pct_duplicates"] = {"ms_per_msm_median": statistics.median(ts[1:]), "ms_per_msm_min": min(ts[1:]), "group": "G1" if g0 == G1 else "G2"}
+            del sk, pts_sk
+            # PCIe-inclusive protocols of SURVEY 8d on this rank's G1 shard: (b) resident bases + scalars from host
+            # memory per call, (c) points and scalars from host memory per call (the reference-shaped MultiScalarMul)
+            if rank == 0 and G1 in groups:
+                hp = points[G1].cpu().numpy().tobytes()
+                hs = scalars.cpu().numpy().tobytes()
+                out_h = ctypes.create_string_buffer(g1b)
+                handle = ctypes.c_void_p()
+                _lib.check(lib.mlhip_bases_create(CURVE, G1, hp, n, WINDOW_C, ctypes.byref(handle)))
+                tb, tc = [], []
+                for _ in range(6):
+                    t1 = time.perf_counter()
+                    _lib.check(lib.mlhip_bases_msm(handle, hs, 0, n, out_h))
+                    tb.append((time.perf_counter() - t1) * 1e3)
+                same_b = world > 1 or out_h.raw == res[G1]
+                _lib.check(lib.mlhip_bases_destroy(handle))
+                for _ in range(6):
+                    t1 = time.perf_counter()
+                    _lib.check(lib.mlhip_msm_g1(CURVE, hp, hs, 0, n, WINDOW_C, out_h))
+                    tc.append((time.perf_counter() - t1) * 1e3)
+                same_c = world > 1 or out_h.raw == res[G1]
+                extra["pcie_inclusive"] = {
+                    "protocol_b_scalars_from_host_resident_bases_ms": {"median": statistics.median(tb[1:]), "min": min(tb[1:])},
+                    "protocol_c_points_and_scalars_from_host_ms": {"median": statistics.median(tc[1:]), "min": min(tc[1:])},
+                    "protocol_b_scalar_muls_per_s": n / (statistics.median(tb[1:]) * 1e-3),
+                    "protocol_c_scalar_muls_per_s": n / (statistics.median(tc[1:]) * 1e-3),
+                    "group": "G1", "pairs": n,
+                    "match_resident_result": bool(same_b and same_c),
+                }
+                extra["headline_protocol_b"] = extra["pcie_inclusive"]["protocol_b_scalar_muls_per_s"]
+                del hp, hs
+                lib.mlhip_release_cache()
+        # ---- batched pairing beside the MSM headline (BASELINE configs[2]): 65 536 x (Miller loop + FExp)
+        if args.config == 2 and not args.no_pairing:
+            npair, q, gt = pairing_setup()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tp = []
+            for _ in range(4):
+                ev0.record()
+                _lib.check(lib.mlhip_pairing_batch_device(CURVE, points[G1].data_ptr(), q.data_ptr(), npair, gt.data_ptr(), stream))
+                ev1.record()
+                torch.cuda.synchronize()
+                tp.append(ev0.elapsed_time(ev1))
+            best = min(tp[1:])
+            extra["pairings_per_s_per_gpu"] = npair / (statistics.median(tp[1:]) * 1e-3)
+            extra["pairing_batch"] = npair
+            extra["pairing_kernel_ms"] = {"median": statistics.median(tp[1:]), "min": best}
+            extra["pairing_roofline"] = {
+                "bound": "hbm", "achieved": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            }
+
+    steps_n = max(args.steps, 1)
+    value = units_per_step * args.steps / elapsed
+    if step_ms:
+        extra["ms_per_step_median"] = statistics.median(step_ms)
+        extra["ms_per_step_min"] = min(step_ms)
+        extra["ms_per_step_max"] = max(step_ms)
+
+    # ---- CPU baseline: the oracle's C restatement on a bounded sample of the same workload, host cores of this box
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cref  # checker / baseline only
 
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         threads = max(1, min(cores, 64))
-        hp = points.cpu().numpy()
-        hs = scalars.cpu().numpy()
-        t1 = time.perf_counter()
-        ref = cref.msm(CURVE, 1, hp, hs, n, False, WINDOW_C, threads)
-        dt = time.perf_counter() - t1
-        cpu_baseline = {
-            "value": n / dt,
-            "unit": "scalar-muls/s",
-            "cores": threads,
-            "kind": "port",
-            "sample": "the full 2^20-point workload (same points and scalars), oracle/cref Pippenger c=16, %d pthreads, %.2f s" % (threads, dt),
-            "matches_gpu_result": bool(ref == res),
-        }
-        if not args.no_pairing:
+        if args.config == 3:
             ns = 2048
+            hp = points[G1][: ns * g1b].cpu().numpy()
+            hq = q[: ns * g2b].cpu().numpy()
             t1 = time.perf_counter()
-            cpu_gt = cref.pairing_batch(CURVE, hp[: ns * g1b], q[: ns * g2b].cpu().numpy(), ns, threads)
-            dtp = time.perf_counter() - t1
-            cpu_baseline["pairings_per_s"] = ns / dtp
-            cpu_baseline["pairings_match_gpu_result"] = bool(cpu_gt == bytes(gt[: ns * gtb].cpu().numpy().tobytes()))
-            cpu_baseline["pairing_sample"] = "%d of the 65 536 pairs, %d pthreads, %.2f s" % (ns, threads, dtp)
+            cpu_gt = cref.pairing_batch(CURVE, hp, hq, ns, threads)
+            dt = time.perf_counter() - t1
+            cpu_baseline = {"value": ns / dt, "unit": "pairings/s", "cores": threads, "kind": "port",
+                            "sample": "%d of the 65 536 pairs, oracle/cref, %d pthreads, %.2f s" % (ns, threads, dt),
+                            "matches_gpu_result": bool(cpu_gt == bytes(gt[: ns * gtb].cpu().numpy().tobytes()))}
+        else:
+            rates, notes, ok = [], [], True
+            for g in groups:
+                ns = min(n, 1 << 20) if g == G1 else min(n, 1 << 18)
+                ptsz = g1b if g == G1 else g2b
+                hp = points[g][: ns * ptsz].cpu().numpy()
+                hs = scalars[:ns].cpu().numpy()
+                t1 = time.perf_counter()
+                ref = cref.msm(CURVE, g, hp, hs, ns, False, WINDOW_C, threads)
+                dt = time.perf_counter() - t1
+                rates.append(ns / dt)
+                notes.append("%s: first %d pairs, %.2f s" % ("G1" if g == G1 else "G2", ns, dt))
+                if ns == n:
+                    ok = ok and ref == res_check[g]
+                else:  # the GPU on the same sample
+                    pl = _lib.MsmPlan(CURVE, g, ns, WINDOW_C)
+                    ok = ok and ref == pl.run(points[g].data_ptr(), scalars.data_ptr(), ns, False, stream)
+                    pl.close()
+            cpu_baseline = {
+                "value": 1.0 / sum(1.0 / r for r in rates), "unit": unit, "cores": threads, "kind": "port",
+                "sample": "oracle/cref Pippenger c=16, %d pthreads; %s" % (threads, "; ".join(notes)),
+                "matches_gpu_result": bool(ok),
+            }
+            if args.config == 2 and not args.no_pairing:
+                ns = 2048
+                t1 = time.perf_counter()
+                cpu_gt = cref.pairing_batch(CURVE, points[G1][: ns * g1b].cpu().numpy(), q[: ns * g2b].cpu().numpy(), ns, threads)
+                dtp = time.perf_counter() - t1
+                cpu_baseline["pairings_per_s"] = ns / dtp
+                cpu_baseline["pairings_match_gpu_result"] = bool(cpu_gt == bytes(gt[: ns * gtb].cpu().numpy().tobytes()))
+                cpu_baseline["pairing_sample"] = "%d of the 65 536 pairs, %d pthreads, %.2f s" % (ns, threads, dtp)
 
     if rank == 0:
+        par = {
+            "weak": "every rank holds its own 2^%d pairs; one all-gather of the partial sums over RCCL + local EC add" % log_n,
+            "strong": "the 2^%d pairs sharded contiguously across ranks; one all-gather of the %s-byte partial sums over RCCL + local EC add"
+            % (log_n, "+".join(str(g1b if g == G1 else g2b) for g in groups)),
+        }[cfg["scaling"]]
+        if args.config == 3:
+            par = "independent pairings split across ranks, no collective"
         line = {
-            "metric": "G1 scalar-muls/sec (BLS12-381 2^20-point MSM per GPU), pairings/sec reported in extra",
+            "metric": metric,
             "value": value,
-            "unit": "scalar-muls/s",
+            "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step": elapsed / steps_n * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": cfg["scaling"],
             "vs_baseline": None,
             "dtype": "u32",
-            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU over gloo, not a measurement)" if rehearsal else ""),
+            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU over gloo, not a measurement)" if rehearsal else "")
+            + (" (REDUCED SIZE --log-n %d: not a measurement of the config)" % log_n if reduced else ""),
             "config": {
-                "workload": "BLS12-381 2^20-point G1 MSM per GPU, Pippenger c=16 (BASELINE configs[1]); inputs resident in HBM",
-                "curve": "BLS12-381",
-                "points_per_gpu": n,
+                "workload": cfg["workload"],
+                "baseline_config": args.config,
+                "curve": cfg["curve_name"],
+                "pairs_total": n_total,
+                "pairs_per_gpu": n,
                 "window_c": WINDOW_C,
-                "parallelism": "pairs sharded contiguously across ranks; one all-gather of 96-byte partial sums over RCCL + local EC add",
-                "msms_in_flight": 1 if args.sequential else 2,
+                "parallelism": par,
+                "protocol": "SURVEY 8d (a): inputs resident in HBM; kernels + D2H of the window sums + host tail" + ("" if args.config == 3 else "; %d step(s) in flight" % (2 if args.pipelined else 1)),
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
@@ -353,6 +547,23 @@ def main() -> None:
         import torch.distributed as dist
 
         dist.destroy_process_group()
+
+
+def _pmc(kernel_prefix: str):
+    """HBM-side traffic of a kernel from the committed PMC passes (the counters cannot be read from inside this process):
+    (bytes per launch, note) or None.  Newest round first."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pm = json.load(f)
+            kk = next(v for k_, v in pm["kernels"].items() if k_.startswith(kernel_prefix) and "Fp2" not in k_)
+            return ((kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024.0,
+                    "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB from profiles/%s (separate --pmc passes), uncorrected: "
+                    "the x2 gfx950 correction applies to wide coalesced streaming reads, this kernel gathers 16-byte pieces of "
+                    "random rows / spills through scratch (uncalibrated pattern); Infinity-Cache hits are counted" % name)
+        except Exception:
+            continue
+    return None
 
 
 if __name__ == "__main__":

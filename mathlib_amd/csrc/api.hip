@@ -317,8 +317,11 @@ void pool_release(PoolEntry* e, bool failed) {
 // Number of segments a host-buffer MSM is streamed in (1 = one upload, one pass).  Measured on MI355X / PCIe gen5
 // (tools/perf_hostapi.py): from 2^19 points the transfer is worth hiding; MLHIP_STREAM_SEGMENTS overrides (0/1 = off).
 int stream_segments(int group, size_t n, const mlhip_msm_plan* plan) {
-  // G1 needs the carry-free kernels (always there unless MLHIP_ACC32=1); G2 streams on every curve
-  if (!plan->aux || (group == MLHIP_GROUP_G1 && !plan->d_points28)) return 1;
+  // G1 and BLS12-381 G2 stream through the carry-free kernels (always there unless MLHIP_ACC32=1); G2 on the other
+  // curves keeps its bucket state in the boundary form and needs nothing beyond the auxiliary stream -- the same
+  // condition plan_stream checks (kBoundary)
+  const bool carry_free_state = group == MLHIP_GROUP_G1 || plan->curve == MLHIP_CURVE_BLS12_381;
+  if (!plan->aux || (carry_free_state && !plan->d_points28)) return 1;
   if (const char* e = getenv("MLHIP_STREAM_SEGMENTS")) {
     int v = atoi(e);
     if (v < 2) return 1;
@@ -437,6 +440,9 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
   if (max_n == 0 || max_n > ((size_t)1 << 27)) return mlhip_rt::fail(MLHIP_EINVAL, "max_n out of range (1 .. 2^27)");
   if (window_c == 0) window_c = pick_window(max_n);
   if (window_c < 4 || window_c > 20) return mlhip_rt::fail(MLHIP_EINVAL, "window_c out of range (4 .. 20)");
+  // sorted-entry offsets, cursors and scans are 32-bit: W * max_n entries must be addressable
+  if ((size_t)msm_num_windows(sz.fr_bits, window_c) * max_n > 0xFFFFFFFFull)
+    return mlhip_rt::fail(MLHIP_EINVAL, "window_c too small for max_n: W * max_n entries exceed 2^32 - 1");
   int rc = ensure_device();
   if (rc) return rc;
   mlhip_msm_plan* p = new mlhip_msm_plan();
@@ -499,11 +505,23 @@ int mlhip_msm_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scal
   if (n && (!d_points || !d_scalars)) return mlhip_rt::fail(MLHIP_EINVAL, "null device pointer");
   HIPCHK(hipSetDevice(p->device));
   hipStream_t st = (hipStream_t)stream;
+  int rc;
   switch (p->curve) {
-    case MLHIP_CURVE_BN254: return mlhip_tu_plan_launch_Bn254(p, d_points, d_scalars, scalars_mont, n, st);
-    case MLHIP_CURVE_BLS12_381: return mlhip_tu_plan_launch_Bls381(p, d_points, d_scalars, scalars_mont, n, st);
-    default: return mlhip_tu_plan_launch_Bls377(p, d_points, d_scalars, scalars_mont, n, st);
+    case MLHIP_CURVE_BN254: rc = mlhip_tu_plan_launch_Bn254(p, d_points, d_scalars, scalars_mont, n, st); break;
+    case MLHIP_CURVE_BLS12_381: rc = mlhip_tu_plan_launch_Bls381(p, d_points, d_scalars, scalars_mont, n, st); break;
+    default: rc = mlhip_tu_plan_launch_Bls377(p, d_points, d_scalars, scalars_mont, n, st); break;
   }
+  if (rc) {
+    // a failure part-way through the launch train: `done` may never have been recorded, so a later finish must not
+    // read h_out.  Drain what was queued (the error text survives: the drain calls do not go through fail()) and leave
+    // the plan reusable, as tu_plan_stream does.
+    (void)hipStreamSynchronize(st);
+    if (p->aux) (void)hipStreamSynchronize(p->aux);
+    (void)hipGetLastError();
+    p->pending = false;
+    p->upload_src = nullptr;
+  }
+  return rc;
 }
 
 int mlhip_msm_finish(mlhip_msm_plan* p, void* out_affine, void* out_xyzz) {

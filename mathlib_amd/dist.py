@@ -22,23 +22,41 @@ def shard_bounds(n: int, rank: int, world: int):
     return n * rank // world, n * (rank + 1) // world
 
 
-def combine_partials(curve: int, group: int, local_affine: bytes, device: torch.device | None = None) -> bytes:
-    """all-gather every rank's partial MSM result and add them; every rank gets the total."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local_affine
+def _all_gather_bytes(local: bytes, device: torch.device | None) -> bytes:
+    """every rank's `local` (same length on all ranks), concatenated in rank order: ONE collective"""
     world = dist.get_world_size()
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    mine = torch.frombuffer(bytearray(local_affine), dtype=torch.uint8).to(device)
+    mine = torch.frombuffer(bytearray(local), dtype=torch.uint8).to(device)
     try:  # one flat buffer: one collective, one copy back to the host
         flat = torch.empty(world * mine.numel(), dtype=torch.uint8, device=device)
         dist.all_gather_into_tensor(flat, mine)
-        blob = bytes(flat.cpu().numpy().tobytes())
+        return bytes(flat.cpu().numpy().tobytes())
     except (RuntimeError, NotImplementedError):  # a backend without the flat form
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
-        blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in gathered)
-    out = ctypes.create_string_buffer(len(local_affine))
-    fn = _lib.load().mlhip_g1_sum if group == _lib.GROUP_G1 else _lib.load().mlhip_g2_sum
-    _lib.check(fn(curve, blob, world, out))
-    return out.raw
+        return b"".join(bytes(t.cpu().numpy().tobytes()) for t in gathered)
+
+
+def combine_many(curve: int, parts, device: torch.device | None = None):
+    """parts = [(group, local_affine_bytes), ...] -- e.g. the G1 and the G2 partial of BASELINE configs[3]: ONE
+    all-gather of the concatenated partials (96 + 192 bytes per rank), then one local EC addition per part."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [p for _, p in parts]
+    world = dist.get_world_size()
+    blob = _all_gather_bytes(b"".join(p for _, p in parts), device)
+    stride = len(blob) // world
+    totals, off = [], 0
+    for group, p in parts:
+        mine = b"".join(blob[r * stride + off : r * stride + off + len(p)] for r in range(world))
+        out = ctypes.create_string_buffer(len(p))
+        fn = _lib.load().mlhip_g1_sum if group == _lib.GROUP_G1 else _lib.load().mlhip_g2_sum
+        _lib.check(fn(curve, mine, world, out))
+        totals.append(out.raw)
+        off += len(p)
+    return totals
+
+
+def combine_partials(curve: int, group: int, local_affine: bytes, device: torch.device | None = None) -> bytes:
+    """all-gather every rank's partial MSM result and add them; every rank gets the total."""
+    return combine_many(curve, [(group, local_affine)], device)[0]

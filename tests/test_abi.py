@@ -44,6 +44,10 @@ def test_argument_errors_are_reported(mlhip):
     assert lib.mlhip_msm_plan_create(1, 3, 10, 0, ctypes.byref(h)) == -1
     assert lib.mlhip_msm_plan_create(1, 1, 10, 40, ctypes.byref(h)) == -1
     assert lib.mlhip_msm_plan_create(1, 1, 0, 0, ctypes.byref(h)) == -1
+    # 32-bit entry offsets: W * max_n must stay below 2^32 (c = 4 gives 64 windows)
+    assert lib.mlhip_msm_plan_create(1, 1, 1 << 26, 4, ctypes.byref(h)) == -1
+    assert b"W * max_n" in lib.mlhip_last_error()
+    assert lib.mlhip_msm_plan_create(1, 1, 1 << 27, 8, ctypes.byref(h)) == -1
 
 
 def test_no_gpu_means_failure_not_fallback(mlhip):

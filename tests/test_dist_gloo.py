@@ -31,6 +31,15 @@ def _worker(rank, world, port, n, ret):
         part = cref.msm(curve, group, pts[lo * ps : hi * ps], sc[lo:hi].copy(), hi - lo)
         total = mdist.combine_partials(curve, group, part)
         ok = ok and total == cref.msm(curve, group, pts, sc, n)
+    # configs[3]: the G1 and the G2 partial travel in ONE all-gather
+    n2 = n // 2
+    g1p = cref.gen_points(1, 1, 17, 3, n2)
+    g2p = cref.gen_points(1, 2, 19, 5, n2)
+    sc = np.random.default_rng(6).integers(0, 1 << 63, size=(n2, 4), dtype=np.uint64)
+    lo, hi = mdist.shard_bounds(n2, rank, world)
+    parts = [(1, cref.msm(1, 1, g1p[lo * 96 : hi * 96], sc[lo:hi].copy(), hi - lo)), (2, cref.msm(1, 2, g2p[lo * 192 : hi * 192], sc[lo:hi].copy(), hi - lo))]
+    t1, t2 = mdist.combine_many(1, parts)
+    ok = ok and t1 == cref.msm(1, 1, g1p, sc, n2) and t2 == cref.msm(1, 2, g2p, sc, n2)
     # degenerate: every rank holds the identity
     zero = bytes(96)
     ok = ok and mdist.combine_partials(1, 1, zero) == zero

@@ -1,0 +1,77 @@
+"""The N > 1 MSM path end to end with the GPU producing the partials (BASELINE configs[3] / [4] at world_size 2):
+two ranks share device 0 and exchange over gloo (RCCL needs one device per rank; this box has one).  Every rank
+runs the single-GPU pipeline on its contiguous shard (mathlib_amd.dist.shard_bounds), the partial sums go through
+mathlib_amd.dist.combine_partials (all-gather + mlhip_g1_sum / mlhip_g2_sum), and the total must equal both the
+single-GPU MSM over the whole input and the C oracle.  tests/test_dist_gloo.py is the CPU-only form of the same
+exchange (its partials come from the oracle)."""
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, cases, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mathlib_amd import _lib, dist as mdist
+    from oracle import cref
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    ok = True
+    msgs = []
+    for curve, group, n, c in cases:
+        # every rank derives the same whole input, then keeps only its shard on the device
+        pts = cref.gen_points(curve, group, 1234 + curve, 77 + group, n)
+        sc = np.random.default_rng(1000 + n).integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+        ps = len(pts) // n
+        lo, hi = mdist.shard_bounds(n, rank, world)
+        d_pts = torch.frombuffer(bytearray(pts[lo * ps : hi * ps]), dtype=torch.uint8).to(dev)
+        d_sc = torch.from_numpy(sc[lo:hi].copy().view(np.uint8).reshape(-1)).to(dev)
+        plan = _lib.MsmPlan(curve, group, hi - lo, c)
+        part = plan.run(d_pts.data_ptr(), d_sc.data_ptr(), hi - lo, False, st)
+        plan.close()
+        total = mdist.combine_partials(curve, group, part)
+        want = cref.msm(curve, group, pts, sc, n, False, 0, 8)
+        if total != want:
+            ok = False
+            msgs.append("combine != oracle for %r" % ((curve, group, n, c),))
+        if rank == 0:  # the same input as ONE MSM on the device
+            whole = _lib.MsmPlan(curve, group, n, c)
+            d_all = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
+            d_sall = torch.from_numpy(sc.view(np.uint8).reshape(-1).copy()).to(dev)
+            single = whole.run(d_all.data_ptr(), d_sall.data_ptr(), n, False, st)
+            whole.close()
+            if single != total:
+                ok = False
+                msgs.append("combine != single-GPU MSM for %r" % ((curve, group, n, c),))
+    ret[rank] = (ok, msgs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gpu_shards_combine_to_the_single_msm():
+    import torch.multiprocessing as mp
+
+    world = 2
+    # (curve, group, n, window): BLS12-381 G1 and G2 (config 4's two halves), BLS12-377 G1 (config 5), ragged n
+    cases = [(1, 1, 40001, 16), (1, 2, 9001, 12), (2, 1, 30011, 16), (0, 1, 5003, 0)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, cases, ret), nprocs=world, join=True)
+    for r in range(world):
+        ok, msgs = ret.get(r, (False, ["rank %d did not report" % r]))
+        assert ok, msgs

@@ -110,12 +110,18 @@ def test_msm_2_20_skewed_scalars_vs_oracle(mlhip, shape):
 
 
 def test_pairing_batch_65536_properties(mlhip):
-    """BASELINE configs[2]: 65 536 pairings.  e([k]G1, Q)^1 checked through bilinearity on a strided sample
-    against the oracle, and the whole batch against a second run split in two (determinism / indexing)."""
+    """BASELINE configs[2]: 65 536 pairings e([k_i]G1, [s_i]G2) + FExp.
+    (1) EVERY output is covered by one identity: prod_i out_i^(w_i) == GenGt^(sum_i w_i k_i s_i mod r) with random 64-bit
+        weights w_i (a wrong, missing or permuted element changes the left side) -- the left side through
+        mlhip_gt_exp_device and a tree of mlhip_gt_mul_device, the right side by the oracle (pyref: one pairing, one
+        exponentiation); the unweighted product is checked the same way;
+    (2) a strided sample of 33 outputs byte for byte against the C oracle;
+    (3) the whole batch against a second run split in two launches (determinism / indexing)."""
     import numpy as np
     import torch
 
     from oracle import cref
+    from oracle import pyref as R
 
     n = 1 << 16
     lib, cid, pts, s, k, st = _setup(mlhip, n, seed=3)
@@ -129,12 +135,42 @@ def test_pairing_batch_65536_properties(mlhip):
     torch.cuda.synchronize()
     o = out.cpu().numpy()
     hp, hq = pts.cpu().numpy(), q.cpu().numpy()
+
+    # (1) all elements
+    cp = R.BLS12_381
+    T = R.tower(cp)
+    gen_gt = R.pairing(cp, cp.g1, R.g2_generator(cp))
+    to_int = lambda row: int(row[0]) | int(row[1]) << 64 | int(row[2]) << 128 | int(row[3]) << 192  # noqa: E731
+    kk = k.cpu().numpy().view(np.uint64).reshape(n, 4)
+    ss = s.cpu().numpy().view(np.uint64).reshape(n, 4)
+    ks = [(to_int(kk[i]) % cp.r) * (to_int(ss[i]) % cp.r) % cp.r for i in range(n)]
+    w = np.zeros((n, 4), dtype=np.uint64)
+    w[:, 0] = np.random.default_rng(65536).integers(1, 1 << 63, size=n, dtype=np.uint64)
+
+    def tree_product(buf):
+        m = n
+        while m > 1:
+            half = m // 2
+            mlhip.check(lib.mlhip_gt_mul_device(cid, buf.data_ptr(), buf.data_ptr() + (m - half) * 576, half, buf.data_ptr(), st))
+            m -= half
+        torch.cuda.synchronize()
+        return bytes(buf[:576].cpu().numpy().tobytes())
+
+    assert tree_product(out.clone()) == R.gt_to_mont_bytes(cp, T.f12_pow(gen_gt, sum(ks) % cp.r))
+    dw = torch.from_numpy(w.view(np.uint8).reshape(-1).copy()).cuda()
+    powered = torch.empty_like(out)
+    mlhip.check(lib.mlhip_gt_exp_device(cid, out.data_ptr(), dw.data_ptr(), 0, n, powered.data_ptr(), st))
+    weighted = sum(int(w[i, 0]) * ks[i] for i in range(n)) % cp.r
+    assert tree_product(powered) == R.gt_to_mont_bytes(cp, T.f12_pow(gen_gt, weighted))
+
+    # (2) sample against the C oracle
     idx = list(range(0, n, n // 32)) + [n - 1]
     g1s = b"".join(hp[i * 96 : (i + 1) * 96].tobytes() for i in idx)
     g2s = b"".join(hq[i * 192 : (i + 1) * 192].tobytes() for i in idx)
     ref = cref.pairing_batch(cid, g1s, g2s, len(idx), 8)
     for j, i in enumerate(idx):
         assert o[i * 576 : (i + 1) * 576].tobytes() == ref[j * 576 : (j + 1) * 576], i
+    # (3) split run
     out2 = torch.empty_like(out)
     h = n // 2 + 77
     mlhip.check(lib.mlhip_pairing_batch_device(cid, pts.data_ptr(), q.data_ptr(), h, out2.data_ptr(), st))
@@ -143,10 +179,12 @@ def test_pairing_batch_65536_properties(mlhip):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("curve_name,group,log_n", [("BLS12-381", 2, 18), ("BLS12-377", 1, 19), ("BN254", 1, 20)])
+@pytest.mark.parametrize("curve_name,group,log_n", [("BLS12-381", 2, 18), ("BLS12-377", 1, 19), ("BN254", 1, 20),
+                                                   ("BLS12-381", 1, 21), ("BLS12-381", 2, 21), ("BLS12-377", 1, 22)])
 def test_msm_other_config_shapes(mlhip, curve_name, group, log_n):
-    """BASELINE configs 4 and 5 shapes per GPU (G2 on BLS12-381 -- the carry-free lane-pair path at scale --, BLS12-377
-    G1 2^19) and BN254 2^20: split-sum property and the C oracle on the whole input."""
+    """BASELINE configs[3] and [4] shapes: the per-GPU shard of config 4 (BLS12-381 2^21 G1 and 2^21 G2), the shard of
+    config 5 (BLS12-377 G1 2^19) and its whole 2^22-point form on one GPU, G2 at 2^18 and BN254 2^20: split-sum
+    property and the C oracle on the whole input."""
     import os
 
     import numpy as np

@@ -43,6 +43,24 @@ def test_fp_mul_kernel_known_answers(lib, mlhip, curve):
     assert bytes(out.cpu().numpy().tobytes()) == exp
 
 
+def test_fp_mul_reference_held_products(lib, mlhip):
+    """The field-multiplication kernel on the only products the REFERENCE itself fixes: the Montgomery-form SWU
+    constants of driver/kilic/custom.go:38-42 -- mont_mul(z, zInv) = p - r1 (zInv holds -1/z, z = 11, r1 at
+    custom.go:29) and mont_mul(minusBOverA, a) = p - b -- plus 1 * 1 = 1 on r1 and x * 1 = x on custom.go:329-336."""
+    import torch
+
+    from test_oracle_pinned import reference_held_products
+
+    table = reference_held_products()
+    da = torch.frombuffer(bytearray(b"".join(t[0] for t in table)), dtype=torch.uint8).cuda()
+    db = torch.frombuffer(bytearray(b"".join(t[1] for t in table)), dtype=torch.uint8).cuda()
+    out = torch.zeros(48 * len(table), dtype=torch.uint8, device="cuda")
+    mlhip.check(lib.mlhip_fp_mul_device(mlhip.CURVE_BLS12_381, da.data_ptr(), db.data_ptr(), len(table), 1, out.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert bytes(out.cpu().numpy().tobytes()) == b"".join(t[2] for t in table)
+
+
 @pytest.mark.parametrize("curve", CURVES)
 @pytest.mark.parametrize("window_c", [0, 4, 7, 12, 16])
 def test_msm_g1_golden_cases(lib, mlhip, curve, window_c):
@@ -479,6 +497,36 @@ def test_msm_alternate_paths(lib, mlhip, curve, switch, monkeypatch):
         out = ctypes.create_string_buffer(g1b)
         mlhip.check(lib.mlhip_msm_g1(cid, p, sc, 0, len(case["points"]), 5, out))
         assert out.raw == _h(case["expected"]), (curve, switch, case["name"])
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("switches", [("MLHIP_ACC32",), ("MLHIP_ACC32", "MLHIP_STREAM_SEGMENTS=2"), ("MLHIP_LEGACY_SORT",)])
+def test_msm_g2_alternate_paths(lib, mlhip, curve, switches, monkeypatch):
+    """G2 on the boundary-form accumulation (MLHIP_ACC32=1), alone and together with a forced segment count: with no
+    carry-free copy of the points a BLS12-381 G2 plan cannot stream and must fall back to one pass, not fail."""
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, _, g2b, _ = mlhip.sizes(cid)
+    monkeypatch.setenv("MLHIP_NO_PLAN_CACHE", "1")  # the knobs are read when a plan is created
+    for sw in switches:
+        name, _, value = sw.partition("=")
+        monkeypatch.setenv(name, value or "1")
+    for case in g["msm_g2"]:
+        pts = b"".join(_h(x) for x in case["points"])
+        sc = b"".join(_h(x) for x in case["scalars"])
+        out = ctypes.create_string_buffer(g2b)
+        mlhip.check(lib.mlhip_msm_g2(cid, pts, sc, 0, len(case["points"]), 5, out))
+        assert out.raw == _h(case["expected"]), (curve, switches, case["name"])
+    n = 3000
+    pts = cref.gen_points(cid, 2, 5151, 777, n)
+    sc = _rand_scalars(n, 909 + cid, 252)
+    exp = cref.msm(cid, 2, pts, sc, n, False, 0, 8)
+    for c in (9, 16):
+        out = ctypes.create_string_buffer(g2b)
+        mlhip.check(lib.mlhip_msm_g2(cid, pts, sc.tobytes(), 0, n, c, out))
+        assert out.raw == exp, (curve, switches, c)
 
 
 @pytest.mark.parametrize("curve", CURVES)

@@ -37,6 +37,41 @@ G1_GENS = {
 }
 
 
+# /root/reference/driver/kilic/custom.go:31-43 (swuParamsForG1, every value in Montgomery form): the only
+# reference-held vectors that exercise a field MULTIPLICATION.  z = 11 (the SWU non-square), zInv holds -1/z,
+# minusBOverA holds -b/a, so with mont_mul(x, y) = x y R^-1 mod p:
+#     mont_mul(z, zInv)        == p - r1   (Montgomery form of -1)
+#     mont_mul(minusBOverA, a) == p - b    (Montgomery form of -b)
+KILIC_SWU_A = [0x2F65AA0E9AF5AA51, 0x86464C2D1E8416C3, 0xB85CE591B7BD31E2, 0x27E11C91B5F24E7C, 0x28376EDA6BFC1835, 0x155455C3E5071D85]
+KILIC_SWU_B = [0xFB996971FE22A1E0, 0x9AA93EB35B742D6F, 0x8C476013DE99C5C4, 0x873E27C3A221E571, 0xCA72B5E45A52D888, 0x06824061418A386B]
+KILIC_SWU_Z = [0x886C00000023FFDC, 0x0F70008D3090001D, 0x77672417ED5828C3, 0x9DAC23E943DC1740, 0x50553F1B9C131521, 0x078C712FBE0AB6E8]
+KILIC_SWU_ZINV = [0x0E8A2E8BA2E83E10, 0x5B28BA2CA4D745D1, 0x678CD5473847377A, 0x4C506DD8A8076116, 0x9BCB227D79284139, 0x0E8D3154B0BA099A]
+KILIC_SWU_MINUS_B_OVER_A = [0x052583C93555A7FE, 0x3B40D72430F93C82, 0x1B75FAA0105EC983, 0x2527E7DC63851767, 0x99FFFD1F34FC181D, 0x097CAB54770CA0D3]
+
+
+def _le(limbs):
+    return b"".join(x.to_bytes(8, "little") for x in limbs)
+
+
+def _int(limbs):
+    return sum(x << (64 * i) for i, x in enumerate(limbs))
+
+
+def reference_held_products():
+    """(a, b, a*b) triples in the ABI's byte form whose three members are all fixed by the reference's constants"""
+    p = _int(KILIC_MODULUS)
+    minus_one = (p - _int(KILIC_R1)).to_bytes(48, "little")
+    minus_b = (p - _int(KILIC_SWU_B)).to_bytes(48, "little")
+    return [
+        (_le(KILIC_SWU_Z), _le(KILIC_SWU_ZINV), minus_one),
+        (_le(KILIC_SWU_ZINV), _le(KILIC_SWU_Z), minus_one),
+        (_le(KILIC_SWU_MINUS_B_OVER_A), _le(KILIC_SWU_A), minus_b),
+        (_le(KILIC_SWU_A), _le(KILIC_SWU_MINUS_B_OVER_A), minus_b),
+        (_le(KILIC_R1), _le(KILIC_R1), _le(KILIC_R1)),  # 1 * 1 = 1
+        (_le(KILIC_F), _le(KILIC_R1), _le(KILIC_F)),  # x * 1 = x on the 2^256 R constant (custom.go:329-336)
+    ]
+
+
 def _limbs(v, n):
     return [(v >> (64 * i)) & (2**64 - 1) for i in range(n)]
 
@@ -49,6 +84,30 @@ def test_bls12_381_field_constants_match_reference():
     assert _limbs((1 << 256) * cp.R % cp.p, 6) == KILIC_F
     # the in-memory form of 1 is r1 (Montgomery, little-endian limbs)
     assert R.fp_to_mont_bytes(cp, 1) == b"".join(x.to_bytes(8, "little") for x in KILIC_R1)
+
+
+def test_reference_held_montgomery_products():
+    """driver/kilic/custom.go:38-42: the oracle's field multiplication (Python integers and the C restatement's
+    CIOS) reproduces the products the reference's constants fix; z really is 11."""
+    from oracle import cref
+
+    cp = R.BLS12_381
+    assert R.fp_from_mont_bytes(cp, _le(KILIC_SWU_Z)) == 11
+    for a, b, ab in reference_held_products():
+        x, y = R.fp_from_mont_bytes(cp, a), R.fp_from_mont_bytes(cp, b)
+        assert R.fp_to_mont_bytes(cp, x * y % cp.p) == ab
+        assert cref.fp_mul(cp.curve_id, a, b) == ab
+
+
+def test_reference_held_products_through_the_kernel_headers(hostmath):
+    """the product's own fp_mul (fp.h, built for the host by tests/hostmath) on the same reference-held vectors;
+    the GPU run of the same table is tests/test_gpu_parity.py::test_fp_mul_reference_held_products"""
+    import ctypes
+
+    for a, b, ab in reference_held_products():
+        out = ctypes.create_string_buffer(48)
+        assert hostmath.hm_fp_op(1, 0, a, b, out) == 0
+        assert out.raw == ab
 
 
 @pytest.mark.parametrize("name", ["BN254", "BLS12-381", "BLS12-377"])
