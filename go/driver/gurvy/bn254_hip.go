@@ -5,7 +5,7 @@ The BN254 element types of package gurvy are unexported (bn254G1, bn254G2, bn254
 so -- unlike the BLS12-381 shim in go/driver/hip, which wraps the exported types of driver/gurvy/bls12381 -- this file
 is meant to be dropped INTO package gurvy, next to bn254.go.  It overrides only the data-parallel methods of Bn254
 (driver/gurvy/bn254.go:232-267) and adds the batched entry points; everything else is inherited by embedding.
-BLS12-377 (driver/gurvy/bls12-377.go:229-264) takes the same treatment with MLHIP_CURVE_BLS12_377.
+BLS12-377 (driver/gurvy/bls12-377.go:229-264) takes the same treatment in bls12-377_hip.go.
 
 NOTE: never compiled (no Go toolchain in the build image); the same C ABI is exercised on the GPU for all three
 curves by the C++ and Python mirrors of the driver interface (include/mlhip_driver.hpp, mathlib_amd/driver.py).
@@ -21,6 +21,7 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 	"unsafe"
 
 	"github.com/IBM/mathlib/driver"
@@ -46,8 +47,13 @@ func NewBn254Hip() *Bn254Hip {
 	return &Bn254Hip{Bn254: *NewBn254(), MinDeviceMSM: 32}
 }
 
-func hipCheck(rc C.int) {
-	if rc != 0 {
+// hipCheck runs one library call and panics with the library's message when it fails.  The message is kept per OS
+// thread and goroutines migrate between threads from one cgo call to the next, so the goroutine is locked to its
+// thread from the call until the message has been read.
+func hipCheck(call func() C.int) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := call(); rc != 0 {
 		panic(fmt.Sprintf("hip: libmlhip error %d: %s", int(rc), C.GoString(C.mlhip_last_error())))
 	}
 }
@@ -67,8 +73,10 @@ func (c *Bn254Hip) MultiScalarMul(a []driver.G1, b []driver.Zr) driver.G1 {
 		scalars[i].SetBigInt(&b[i].(*common.BaseZr).Int)
 	}
 	var result bn254.G1Affine
-	hipCheck(C.mlhip_msm_g1(C.MLHIP_CURVE_BN254, unsafe.Pointer(&points[0]), unsafe.Pointer(&scalars[0]), 1,
-		C.size_t(n), C.int(c.WindowC), unsafe.Pointer(&result)))
+	hipCheck(func() C.int {
+		return C.mlhip_msm_g1(C.MLHIP_CURVE_BN254, unsafe.Pointer(&points[0]), unsafe.Pointer(&scalars[0]), 1,
+			C.size_t(n), C.int(c.WindowC), unsafe.Pointer(&result))
+	})
 	return &bn254G1{result}
 }
 
@@ -89,8 +97,10 @@ func (c *Bn254Hip) PairingBatch(g2s []driver.G2, g1s []driver.G1) []driver.Gt {
 		q[i] = g2s[i].(*bn254G2).G2Affine
 	}
 	gts := make([]bn254.GT, n)
-	hipCheck(C.mlhip_pairing_batch(C.MLHIP_CURVE_BN254, unsafe.Pointer(&p[0]), unsafe.Pointer(&q[0]), C.size_t(n),
-		unsafe.Pointer(&gts[0])))
+	hipCheck(func() C.int {
+		return C.mlhip_pairing_batch(C.MLHIP_CURVE_BN254, unsafe.Pointer(&p[0]), unsafe.Pointer(&q[0]), C.size_t(n),
+			unsafe.Pointer(&gts[0]))
+	})
 	out := make([]driver.Gt, n)
 	for i := range gts {
 		out[i] = &bn254Gt{gts[i]}

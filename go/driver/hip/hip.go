@@ -33,6 +33,7 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 	"unsafe"
 
 	"github.com/IBM/mathlib/driver"
@@ -49,7 +50,13 @@ var WindowC = 0
 // exponentiation 14.2 ms, because a single pairing occupies a single lane pair (65 536 of them take 23 ms).
 // gnark on the CPU does a single pairing in about a millisecond.  Hence:
 //
-// MinDeviceMSM: MultiScalarMul with fewer pairs stays on the embedded gurvy driver.
+// MinDeviceMSM: MultiScalarMul with fewer pairs stays on the embedded gurvy driver.  A host-slice MSM costs the device
+// a flat 0.35-0.7 ms up to 2^10 pairs and about 1.1 ms from 2^12 to 2^16 (profiles/r01_perf_small_msm.txt).  The CPU
+// side cannot be measured with gnark here (no Go toolchain); the stated stand-in, one thread of the C restatement
+// (oracle/cref, tools/perf_min_device_msm.py, profiles/r02_min_device_msm.txt), needs 0.74 ms for 2 pairs, 4.3 ms for 32
+// and 51 ms for 2^10 -- the device wins from the first pair against it.  gnark with ADX assembly and GLV is roughly an
+// order of magnitude faster than that plain-C port (about 60 us per scalar multiplication), which puts the break-even
+// near 8-32 pairs; 32 keeps the tiny proofs-of-knowledge MSMs (perf_test.go:198-224, 3-7 pairs) on the CPU.
 var MinDeviceMSM = 32
 
 // MinDevicePairingBatch: PairingBatch with fewer pairs stays on the embedded gurvy driver.  Any batch up to 32 768
@@ -70,10 +77,33 @@ func init() {
 	}
 }
 
-func check(rc C.int) {
-	if rc != 0 {
+// check runs one library call and panics with the library's message when it fails.  libmlhip keeps the message (and
+// a thread's optional device pin) per OS thread, and goroutines migrate between threads from one cgo call to the
+// next: the goroutine is locked to its thread from the call until the message has been read.  Device selection does
+// not rely on thread state at all -- it is the process-wide list of SetDevices below.
+func check(call func() C.int) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := call(); rc != 0 {
 		panic(fmt.Sprintf("hip: libmlhip error %d: %s", int(rc), C.GoString(C.mlhip_last_error())))
 	}
+}
+
+// SetDevices sets the GPUs of this process (mlhip_init; no argument = every visible device; the environment variable
+// MLHIP_DEVICES does the same).  With two or more, MultiScalarMul / MultiScalarMulG2 / NewBases of 2^21 pairs and more
+// and PairingBatch of 2^17 pairs and more are cut into contiguous shards, one per GPU, each run by its own host thread
+// inside the library; the per-GPU partial sums are added on the host (SURVEY.md 8e; BASELINE configs 4 and 5).
+// Smaller calls run on the first listed device.
+func SetDevices(devices ...int) {
+	var p *C.int
+	d := make([]C.int, len(devices))
+	for i, v := range devices {
+		d[i] = C.int(v)
+	}
+	if len(d) > 0 {
+		p = &d[0]
+	}
+	check(func() C.int { return C.mlhip_init(p, C.int(len(d))) })
 }
 
 // Curve is the gurvy BLS12-381 curve with its hot methods moved to the GPU.
@@ -102,9 +132,11 @@ func (c *Curve) MultiScalarMul(a []driver.G1, b []driver.Zr) driver.G1 {
 	if n < MinDeviceMSM {
 		return c.Curve.MultiScalarMul(a, b)
 	}
-	check(C.mlhip_msm_g1(C.MLHIP_CURVE_BLS12_381,
+	check(func() C.int {
+		return C.mlhip_msm_g1(C.MLHIP_CURVE_BLS12_381,
 		unsafe.Pointer(&points[0]), unsafe.Pointer(&scalars[0]), 1, C.size_t(n), C.int(WindowC),
-		unsafe.Pointer(&out.G1Affine)))
+		unsafe.Pointer(&out.G1Affine))
+	})
 	return out
 }
 
@@ -114,9 +146,11 @@ func (c *Curve) Pairing(p2 driver.G2, p1 driver.G1) driver.Gt {
 		return c.Curve.Pairing(p2, p1)
 	}
 	out := &gurvy381.Gt{}
-	check(C.mlhip_miller_loop(C.MLHIP_CURVE_BLS12_381,
+	check(func() C.int {
+		return C.mlhip_miller_loop(C.MLHIP_CURVE_BLS12_381,
 		unsafe.Pointer(&p1.(*gurvy381.G1).G1Affine), unsafe.Pointer(&p2.(*gurvy381.G2).G2Affine),
-		1, 1, unsafe.Pointer(&out.GT)))
+		1, 1, unsafe.Pointer(&out.GT))
+	})
 	return out
 }
 
@@ -128,8 +162,10 @@ func (c *Curve) Pairing2(p2a, p2b driver.G2, p1a, p1b driver.G1) driver.Gt {
 	g1 := [2]bls12381.G1Affine{p1a.(*gurvy381.G1).G1Affine, p1b.(*gurvy381.G1).G1Affine}
 	g2 := [2]bls12381.G2Affine{p2a.(*gurvy381.G2).G2Affine, p2b.(*gurvy381.G2).G2Affine}
 	out := &gurvy381.Gt{}
-	check(C.mlhip_miller_loop(C.MLHIP_CURVE_BLS12_381,
-		unsafe.Pointer(&g1[0]), unsafe.Pointer(&g2[0]), 2, 1, unsafe.Pointer(&out.GT)))
+	check(func() C.int {
+		return C.mlhip_miller_loop(C.MLHIP_CURVE_BLS12_381,
+		unsafe.Pointer(&g1[0]), unsafe.Pointer(&g2[0]), 2, 1, unsafe.Pointer(&out.GT))
+	})
 	return out
 }
 
@@ -139,8 +175,10 @@ func (c *Curve) FExp(a driver.Gt) driver.Gt {
 		return c.Curve.FExp(a)
 	}
 	out := &gurvy381.Gt{}
-	check(C.mlhip_final_exp(C.MLHIP_CURVE_BLS12_381,
-		unsafe.Pointer(&a.(*gurvy381.Gt).GT), 1, unsafe.Pointer(&out.GT)))
+	check(func() C.int {
+		return C.mlhip_final_exp(C.MLHIP_CURVE_BLS12_381,
+		unsafe.Pointer(&a.(*gurvy381.Gt).GT), 1, unsafe.Pointer(&out.GT))
+	})
 	return out
 }
 
@@ -159,9 +197,11 @@ func (c *Curve) MultiScalarMulG2(a []driver.G2, b []driver.Zr) driver.G2 {
 	if len(b) != n || n == 0 {
 		return out
 	}
-	check(C.mlhip_msm_g2(C.MLHIP_CURVE_BLS12_381,
+	check(func() C.int {
+		return C.mlhip_msm_g2(C.MLHIP_CURVE_BLS12_381,
 		unsafe.Pointer(&points[0]), unsafe.Pointer(&scalars[0]), 1, C.size_t(n), C.int(WindowC),
-		unsafe.Pointer(&out.G2Affine)))
+		unsafe.Pointer(&out.G2Affine))
+	})
 	return out
 }
 
@@ -188,8 +228,10 @@ func (c *Curve) PairingBatch(g2s []driver.G2, g1s []driver.G1) []driver.Gt {
 		q[i] = g2s[i].(*gurvy381.G2).G2Affine
 	}
 	gts := make([]bls12381.GT, n)
-	check(C.mlhip_pairing_batch(C.MLHIP_CURVE_BLS12_381,
-		unsafe.Pointer(&p[0]), unsafe.Pointer(&q[0]), C.size_t(n), unsafe.Pointer(&gts[0])))
+	check(func() C.int {
+		return C.mlhip_pairing_batch(C.MLHIP_CURVE_BLS12_381,
+		unsafe.Pointer(&p[0]), unsafe.Pointer(&q[0]), C.size_t(n), unsafe.Pointer(&gts[0]))
+	})
 	out := make([]driver.Gt, n)
 	for i := range gts {
 		out[i] = &gurvy381.Gt{GT: gts[i]}
@@ -213,8 +255,10 @@ func (c *Curve) NewG1sFromCompressed(raw []byte) []driver.G1 {
 	}
 	pts := make([]bls12381.G1Affine, n)
 	status := make([]byte, n)
-	check(C.mlhip_g1_from_bytes(C.MLHIP_CURVE_BLS12_381, unsafe.Pointer(&raw[0]), C.size_t(n), 1, 1,
-		unsafe.Pointer(&pts[0]), (*C.uchar)(unsafe.Pointer(&status[0]))))
+	check(func() C.int {
+		return C.mlhip_g1_from_bytes(C.MLHIP_CURVE_BLS12_381, unsafe.Pointer(&raw[0]), C.size_t(n), 1, 1,
+		unsafe.Pointer(&pts[0]), (*C.uchar)(unsafe.Pointer(&status[0])))
+	})
 	out := make([]driver.G1, n)
 	for i := range pts {
 		switch status[i] {
@@ -242,7 +286,9 @@ func (c *Curve) G1sCompressed(pts []driver.G1) []byte {
 		aff[i] = pts[i].(*gurvy381.G1).G1Affine
 	}
 	out := make([]byte, n*bls12381.SizeOfG1AffineCompressed)
-	check(C.mlhip_g1_to_bytes(C.MLHIP_CURVE_BLS12_381, unsafe.Pointer(&aff[0]), C.size_t(n), 1, unsafe.Pointer(&out[0])))
+	check(func() C.int {
+		return C.mlhip_g1_to_bytes(C.MLHIP_CURVE_BLS12_381, unsafe.Pointer(&aff[0]), C.size_t(n), 1, unsafe.Pointer(&out[0]))
+	})
 	return out
 }
 
@@ -263,8 +309,10 @@ func (c *Curve) NewBases(points []driver.G1) *Bases {
 		aff[i] = points[i].(*gurvy381.G1).G1Affine
 	}
 	b := &Bases{n: n}
-	check(C.mlhip_bases_create(C.MLHIP_CURVE_BLS12_381, C.MLHIP_GROUP_G1, unsafe.Pointer(&aff[0]), C.size_t(n),
-		C.int(WindowC), &b.h))
+	check(func() C.int {
+		return C.mlhip_bases_create(C.MLHIP_CURVE_BLS12_381, C.MLHIP_GROUP_G1, unsafe.Pointer(&aff[0]), C.size_t(n),
+		C.int(WindowC), &b.h)
+	})
 	return b
 }
 
@@ -281,7 +329,9 @@ func (b *Bases) MultiScalarMul(scalars []driver.Zr) driver.G1 {
 	for i := range scalars {
 		sc[i] = gurvy381.ZrValue(scalars[i])
 	}
-	check(C.mlhip_bases_msm(b.h, unsafe.Pointer(&sc[0]), 1, C.size_t(len(sc)), unsafe.Pointer(&out.G1Affine)))
+	check(func() C.int {
+		return C.mlhip_bases_msm(b.h, unsafe.Pointer(&sc[0]), 1, C.size_t(len(sc)), unsafe.Pointer(&out.G1Affine))
+	})
 	return out
 }
 

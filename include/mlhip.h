@@ -56,10 +56,30 @@ extern "C" {
 int mlhip_version(void);
 const char* mlhip_last_error(void);
 int mlhip_device_count(int* count);
-/* Device used by the calling thread's subsequent calls (default 0).  Nothing touches the GPU
- * before the first compute call (the reference computes GenGt at package init, math.go:142-255:
+/* Pins the calling thread's subsequent calls to one device (-1 undoes it: the thread follows the process's device
+ * list again, whose first entry -- device 0 when there is no list -- serves calls that are not spread).  Nothing
+ * touches the GPU before the first compute call (the reference computes GenGt at package init, math.go:142-255:
  * importing the backend must not need a GPU). */
 int mlhip_set_device(int device);
+
+/* ---- several devices in one process (one host thread per device, the ABI takes a device list) ------
+ * mlhip_init sets the process's device list (n_devices = 0: every visible device; the environment variable
+ * MLHIP_DEVICES="0,1,2,3" | "all" does the same without a call).  With two or more devices listed, the host-buffer
+ * entry points a Go caller reaches through math.Curve.MultiScalarMul (math.go:960-969,
+ * driver/gurvy/bls12381/bls12-381.go:766-783) -- mlhip_msm_g1 / mlhip_msm_g2 / mlhip_bases_create + mlhip_bases_msm
+ * from MLHIP_MULTI_MIN pairs (default 2^21), and mlhip_miller_loop / mlhip_final_exp / mlhip_pairing_batch from
+ * MLHIP_MULTI_MIN_PAIRINGS elements (default 2^17) -- cut the call into contiguous shards, one per listed device, each
+ * run by its own host thread through the whole single-device pipeline (own pooled plan, own PCIe link); the
+ * per-device partial sums (already in host memory, where each shard's host tail leaves them) are added on the host.
+ * No device-side collective is involved: the caller wants the result in host memory.  (The process-per-GPU form,
+ * mathlib_amd/dist.py, exchanges the partials with one RCCL all-gather because there every rank wants the total.)
+ * Threads pinned with mlhip_set_device are never spread.  A device may be listed more than once. */
+int mlhip_init(const int* devices, int n_devices);
+int mlhip_get_devices(int* devices, int cap); /* returns the length of the list */
+int mlhip_shutdown(void);                     /* frees every cached plan / arena and forgets the device list */
+/* The same MSM with an explicit device list, whatever its size (group: MLHIP_GROUP_G1 / _G2). */
+int mlhip_msm_multi(int curve, int group, const int* devices, int n_devices, const void* points, const void* scalars,
+                    int scalars_mont, size_t n, int window_c, void* out_affine);
 
 /* sizes in bytes for a curve: Fp element, G1 affine, G2 affine, Gt, scalar (always 32) */
 int mlhip_sizes(int curve, size_t* fp, size_t* g1, size_t* g2, size_t* gt);
@@ -146,6 +166,11 @@ int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stri
  * time per handle); handles are independent of each other. */
 typedef struct mlhip_bases mlhip_bases;
 int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** bases);
+/* the table cut into contiguous shards over an explicit device list (mlhip_bases_create does this by itself with the
+ * process's list from MLHIP_MULTI_MIN bases on): every mlhip_bases_msm then moves each device's scalars over its own
+ * PCIe link and adds the per-device partial sums on the host */
+int mlhip_bases_create_multi(int curve, int group, const int* devices, int n_devices, const void* points, size_t n,
+                             int window_c, mlhip_bases** bases);
 int mlhip_bases_msm(mlhip_bases* bases, const void* scalars, int scalars_mont, size_t n, void* out_affine);
 int mlhip_bases_destroy(mlhip_bases* bases);
 

@@ -237,6 +237,12 @@ class Gt {
 };
 
 // ---------------------------------------------------------------------------------------------------
+// hip.SetDevices of the Go shim: the GPUs of this process (no argument: every visible device).  With two or more, large
+// MultiScalarMul / MultiScalarMulG2 / NewBases / PairingBatch calls are sharded over them inside the library.
+inline void SetDevices(const std::vector<int>& devices = {}) {
+  check(mlhip_init(devices.empty() ? nullptr : devices.data(), (int)devices.size()));
+}
+
 class Curve {
  public:
   int id;

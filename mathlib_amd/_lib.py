@@ -22,6 +22,11 @@ SYMBOLS = [
     "mlhip_last_error",
     "mlhip_device_count",
     "mlhip_set_device",
+    "mlhip_init",
+    "mlhip_get_devices",
+    "mlhip_shutdown",
+    "mlhip_msm_multi",
+    "mlhip_bases_create_multi",
     "mlhip_sizes",
     "mlhip_msm_g1",
     "mlhip_msm_g2",
@@ -95,6 +100,11 @@ def load() -> ctypes.CDLL:
     lib.mlhip_last_error.restype = c_char_p
     lib.mlhip_device_count.argtypes = [POINTER(ci)]
     lib.mlhip_set_device.argtypes = [ci]
+    lib.mlhip_init.argtypes = [POINTER(ci), ci]
+    lib.mlhip_get_devices.argtypes = [POINTER(ci), ci]
+    lib.mlhip_shutdown.argtypes = []
+    lib.mlhip_msm_multi.argtypes = [ci, ci, POINTER(ci), ci, vp, vp, ci, sz, ci, vp]
+    lib.mlhip_bases_create_multi.argtypes = [ci, ci, POINTER(ci), ci, vp, sz, ci, ctypes.POINTER(c_void_p)]
     lib.mlhip_sizes.argtypes = [ci, POINTER(sz), POINTER(sz), POINTER(sz), POINTER(sz)]
     for f in (lib.mlhip_msm_g1, lib.mlhip_msm_g2):
         f.argtypes = [ci, vp, vp, ci, sz, ci, vp]
@@ -149,6 +159,19 @@ def sizes(curve: int):
     a, b, c, d = c_size_t(), c_size_t(), c_size_t(), c_size_t()
     check(lib.mlhip_sizes(curve, byref(a), byref(b), byref(c), byref(d)))
     return a.value, b.value, c.value, d.value
+
+
+def init_devices(devices=None) -> None:
+    """the process's device list (mlhip_init): None / [] = every visible device"""
+    devices = list(devices or [])
+    arr = (c_int * max(1, len(devices)))(*devices)
+    check(load().mlhip_init(arr, len(devices)))
+
+
+def get_devices():
+    buf = (c_int * 64)()
+    k = load().mlhip_get_devices(buf, 64)
+    return [buf[i] for i in range(min(k, 64))]
 
 
 def device_count() -> int:

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include <string>
 
@@ -15,7 +16,50 @@ using namespace mlhip;
 
 namespace {
 thread_local std::string g_err;
-thread_local int g_device = 0;
+thread_local int g_device_sel = -1;  // mlhip_set_device on this thread; -1: follow the process's device list
+thread_local int g_device = 0;       // device of the call in progress on this thread (set by ensure_device)
+
+// ---- the process's device list (mlhip_init / MLHIP_DEVICES) ---------------------------------------------------------
+// one process, one host thread per device, the C ABI takes a device list.  A host-buffer MSM / pairing
+// batch issued by a thread that has not pinned itself to one device (mlhip_set_device) is cut into contiguous shards,
+// one per listed device, when it is large enough to pay (MLHIP_MULTI_MIN pairs, MLHIP_MULTI_MIN_PAIRINGS pairings).
+std::mutex g_devs_mu;
+std::vector<int> g_devs;
+bool g_devs_set = false;
+size_t g_multi_min_msm = (size_t)1 << 21, g_multi_min_pairing = (size_t)1 << 17;
+
+bool parse_device_list(const char* e, std::vector<int>& out) {
+  out.clear();
+  if (!e || !*e) return true;
+  if (!strcmp(e, "all")) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    for (int i = 0; i < n && i < 64; i++) out.push_back(i);
+    return true;
+  }
+  const char* q = e;
+  while (*q) {
+    char* end = nullptr;
+    long v = strtol(q, &end, 10);
+    if (end == q || v < 0 || v > 1023 || out.size() >= 64) return false;
+    out.push_back((int)v);
+    q = end;
+    if (*q == ',') q++;
+    else if (*q) return false;
+  }
+  return true;
+}
+
+std::vector<int> device_list() {
+  std::lock_guard<std::mutex> lk(g_devs_mu);
+  if (!g_devs_set) {
+    g_devs_set = true;
+    if (!parse_device_list(getenv("MLHIP_DEVICES"), g_devs)) g_devs.clear();
+    if (const char* e = getenv("MLHIP_MULTI_MIN")) g_multi_min_msm = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("MLHIP_MULTI_MIN_PAIRINGS")) g_multi_min_pairing = strtoull(e, nullptr, 10);
+  }
+  return g_devs;
+}
 
 int ensure_device() {
   int n = 0;
@@ -23,8 +67,47 @@ int ensure_device() {
   if (e != hipSuccess || n <= 0)
     return mlhip_rt::fail(MLHIP_ENODEVICE,
                           std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
-  if (g_device < 0 || g_device >= n) return mlhip_rt::fail(MLHIP_EINVAL, "device index out of range");
-  HIPCHK(hipSetDevice(g_device));
+  int d = g_device_sel;
+  if (d < 0) {
+    const std::vector<int> l = device_list();
+    d = l.empty() ? 0 : l[0];
+  }
+  if (d < 0 || d >= n) return mlhip_rt::fail(MLHIP_EINVAL, "device index out of range");
+  g_device = d;
+  HIPCHK(hipSetDevice(d));
+  return 0;
+}
+
+// Devices a call of `units` items issued by this thread is spread over: empty = stay on one device.
+std::vector<int> spread_devices(size_t units, bool pairing) {
+  if (g_device_sel >= 0) return {};
+  std::vector<int> l = device_list();
+  if (l.size() < 2 || units < (pairing ? g_multi_min_pairing : g_multi_min_msm)) return {};
+  if (l.size() > units) l.resize(units);
+  return l;
+}
+
+// fn(shard, lo, hi) runs on one host thread per listed device, with that device selected for the thread: contiguous
+// shards [n r / D, n (r + 1) / D).  A device may be listed more than once (two shards in flight on it).
+template <class Fn>
+int run_on_devices(const std::vector<int>& devs, size_t n, Fn fn) {
+  const size_t D = devs.size();
+  std::vector<int> rcs(D, 0);
+  std::vector<std::string> errs(D);
+  auto body = [&](size_t r) {
+    const int saved = g_device_sel;
+    g_device_sel = devs[r];
+    rcs[r] = fn(r, n * r / D, n * (r + 1) / D);
+    if (rcs[r]) errs[r] = g_err;
+    g_device_sel = saved;
+  };
+  std::vector<std::thread> th;
+  th.reserve(D);
+  for (size_t r = 1; r < D; r++) th.emplace_back(body, r);
+  body(0);
+  for (std::thread& t : th) t.join();
+  for (size_t r = 0; r < D; r++)
+    if (rcs[r]) return mlhip_rt::fail(rcs[r], "device " + std::to_string(devs[r]) + " (shard " + std::to_string(r) + "): " + errs[r]);
   return 0;
 }
 
@@ -176,6 +259,16 @@ int pairing_host(int curve, int what, const void* g1, const void* g2, size_t ppp
   if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
   if (n == 0) return 0;
   if (!out || (what == 1 ? !in : (!g1 || !g2))) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  {
+    // independent per element: a large batch is split over the process's devices, no exchange at all
+    const std::vector<int> devs = spread_devices(n, true);
+    if (!devs.empty())
+      return run_on_devices(devs, n, [&](size_t, size_t lo, size_t hi) {
+        return pairing_host(curve, what, g1 ? (const char*)g1 + lo * ppp * sz.g1 : nullptr,
+                            g2 ? (const char*)g2 + lo * ppp * sz.g2 : nullptr, ppp, hi - lo,
+                            in ? (const char*)in + lo * sz.gt : nullptr, (char*)out + lo * sz.gt);
+      });
+  }
   int rc = ensure_device();
   if (rc) return rc;
   HostCall hc;
@@ -212,8 +305,8 @@ struct PoolEntry {
   unsigned long stamp = 0;
   size_t bytes = 0;  // device memory the entry took (free memory before - after its creation)
 };
-constexpr size_t POOL_MAX = 16;
-constexpr size_t POOL_MAX_BYTES = (size_t)32 << 30;
+constexpr size_t POOL_MAX = 16;  // per device
+constexpr size_t POOL_MAX_BYTES = (size_t)32 << 30;  // per device
 std::mutex g_pool_mu;
 std::vector<PoolEntry*> g_pool;
 unsigned long g_pool_clock = 0;
@@ -240,14 +333,18 @@ PoolEntry* pool_acquire(int curve, int group, int c, size_t n, size_t ptsz, int&
         e->stamp = ++g_pool_clock;
         return e;
       }
-    // evict least recently used idle entries while the pool is full or over its memory budget
+    // evict this device's least recently used idle entries while its share of the pool is full or over budget
     for (;;) {
-      size_t total = 0;
-      for (PoolEntry* e : g_pool) total += e->bytes;
-      if (g_pool.size() < POOL_MAX && total <= POOL_MAX_BYTES) break;
+      size_t total = 0, count = 0;
+      for (PoolEntry* e : g_pool)
+        if (e->device == g_device) {
+          total += e->bytes;
+          count++;
+        }
+      if (count < POOL_MAX && total <= POOL_MAX_BYTES) break;
       size_t vi = g_pool.size();
       for (size_t i = 0; i < g_pool.size(); i++)
-        if (!g_pool[i]->busy && (vi == g_pool.size() || g_pool[i]->stamp < g_pool[vi]->stamp)) vi = i;
+        if (g_pool[i]->device == g_device && !g_pool[i]->busy && (vi == g_pool.size() || g_pool[i]->stamp < g_pool[vi]->stamp)) vi = i;
       if (vi == g_pool.size()) break;  // everything is in use
       victims.push_back(g_pool[vi]);
       g_pool.erase(g_pool.begin() + vi);
@@ -287,7 +384,9 @@ PoolEntry* pool_acquire(int curve, int group, int c, size_t n, size_t ptsz, int&
   e->bytes = free_before > free_after ? free_before - free_after : 0;
   if (use_pool) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (g_pool.size() < POOL_MAX) {
+    size_t count = 0;
+    for (PoolEntry* o : g_pool) count += o->device == e->device;
+    if (count < POOL_MAX) {
       e->pooled = true;
       e->stamp = ++g_pool_clock;
       g_pool.push_back(e);
@@ -351,6 +450,30 @@ int tu_plan_stream(mlhip_msm_plan* p, void* d_pts, void* d_sc, const void* point
   return rc;
 }
 
+int host_group_sum(int curve, int group, const void* pts, size_t n, void* out) {
+  return group == MLHIP_GROUP_G1 ? mlhip_g1_sum(curve, pts, n, out) : mlhip_g2_sum(curve, pts, n, out);
+}
+
+int msm_host_buffers(int curve, int group, const void* points, const void* scalars, int mont, size_t n, int window_c,
+                     void* out);
+
+// One MSM over several devices (reference semantics math.go:960-969 /
+// driver/gurvy/bls12381/bls12-381.go:766-783): contiguous shards of the pairs, one host thread per device running the
+// whole single-device pipeline on its shard (its own pooled plan, its own PCIe link), the per-device partial sums --
+// already in host memory, where each shard's Horner tail leaves them -- added on the host.  The caller wants the sum in
+// host memory, so there is nothing for a device-side collective to do here; the RCCL all-gather lives in the
+// process-per-GPU form (mathlib_amd/dist.py), where every rank wants the total.
+int msm_multi(const std::vector<int>& devs, int curve, int group, const void* points, const void* scalars, int mont,
+              size_t n, int window_c, void* out, size_t ptsz) {
+  std::vector<char> partial(devs.size() * ptsz);
+  int rc = run_on_devices(devs, n, [&](size_t r, size_t lo, size_t hi) {
+    return msm_host_buffers(curve, group, (const char*)points + lo * ptsz, (const char*)scalars + lo * 32, mont, hi - lo,
+                            window_c, &partial[r * ptsz]);
+  });
+  if (rc) return rc;
+  return host_group_sum(curve, group, partial.data(), devs.size(), out);
+}
+
 int msm_host_buffers(int curve, int group, const void* points, const void* scalars, int mont, size_t n, int window_c,
                      void* out) {
   Sizes sz;
@@ -364,6 +487,10 @@ int msm_host_buffers(int curve, int group, const void* points, const void* scala
     return 0;
   }
   if (!points || !scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  {
+    const std::vector<int> devs = spread_devices(n, false);
+    if (!devs.empty()) return msm_multi(devs, curve, group, points, scalars, mont, n, window_c, out, ptsz);
+  }
   if (window_c == 0) window_c = pick_window(n);
   int rc = ensure_device();
   if (rc) return rc;
@@ -415,9 +542,61 @@ int mlhip_device_count(int* count) {
 }
 
 int mlhip_set_device(int device) {
-  if (device < 0) return mlhip_rt::fail(MLHIP_EINVAL, "negative device index");
-  g_device = device;
+  if (device < -1) return mlhip_rt::fail(MLHIP_EINVAL, "negative device index");
+  g_device_sel = device;
   return 0;
+}
+
+int mlhip_init(const int* devices, int n_devices) {
+  if (n_devices < 0 || n_devices > 64 || (n_devices > 0 && !devices))
+    return mlhip_rt::fail(MLHIP_EINVAL, "device list: 0 .. 64 entries");
+  std::vector<int> l;
+  if (n_devices == 0) {
+    parse_device_list("all", l);
+  } else {
+    for (int i = 0; i < n_devices; i++) {
+      if (devices[i] < 0) return mlhip_rt::fail(MLHIP_EINVAL, "negative device index in the device list");
+      l.push_back(devices[i]);
+    }
+  }
+  (void)device_list();  // the environment's thresholds are read once, before the list is replaced
+  std::lock_guard<std::mutex> lk(g_devs_mu);
+  g_devs = l;
+  return 0;
+}
+
+int mlhip_get_devices(int* devices, int cap) {
+  const std::vector<int> l = device_list();
+  for (size_t i = 0; i < l.size() && (int)i < cap; i++)
+    if (devices) devices[i] = l[i];
+  return (int)l.size();
+}
+
+int mlhip_shutdown(void) {
+  mlhip_release_cache();
+  std::lock_guard<std::mutex> lk(g_devs_mu);
+  g_devs.clear();
+  return 0;
+}
+
+int mlhip_msm_multi(int curve, int group, const int* devices, int n_devices, const void* points, const void* scalars,
+                    int scalars_mont, size_t n, int window_c, void* out_affine) {
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (group != MLHIP_GROUP_G1 && group != MLHIP_GROUP_G2) return mlhip_rt::fail(MLHIP_EINVAL, "group must be 1 (G1) or 2 (G2)");
+  if (!out_affine) return mlhip_rt::fail(MLHIP_EINVAL, "null output pointer");
+  if (n_devices < 1 || n_devices > 64 || !devices) return mlhip_rt::fail(MLHIP_EINVAL, "device list: 1 .. 64 entries");
+  const size_t ptsz = group == MLHIP_GROUP_G1 ? sz.g1 : sz.g2;
+  if (n == 0) {
+    memset(out_affine, 0, ptsz);
+    return 0;
+  }
+  if (!points || !scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  std::vector<int> devs(devices, devices + n_devices);
+  for (int d : devs)
+    if (d < 0) return mlhip_rt::fail(MLHIP_EINVAL, "negative device index in the device list");
+  if (devs.size() > n) devs.resize(n);
+  return msm_multi(devs, curve, group, points, scalars, scalars_mont, n, window_c, out_affine, ptsz);
 }
 
 int mlhip_sizes(int curve, size_t* fp, size_t* g1, size_t* g2, size_t* gt) {
@@ -559,35 +738,39 @@ struct mlhip_bases {
   mlhip_msm_plan* plan = nullptr;
   void *d_pts = nullptr, *d_sc = nullptr;
   size_t n = 0, ptsz = 0;
-  int device = 0;
+  int curve = 0, group = 0, device = 0;
   hipStream_t stream = nullptr;  // own non-blocking stream (see PoolEntry)
   std::mutex mu;  // one MSM at a time per handle: the plan and the scalar buffer are shared state
+  // a table spread over several devices: contiguous shards, shard r = bases [lo[r], lo[r + 1]) on devs[r]
+  std::vector<mlhip_bases*> shards;
+  std::vector<size_t> lo;
+  std::vector<int> devs;
 };
 
 int mlhip_bases_destroy(mlhip_bases* b) {
   if (!b) return 0;
-  (void)hipSetDevice(b->device);
-  if (b->d_pts) (void)hipFree(b->d_pts);
-  if (b->d_sc) (void)hipFree(b->d_sc);
-  if (b->plan) mlhip_msm_plan_destroy(b->plan);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  for (mlhip_bases* sh : b->shards) mlhip_bases_destroy(sh);
+  if (b->shards.empty()) {
+    (void)hipSetDevice(b->device);
+    if (b->d_pts) (void)hipFree(b->d_pts);
+    if (b->d_sc) (void)hipFree(b->d_sc);
+    if (b->plan) mlhip_msm_plan_destroy(b->plan);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+  }
   delete b;
   return 0;
 }
 
-int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** out) {
-  if (!out) return mlhip_rt::fail(MLHIP_EINVAL, "null output pointer");
-  *out = nullptr;
-  Sizes sz;
-  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
-  if (group != MLHIP_GROUP_G1 && group != MLHIP_GROUP_G2) return mlhip_rt::fail(MLHIP_EINVAL, "group must be 1 (G1) or 2 (G2)");
-  if (!points || n == 0) return mlhip_rt::fail(MLHIP_EINVAL, "bases need at least one point");
+static int bases_create_single(int curve, int group, const void* points, size_t n, int window_c, size_t ptsz,
+                               mlhip_bases** out) {
   int rc = ensure_device();
   if (rc) return rc;
   mlhip_bases* b = new mlhip_bases();
   b->device = g_device;
+  b->curve = curve;
+  b->group = group;
   b->n = n;
-  b->ptsz = group == MLHIP_GROUP_G1 ? sz.g1 : sz.g2;
+  b->ptsz = ptsz;
   rc = mlhip_msm_plan_create(curve, group, n, window_c, &b->plan);
   if (!rc && (hipMalloc(&b->d_pts, n * b->ptsz) != hipSuccess || hipMalloc(&b->d_sc, n * 32) != hipSuccess))
     rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of the bases failed");
@@ -604,6 +787,58 @@ int mlhip_bases_create(int curve, int group, const void* points, size_t n, int w
   return 0;
 }
 
+static int bases_create_on(const std::vector<int>& devs, int curve, int group, const void* points, size_t n, int window_c,
+                           size_t ptsz, mlhip_bases** out) {
+  mlhip_bases* b = new mlhip_bases();
+  b->curve = curve;
+  b->group = group;
+  b->n = n;
+  b->ptsz = ptsz;
+  b->devs = devs;
+  b->shards.assign(devs.size(), nullptr);
+  b->lo.assign(devs.size() + 1, n);
+  int rc = run_on_devices(devs, n, [&](size_t r, size_t lo, size_t hi) {
+    b->lo[r] = lo;
+    return bases_create_single(curve, group, (const char*)points + lo * ptsz, hi - lo, window_c, ptsz, &b->shards[r]);
+  });
+  if (rc) {
+    std::string msg = g_err;
+    mlhip_bases_destroy(b);
+    return mlhip_rt::fail(rc, msg);
+  }
+  *out = b;
+  return 0;
+}
+
+int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** out) {
+  if (!out) return mlhip_rt::fail(MLHIP_EINVAL, "null output pointer");
+  *out = nullptr;
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (group != MLHIP_GROUP_G1 && group != MLHIP_GROUP_G2) return mlhip_rt::fail(MLHIP_EINVAL, "group must be 1 (G1) or 2 (G2)");
+  if (!points || n == 0) return mlhip_rt::fail(MLHIP_EINVAL, "bases need at least one point");
+  const size_t ptsz = group == MLHIP_GROUP_G1 ? sz.g1 : sz.g2;
+  const std::vector<int> devs = spread_devices(n, false);
+  if (!devs.empty()) return bases_create_on(devs, curve, group, points, n, window_c, ptsz, out);
+  return bases_create_single(curve, group, points, n, window_c, ptsz, out);
+}
+
+int mlhip_bases_create_multi(int curve, int group, const int* devices, int n_devices, const void* points, size_t n,
+                             int window_c, mlhip_bases** out) {
+  if (!out) return mlhip_rt::fail(MLHIP_EINVAL, "null output pointer");
+  *out = nullptr;
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (group != MLHIP_GROUP_G1 && group != MLHIP_GROUP_G2) return mlhip_rt::fail(MLHIP_EINVAL, "group must be 1 (G1) or 2 (G2)");
+  if (!points || n == 0) return mlhip_rt::fail(MLHIP_EINVAL, "bases need at least one point");
+  if (n_devices < 1 || n_devices > 64 || !devices) return mlhip_rt::fail(MLHIP_EINVAL, "device list: 1 .. 64 entries");
+  std::vector<int> devs(devices, devices + n_devices);
+  for (int d : devs)
+    if (d < 0) return mlhip_rt::fail(MLHIP_EINVAL, "negative device index in the device list");
+  if (devs.size() > n) devs.resize(n);
+  return bases_create_on(devs, curve, group, points, n, window_c, group == MLHIP_GROUP_G1 ? sz.g1 : sz.g2, out);
+}
+
 int mlhip_bases_msm(mlhip_bases* b, const void* scalars, int scalars_mont, size_t n, void* out_affine) {
   if (!b || !out_affine) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
   if (n > b->n) return mlhip_rt::fail(MLHIP_EINVAL, "more scalars than resident bases");
@@ -612,6 +847,18 @@ int mlhip_bases_msm(mlhip_bases* b, const void* scalars, int scalars_mont, size_
     return 0;
   }
   if (!scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  if (!b->shards.empty()) {
+    // every device adds up its part of the first n bases; the partial sums meet on the host (see msm_multi)
+    const size_t D = b->shards.size();
+    std::vector<char> partial(D * b->ptsz, 0);
+    int rc = run_on_devices(b->devs, D, [&](size_t r, size_t, size_t) {
+      const size_t lo = b->lo[r], hi = std::min(b->lo[r + 1], n);
+      if (lo >= hi) return 0;  // this shard's bases lie beyond the call's scalars: identity
+      return mlhip_bases_msm(b->shards[r], (const char*)scalars + lo * 32, scalars_mont, hi - lo, &partial[r * b->ptsz]);
+    });
+    if (rc) return rc;
+    return host_group_sum(b->curve, b->group, partial.data(), D, out_affine);
+  }
   if (hipSetDevice(b->device) != hipSuccess) return mlhip_rt::fail(MLHIP_EHIP, "hipSetDevice failed");
   std::lock_guard<std::mutex> lk(b->mu);
   {

@@ -434,6 +434,12 @@ class Curve:
         return Gt(out.raw, self)
 
 
+def SetDevices(*devices: int) -> None:
+    """the GPUs of this process (hip.SetDevices in the Go shim -> mlhip_init): with two or more listed, large
+    MultiScalarMul / MultiScalarMulG2 / NewBases / PairingBatch calls are sharded over them inside the library"""
+    _lib.init_devices(list(devices))
+
+
 def NewCurve(name: str, **kw) -> Curve:
     ids = {"BN254": CURVE_BN254, "BLS12_381": CURVE_BLS12_381, "BLS12_377": CURVE_BLS12_377}
     return Curve(ids[name.upper().replace("-", "_")], **kw)
