@@ -106,6 +106,12 @@ MLHIP_HD void fp2_select(Fp2L<C>& r, bool c, const Fp2L<C>& a, const Fp2L<C>& b)
   fp_select<C>(r.v, c, a.v, b.v);
 }
 template <class C>
+MLHIP_HD void fp2_norm(Fp2L<C>&) {}
+template <class C>
+MLHIP_HD void fp2_reduce(Fp2L<C>&) {}
+template <class C>
+MLHIP_HD int fp2_weight(const Fp2L<C>&) { return 1; }
+template <class C>
 MLHIP_HD void fp2_halve(Fp2L<C>& r, const Fp2L<C>& a);  // defined after pairing.h's fp_halve
 
 // (a0 + a1 u)(b0 + b1 u) = (a0 b0 + BETA a1 b1) + (a1 b0 + a0 b1) u

@@ -1,0 +1,421 @@
+// fp2_lanes28.h -- Fp2 elements over lane pairs in the CARRY-FREE form (fp28.h): the element type of the batched
+// pairing kernels for BLS12-381 (pairing_kernels.h: k_pairing_lp28).
+//
+// Same layout as fp2_lanes.h -- lane 2i owns c0 and lane 2i+1 owns c1 of every Fp2 value, one pairing per lane pair --
+// but each component is an Fp28 (14 signed 28-bit limbs, Montgomery R28 = 2^392) instead of 12 saturated 32-bit limbs:
+//   * a limb product is ONE v_mad_i64_i32 (no v_addc on a third accumulator word): an Fp2 product (one fused dual
+//     product per lane) costs 602 multiplier instructions and ~70 others instead of 432 v_mad + 432 v_addc + ~200;
+//   * add / sub / neg / conj / small multiples are 14 independent 32-bit operations with no carry chain and no
+//     conditional subtraction (a saturated fp_add is 12 v_addc + 12 v_subb + 12 selects);
+//   * the price is bookkeeping: a value carries a WEIGHT w (it is a sum / difference of w normalized values,
+//     |limb| < w 2^28), storage needs w <= 8, a dual product needs 2 w_a w_b <= 8, a single product w_a w_b <= 8, the
+//     one-product square w = 1 (fp28.h).  The tower / pairing formulas (tower.h, pairing.h) call fp2_norm() -- one
+//     carry propagation, ~40 full-rate instructions -- where a weight would otherwise exceed its budget; for the
+//     saturated element types fp2_norm is a no-op.
+// A second budget is the VALUE: carry propagation does not reduce mod p, so a value also carries a bound vb (|value| <
+// 1.2 vb p; a Montgomery product resets it to 1 whenever sum vb_x vb_y <= 280, because R28 = 2^11 p).  Sums of products
+// stay small by themselves; only linear terms carried from one loop iteration to the next (the -2 a / +2 a terms of the
+// cyclotomic squarings) would double per iteration -- there fp2_reduce() subtracts round(value / p) p, a float
+// estimate from the top limb plus one multiply-and-propagate pass (~1.7 x the cost of fp2_norm).
+// The weights do not depend on the data (the formulas are straight-line), so the budget is verified once and for all on
+// the CPU: Fp2H28 below is the host model of one lane pair (both components + the weight), every operation checks its
+// precondition, and tests/test_host_math.py runs the whole pairing through it against the oracle.
+// Only u^2 = -1 and xi = 1 + u (BLS12-381) are implemented; BN254's 10-limb form gains nothing on the multiplier and
+// BLS12-377's u^2 = -5 does not fit the dual product's weight budget -- both stay on fp2_lanes.h.
+#pragma once
+#include "fp28.h"
+#include "fp2_lanes.h"
+
+#if !defined(__HIPCC__)
+#include <cstdio>
+#include <cstdlib>
+#include <execinfo.h>
+#endif
+
+namespace mlhip {
+
+// ---- device element: this lane's component --------------------------------------------------------------------
+template <class C>
+struct Fp2L28 {
+  Fp28<C> v;
+  static constexpr int LANES = 1;
+  MLHIP_HD Fp28<C>& at(int) { return v; }
+  MLHIP_HD const Fp28<C>& at(int) const { return v; }
+  MLHIP_HD static bool hi(int) { return lane_is_hi(); }
+  MLHIP_HD int w() const { return 1; }
+  MLHIP_HD void set_w(int) {}
+  MLHIP_HD int vb() const { return 1; }
+  MLHIP_HD void set_vb(int) {}
+  MLHIP_HD static void require(bool, const char*, int, int) {}
+};
+template <class C>
+MLHIP_HD void lp28_partner(Fp2L28<C>& r, const Fp2L28<C>& a) {
+#pragma unroll
+  for (int i = 0; i < C::N28; i++) r.v.l[i] = (int32_t)pair_xchg_u32((uint32_t)a.v.l[i]);
+}
+template <class C>
+MLHIP_HD bool lp28_both(const Fp2L28<C>&, const bool (&b)[1]) {
+  const uint32_t z = b[0] ? 1u : 0u;
+  return (z & pair_xchg_u32(z)) != 0;
+}
+
+#if !defined(__HIPCC__)
+// ---- host model of one lane pair (g++ test build only): both components and the weight ------------------------
+template <class C>
+struct Fp2H28 {
+  Fp28<C> c[2];
+  int wt = 1, vbound = 1;
+  static constexpr int LANES = 2;
+  Fp28<C>& at(int i) { return c[i]; }
+  const Fp28<C>& at(int i) const { return c[i]; }
+  static bool hi(int i) { return i == 1; }
+  int w() const { return wt; }
+  void set_w(int x) { wt = x; }
+  int vb() const { return vbound; }
+  void set_vb(int x) {
+    require(x <= 512, "a stored value (value bound)", x, 0);
+    vbound = x;
+  }
+  static void require(bool ok, const char* what, int wa, int wb) {
+    if (!ok) {
+      fprintf(stderr, "fp2_lanes28: weight budget exceeded in %s (w_a = %d, w_b = %d)\n", what, wa, wb);
+      void* frames[24];
+      backtrace_symbols_fd(frames, backtrace(frames, 24), 2);  // which formula: pipe through c++filt
+      abort();
+    }
+  }
+};
+template <class C>
+inline void lp28_partner(Fp2H28<C>& r, const Fp2H28<C>& a) {
+  const Fp28<C> t0 = a.c[0], t1 = a.c[1];
+  r.c[0] = t1;
+  r.c[1] = t0;
+  r.wt = a.wt;
+  r.vbound = a.vbound;
+}
+template <class C>
+inline bool lp28_both(const Fp2H28<C>&, const bool (&b)[2]) {
+  return b[0] && b[1];
+}
+#endif
+
+constexpr int LP28_MAXW = 8;    // |limb| < w 2^28 must fit an int32
+constexpr int LP28_MAXU = 280;  // sum of vb_x vb_y over the products of one reduction: the result is then within 1.2 p
+
+// value -> value - round(value / p) p, carry-propagated: limbs normalized, |result| < 0.6 p.  The quotient comes from
+// the top limb (value / 2^364 up to the weight) in single precision: exact to well within +-0.01.
+template <class C>
+MLHIP_HD void fp28_reduce(Fp28<C>& r, const Fp28<C>& a) {
+  constexpr int L = C::N28;
+  constexpr float inv_ptop = 1.0f / ((float)C::P28[L - 1] + (float)C::P28[L - 2] * (1.0f / 268435456.0f));
+  const float qf = (float)a.l[L - 1] * inv_ptop;
+  const int32_t q = (int32_t)(qf + (qf >= 0.0f ? 0.5f : -0.5f));
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < L - 1; i++) {
+    const int64_t v = (int64_t)a.l[i] - (int64_t)q * C::P28[i] + c;
+    r.l[i] = (int32_t)((uint32_t)v & MASK28);
+    c = v >> 28;
+  }
+  r.l[L - 1] = (int32_t)((int64_t)a.l[L - 1] - (int64_t)q * C::P28[L - 1] + c);
+}
+
+// ---- generic bodies over either element -------------------------------------------------------------------------
+template <class C, class E>
+MLHIP_HD void lp28_zero(E& r) {
+  for (int i = 0; i < E::LANES; i++) fp28_zero<C>(r.at(i));
+  r.set_w(1);
+  r.set_vb(1);
+}
+template <class C, class E>
+MLHIP_HD void lp28_one(E& r) {
+  for (int i = 0; i < E::LANES; i++) {
+    Fp28<C> one, zero;
+    fp28_from_const<C>(one, C::ONE28);
+    fp28_zero<C>(zero);
+    fp28_select<C>(r.at(i), E::hi(i), zero, one);
+  }
+  r.set_w(1);
+  r.set_vb(1);
+}
+template <class C, class E>
+MLHIP_HD void lp28_add(E& r, const E& a, const E& b) {
+  const int w = a.w() + b.w();
+  E::require(w <= LP28_MAXW, "fp2_add / fp2_sub", a.w(), b.w());
+  const int v = a.vb() + b.vb();
+  for (int i = 0; i < E::LANES; i++) fp28_add<C>(r.at(i), a.at(i), b.at(i));
+  r.set_w(w);
+  r.set_vb(v);
+}
+template <class C, class E>
+MLHIP_HD void lp28_sub(E& r, const E& a, const E& b) {
+  const int w = a.w() + b.w();
+  E::require(w <= LP28_MAXW, "fp2_add / fp2_sub", a.w(), b.w());
+  const int v = a.vb() + b.vb();
+  for (int i = 0; i < E::LANES; i++) fp28_sub<C>(r.at(i), a.at(i), b.at(i));
+  r.set_w(w);
+  r.set_vb(v);
+}
+template <class C, class E>
+MLHIP_HD void lp28_neg(E& r, const E& a) {
+  for (int i = 0; i < E::LANES; i++) fp28_neg<C>(r.at(i), a.at(i));
+  r.set_w(a.w());
+  r.set_vb(a.vb());
+}
+template <class C, class E>
+MLHIP_HD void lp28_conj(E& r, const E& a) {
+  for (int i = 0; i < E::LANES; i++) {
+    Fp28<C> n;
+    fp28_neg<C>(n, a.at(i));
+    fp28_select<C>(r.at(i), E::hi(i), n, a.at(i));
+  }
+  r.set_w(a.w());
+  r.set_vb(a.vb());
+}
+template <class C, class E>
+MLHIP_HD void lp28_select(E& r, bool c, const E& a, const E& b) {
+  const int w = a.w() > b.w() ? a.w() : b.w(), v = a.vb() > b.vb() ? a.vb() : b.vb();
+  for (int i = 0; i < E::LANES; i++) fp28_select<C>(r.at(i), c, a.at(i), b.at(i));
+  r.set_w(w);
+  r.set_vb(v);
+}
+template <class C, class E>
+MLHIP_HD void lp28_norm(E& r) {
+  for (int i = 0; i < E::LANES; i++) fp28_normalize<C>(r.at(i), r.at(i));
+  r.set_w(1);
+}
+template <class C, class E>
+MLHIP_HD void lp28_reduce(E& r) {
+  for (int i = 0; i < E::LANES; i++) fp28_reduce<C>(r.at(i), r.at(i));
+  r.set_w(1);
+  r.set_vb(1);
+}
+// k a for a small positive k; for k > 2 carry-propagated in the same pass (64-bit intermediates): normalized result
+template <class C, class E>
+MLHIP_HD void lp28_mul_small(E& r, const E& a, int k) {
+  E::require(k >= 1 && k <= 64, "fp2_mul_small", a.w(), k);
+  if (k <= 2) {  // doubling stays lazy (the branch depends on k only: the host model and the device take the same one)
+    E::require(k * a.w() <= LP28_MAXW, "fp2_mul_small", a.w(), k);
+    for (int i = 0; i < E::LANES; i++)
+#pragma unroll
+      for (int j = 0; j < C::N28; j++) r.at(i).l[j] = a.at(i).l[j] * k;
+    r.set_w(k * a.w());
+    r.set_vb(k * a.vb());
+    return;
+  }
+  const int v = k * a.vb();
+  for (int i = 0; i < E::LANES; i++) {
+    int64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < C::N28 - 1; j++) {
+      const int64_t v = (int64_t)a.at(i).l[j] * k + c;
+      r.at(i).l[j] = (int32_t)((uint32_t)v & MASK28);
+      c = v >> 28;
+    }
+    r.at(i).l[C::N28 - 1] = (int32_t)((int64_t)a.at(i).l[C::N28 - 1] * k + c);
+  }
+  r.set_w(1);
+  r.set_vb(v);
+}
+// (a + (a odd ? p : 0)) / 2, limb-wise: bit 0 of limb j+1 moves to bit 27 of limb j.  Needs limbs that are integers of
+// the right parity only -- any weight; the weight does not grow.
+template <class C, class E>
+MLHIP_HD void lp28_halve(E& r, const E& a) {
+  E::require(a.w() + 1 <= LP28_MAXW, "fp2_halve", a.w(), 0);
+  for (int i = 0; i < E::LANES; i++) {
+    const int32_t odd = a.at(i).l[0] & 1;
+    int32_t t[C::N28];
+#pragma unroll
+    for (int j = 0; j < C::N28; j++) t[j] = a.at(i).l[j] + (odd ? C::P28[j] : 0);
+#pragma unroll
+    for (int j = 0; j < C::N28 - 1; j++) r.at(i).l[j] = (t[j] >> 1) + ((t[j + 1] & 1) << 27);
+    r.at(i).l[C::N28 - 1] = t[C::N28 - 1] >> 1;
+  }
+  const int v = (a.vb() + 1) / 2 + 1;
+  r.set_w((a.w() + 1) / 2 + 1);  // |limb| < ((w + 1) 2^28) / 2 + 2^27
+  r.set_vb(v);
+}
+
+// (a0 + a1 u)(b0 + b1 u), u^2 = -1: one fused dual product per lane
+//   lane c0: a0 b0 + a1 (-b1)        lane c1: a1 b0 + a0 b1
+template <class C, class E>
+MLHIP_HD void lp28_mul(E& r, const E& a, const E& b) {
+  static_assert(C::BETA == -1, "carry-free lane pairs: u^2 = -1 only");
+  E::require(2 * a.w() * b.w() <= 8, "fp2_mul", a.w(), b.w());
+  E::require(2 * a.vb() * b.vb() <= LP28_MAXU, "fp2_mul (value bound)", a.vb(), b.vb());
+  E ax, bx, o;
+  lp28_partner<C>(ax, a);
+  lp28_partner<C>(bx, b);
+  for (int i = 0; i < E::LANES; i++) {
+    const bool hi = E::hi(i);
+    Fp28<C> nb, y1, y2;
+    fp28_neg<C>(nb, bx.at(i));
+    fp28_select<C>(y1, hi, bx.at(i), b.at(i));
+    fp28_select<C>(y2, hi, b.at(i), nb);
+    fp28_mul2<C>(o.at(i), a.at(i), y1, ax.at(i), y2);
+  }
+  o.set_w(1);
+  o.set_vb(1);
+  r = o;
+}
+// c0 = (a0 + a1)(a0 - a1), c1 = (2 a1) a0: one single product per lane; the operands have twice the weight of a
+template <class C, class E>
+MLHIP_HD void lp28_sqr(E& r, const E& a) {
+  static_assert(C::BETA == -1, "carry-free lane pairs: u^2 = -1 only");
+  E::require(4 * a.w() * a.w() <= 8, "fp2_sqr", a.w(), a.w());
+  E::require(4 * a.vb() * a.vb() <= LP28_MAXU, "fp2_sqr (value bound)", a.vb(), a.vb());
+  E ax, o;
+  lp28_partner<C>(ax, a);
+  for (int i = 0; i < E::LANES; i++) {
+    const bool hi = E::hi(i);
+    Fp28<C> s, d, dd, x, y;
+    fp28_add<C>(s, a.at(i), ax.at(i));
+    fp28_sub<C>(d, a.at(i), ax.at(i));
+    fp28_add<C>(dd, a.at(i), a.at(i));
+    fp28_select<C>(x, hi, dd, s);
+    fp28_select<C>(y, hi, ax.at(i), d);
+    fp28_mul<C>(o.at(i), x, y);
+  }
+  o.set_w(1);
+  o.set_vb(1);
+  r = o;
+}
+// a * k, k in Fp (normalized carry-free form)
+template <class C, class E>
+MLHIP_HD void lp28_mul_fp(E& r, const E& a, const Fp28<C>& k) {
+  E::require(a.w() <= 8, "fp2_mul_fp", a.w(), 1);
+  E::require(a.vb() <= LP28_MAXU, "fp2_mul_fp (value bound)", a.vb(), 1);
+  for (int i = 0; i < E::LANES; i++) fp28_mul<C>(r.at(i), a.at(i), k);
+  r.set_w(1);
+  r.set_vb(1);
+}
+// xi a, xi = 1 + u: c0 = a0 - a1, c1 = a0 + a1
+template <class C, class E>
+MLHIP_HD void lp28_mul_xi(E& r, const E& a) {
+  static_assert(C::XI0 == 1 && C::XI1 == 1 && C::BETA == -1, "carry-free lane pairs: xi = 1 + u only");
+  E::require(2 * a.w() <= LP28_MAXW, "fp2_mul_xi", a.w(), 0);
+  E ax, o;
+  lp28_partner<C>(ax, a);
+  for (int i = 0; i < E::LANES; i++) {
+    Fp28<C> n, t;
+    fp28_neg<C>(n, ax.at(i));
+    fp28_select<C>(t, E::hi(i), ax.at(i), n);
+    fp28_add<C>(o.at(i), a.at(i), t);
+  }
+  o.set_w(2 * a.w());
+  o.set_vb(2 * a.vb());
+  r = o;
+}
+// both components congruent to 0 mod p (exact, any weight <= 8)
+template <class C, class E>
+MLHIP_HD bool lp28_is_zero(const E& a) {
+  E::require(a.vb() <= 6, "fp2_is_zero (value bound)", a.vb(), 0);  // fp28_is_zero_exact: |value| < 8 p
+  bool z[E::LANES];
+  for (int i = 0; i < E::LANES; i++) z[i] = fp28_is_zero_exact<C>(a.at(i));
+  return lp28_both<C>(a, z);
+}
+// constants held in the boundary form (curve_constants.h): converted on the fly, one product
+template <class C, class E>
+MLHIP_HD void lp28_from_const(E& r, const uint32_t (&k)[2][C::N]) {
+  for (int i = 0; i < E::LANES; i++) {
+    Fp<C> sel;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) sel.l[j] = E::hi(i) ? k[1][j] : k[0][j];
+    fp28_from_fp<C>(r.at(i), sel);
+  }
+  r.set_w(1);
+  r.set_vb(1);
+}
+template <class C, class E>
+MLHIP_HD void lp28_mul_by_real_const(E& r, const E& a, const uint32_t (&k)[2][C::N]) {
+  Fp<C> kr;
+  fp_from_const<C>(kr, k[0]);
+  Fp28<C> k28;
+  fp28_from_fp<C>(k28, kr);
+  lp28_mul_fp<C>(r, a, k28);
+}
+// 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2): the norm goes through the boundary form for the divsteps inversion
+template <class C, class E>
+MLHIP_HD void lp28_inv(E& r, const E& a) {
+  E::require(a.w() * a.w() <= 8, "fp2_inv", a.w(), a.w());
+  E::require(a.vb() * a.vb() <= LP28_MAXU, "fp2_inv (value bound)", a.vb(), a.vb());
+  E sq, sqx, o;
+  for (int i = 0; i < E::LANES; i++) fp28_mul<C>(sq.at(i), a.at(i), a.at(i));
+  sq.set_w(1);
+  sq.set_vb(1);
+  lp28_partner<C>(sqx, sq);
+  for (int i = 0; i < E::LANES; i++) {
+    Fp28<C> n, ni28, t, nt;
+    fp28_add<C>(n, sq.at(i), sqx.at(i));  // a0^2 + a1^2 on both lanes
+    Fp<C> n32, ni32;
+    fp28_to_fp<C>(n32, n);
+    fp_inv<C>(ni32, n32);
+    fp28_from_fp<C>(ni28, ni32);
+    fp28_mul<C>(t, a.at(i), ni28);
+    fp28_neg<C>(nt, t);
+    fp28_select<C>(o.at(i), E::hi(i), nt, t);
+  }
+  o.set_w(1);
+  o.set_vb(1);
+  r = o;
+}
+
+// ---- the fp2_* overload set the towers are written against (tower.h, pairing.h) ----------------------------------
+#define MLHIP_LP28_OVERLOADS(E)                                                                                       \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_zero(E<C>& r) { lp28_zero<C>(r); }                                                                \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_one(E<C>& r) { lp28_one<C>(r); }                                                                  \
+  template <class C>                                                                                                  \
+  MLHIP_HD bool fp2_is_zero(const E<C>& a) { return lp28_is_zero<C>(a); }                                             \
+  template <class C>                                                                                                  \
+  MLHIP_HD bool fp2_eq(const E<C>& a, const E<C>& b) {                                                                \
+    E<C> d;                                                                                                           \
+    lp28_sub<C>(d, a, b);                                                                                             \
+    return lp28_is_zero<C>(d);                                                                                        \
+  }                                                                                                                   \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_add(E<C>& r, const E<C>& a, const E<C>& b) { lp28_add<C>(r, a, b); }                              \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_sub(E<C>& r, const E<C>& a, const E<C>& b) { lp28_sub<C>(r, a, b); }                              \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_dbl(E<C>& r, const E<C>& a) { lp28_add<C>(r, a, a); }                                             \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_neg(E<C>& r, const E<C>& a) { lp28_neg<C>(r, a); }                                                \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_conj(E<C>& r, const E<C>& a) { lp28_conj<C>(r, a); }                                              \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_select(E<C>& r, bool c, const E<C>& a, const E<C>& b) { lp28_select<C>(r, c, a, b); }             \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_halve(E<C>& r, const E<C>& a) { lp28_halve<C>(r, a); }                                            \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_mul(E<C>& r, const E<C>& a, const E<C>& b) { lp28_mul<C>(r, a, b); }                              \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_sqr(E<C>& r, const E<C>& a) { lp28_sqr<C>(r, a); }                                                \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_mul_fp(E<C>& r, const E<C>& a, const Fp28<C>& k) { lp28_mul_fp<C>(r, a, k); }                     \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_mul_small(E<C>& r, const E<C>& a, int k) { lp28_mul_small<C>(r, a, k); }                          \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_mul_xi(E<C>& r, const E<C>& a) { lp28_mul_xi<C>(r, a); }                                          \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_inv(E<C>& r, const E<C>& a) { lp28_inv<C>(r, a); }                                                \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_from_const(E<C>& r, const uint32_t (&k)[2][C::N]) { lp28_from_const<C>(r, k); }                   \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_mul_by_real_const(E<C>& r, const E<C>& a, const uint32_t (&k)[2][C::N]) {                         \
+    lp28_mul_by_real_const<C>(r, a, k);                                                                               \
+  }                                                                                                                   \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_norm(E<C>& r) { lp28_norm<C>(r); }                                                                \
+  template <class C>                                                                                                  \
+  MLHIP_HD void fp2_reduce(E<C>& r) { lp28_reduce<C>(r); }                                                            \
+  template <class C>                                                                                                  \
+  MLHIP_HD int fp2_weight(const E<C>& a) { return a.w(); }
+
+MLHIP_LP28_OVERLOADS(Fp2L28)
+#if !defined(__HIPCC__)
+MLHIP_LP28_OVERLOADS(Fp2H28)
+#endif
+
+}  // namespace mlhip

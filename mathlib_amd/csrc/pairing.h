@@ -68,25 +68,31 @@ MLHIP_HD void g2_double_step(G2Proj<C, E2>& T, Line<C, E2>& l) {
     fp2_from_const<C>(b3, C::B3_TW);
     fp2_mul<C>(E, Cc, b3);  // 3 b' Z^2
   }
+  // (carry-free element: T is normalized on entry and on exit; weights in the comments)
+  fp2_reduce<C>(E);     // E = 3 b' Z^2 = 12 xi Z^2 is squared below: bring the VALUE back under p as well
   fp2_dbl<C>(F, E);
-  fp2_add<C>(F, F, E);  // 3E
-  fp2_add<C>(G, B, F);
+  fp2_add<C>(F, F, E);  // 3E: 3
+  fp2_add<C>(G, B, F);  // 4
   fp2_halve<C>(G, G);
+  fp2_norm<C>(G);
   fp2_add<C>(H, T.y, T.z);
+  fp2_norm<C>(H);
   fp2_sqr<C>(H, H);
   fp2_add<C>(t, B, Cc);
-  fp2_sub<C>(H, H, t);  // 2YZ
-  fp2_sub<C>(I, E, B);
+  fp2_sub<C>(H, H, t);  // 2YZ: 3
+  fp2_sub<C>(I, E, B);  // 2
   fp2_sqr<C>(J, T.x);
   fp2_sqr<C>(EE, E);
   // X3 = A (B - F) ; Y3 = G^2 - 3 EE ; Z3 = B H
-  fp2_sub<C>(t, B, F);
-  fp2_mul<C>(T.x, A, t);
+  fp2_sub<C>(t, B, F);  // 4
+  fp2_norm<C>(t);
+  fp2_mul<C>(T.x, A, t);  // A has weight 2 (halved)
   fp2_sqr<C>(G, G);
   fp2_dbl<C>(t, EE);
   fp2_add<C>(t, t, EE);
-  fp2_sub<C>(T.y, G, t);
-  fp2_mul<C>(T.z, B, H);
+  fp2_sub<C>(T.y, G, t);  // 4
+  fp2_norm<C>(T.y);
+  fp2_mul<C>(T.z, B, H);  // 2 x 1 x 3
   fp2_neg<C>(l.r0, H);
   fp2_dbl<C>(l.r1, J);
   fp2_add<C>(l.r1, l.r1, J);
@@ -99,8 +105,10 @@ MLHIP_HD_NOINLINE void g2_add_step(G2Proj<C, E2>& T, const E2& qx, const E2& qy,
   E2 O, L, Cc, D, E, F, G, H, t, t2;
   fp2_mul<C>(t, qy, T.z);
   fp2_sub<C>(O, T.y, t);
+  fp2_norm<C>(O);
   fp2_mul<C>(t, qx, T.z);
   fp2_sub<C>(L, T.x, t);
+  fp2_norm<C>(L);
   fp2_sqr<C>(Cc, O);
   fp2_sqr<C>(D, L);
   fp2_mul<C>(E, L, D);
@@ -108,12 +116,14 @@ MLHIP_HD_NOINLINE void g2_add_step(G2Proj<C, E2>& T, const E2& qx, const E2& qy,
   fp2_mul<C>(G, T.x, D);
   fp2_dbl<C>(t, G);
   fp2_add<C>(H, E, F);
-  fp2_sub<C>(H, H, t);
+  fp2_sub<C>(H, H, t);  // 4
+  fp2_norm<C>(H);
   fp2_mul<C>(t2, T.y, E);
   fp2_mul<C>(T.x, L, H);
   fp2_sub<C>(t, G, H);
   fp2_mul<C>(t, O, t);
   fp2_sub<C>(T.y, t, t2);
+  fp2_norm<C>(T.y);
   fp2_mul<C>(T.z, T.z, E);
   // line
   fp2_mul<C>(t, L, qy);
@@ -123,22 +133,24 @@ MLHIP_HD_NOINLINE void g2_add_step(G2Proj<C, E2>& T, const E2& qx, const E2& qy,
   fp2_neg<C>(l.r1, O);
 }
 
-template <class C, class E2>
-MLHIP_HD void mul_by_line(Fp12<C, E2>& f, const Line<C, E2>& l, const Fp<C>& px, const Fp<C>& py) {
-  E2 a, b;
-  fp2_mul_fp<C>(a, l.r0, py);
+// EP: the type of P's coordinates -- Fp<C>, or Fp28<C> when E2 is the carry-free element
+template <class C, class E2, class EP>
+MLHIP_HD void mul_by_line(Fp12<C, E2>& f, const Line<C, E2>& l, const EP& px, const EP& py) {
+  E2 a, b, c = l.r2;
+  fp2_mul_fp<C>(a, l.r0, py);  // single products: any storable weight
   fp2_mul_fp<C>(b, l.r1, px);
+  fp2_norm<C>(c);
   if (C::MTWIST)
-    fp12_mul_by_014<C>(f, l.r2, b, a);
+    fp12_mul_by_014<C>(f, c, b, a);
   else
-    fp12_mul_by_034<C>(f, a, b, l.r2);
+    fp12_mul_by_034<C>(f, a, b, c);
 }
 
 // f = prod_k f_{loop,Q_k}(P_k) over n_pairs pairs (shared squaring chain: the reference's Pairing2,
 // driver/gurvy/bls12381/bls12-381.go:457-464).  Pairs flagged not live (one side at infinity) are skipped, as
 // gnark does.  MAXP bounds n_pairs (state is kept per pair).  Coordinates: px/py in Fp, qx/qy in E2.
-template <class C, int MAXP, class E2>
-MLHIP_HD void miller_loop_core(Fp12<C, E2>& f, const Fp<C>* px, const Fp<C>* py, const E2* qx, const E2* qy,
+template <class C, int MAXP, class E2, class EP>
+MLHIP_HD void miller_loop_core(Fp12<C, E2>& f, const EP* px, const EP* py, const E2* qx, const E2* qy,
                                const bool* live, int n_pairs) {
   G2Proj<C, E2> T[MAXP];
   int any = 0;
@@ -202,7 +214,7 @@ MLHIP_HD void miller_loop(Fp12<C>& f, const Affine<FpField<C>>* P, const Affine<
     qx[k] = Q[k].x;
     qy[k] = Q[k].y;
   }
-  miller_loop_core<C, MAXP, Fp2<C>>(f, px, py, qx, qy, live, n_pairs);
+  miller_loop_core<C, MAXP, Fp2<C>, Fp<C>>(f, px, py, qx, qy, live, n_pairs);
 }
 
 // ---- Karabina's compressed cyclotomic squaring ----------------------------------------------------------------
@@ -227,21 +239,27 @@ MLHIP_HD void cyclo_sqr_compressed(CycloComp<C, E2>& k) {
   fp2_sqr<C>(t2, k.b1);
   fp2_sqr<C>(t3, k.b0);
   fp2_add<C>(s, k.b0, k.b1);
+  fp2_norm<C>(s);
   fp2_sqr<C>(t7, s);
   fp2_sub<C>(t7, t7, t2);
-  fp2_sub<C>(t7, t7, t3);  // 2 b0 b1
+  fp2_sub<C>(t7, t7, t3);  // 2 b0 b1: 3
   fp2_sqr<C>(t4, k.d1);
   fp2_sqr<C>(t5, k.d0);
   fp2_add<C>(s, k.d0, k.d1);
+  fp2_norm<C>(s);
   fp2_sqr<C>(t8, s);
   fp2_sub<C>(t8, t8, t4);
   fp2_sub<C>(t8, t8, t5);
-  fp2_mul_xi<C>(t8, t8);  // 2 xi d0 d1
+  fp2_mul_xi<C>(t8, t8);  // 2 xi d0 d1: 6
   fp2_mul_xi<C>(t2, t2);
-  fp2_add<C>(t2, t2, t3);  // xi b1^2 + b0^2
+  fp2_add<C>(t2, t2, t3);  // xi b1^2 + b0^2: 3
   fp2_mul_xi<C>(t4, t4);
-  fp2_add<C>(t4, t4, t5);  // xi d1^2 + d0^2
-  // d0' = 3 t2 - 2 d0 ; d1' = 3 t7 + 2 d1 ; b1' = 3 t4 - 2 b1 ; b0' = 3 t8 + 2 b0
+  fp2_add<C>(t4, t4, t5);  // xi d1^2 + d0^2: 3
+  fp2_norm<C>(t2);
+  fp2_norm<C>(t4);
+  fp2_norm<C>(t7);
+  fp2_norm<C>(t8);
+  // d0' = 3 t2 - 2 d0 ; d1' = 3 t7 + 2 d1 ; b1' = 3 t4 - 2 b1 ; b0' = 3 t8 + 2 b0   (5 each)
   fp2_sub<C>(s, t2, k.d0);
   fp2_dbl<C>(s, s);
   fp2_add<C>(k.d0, s, t2);
@@ -254,6 +272,11 @@ MLHIP_HD void cyclo_sqr_compressed(CycloComp<C, E2>& k) {
   fp2_add<C>(s, t8, k.b0);
   fp2_dbl<C>(s, s);
   fp2_add<C>(k.b0, s, t8);
+  // the -+2 x terms are linear in the input: reduce mod p (fp2_reduce), or the value would double every step
+  fp2_reduce<C>(k.d0);
+  fp2_reduce<C>(k.d1);
+  fp2_reduce<C>(k.b1);
+  fp2_reduce<C>(k.b0);
 }
 
 // numerator and denominator of a1 for one compressed value (both formulas, selected by b0 = 0 / b1 = 0)
@@ -277,6 +300,8 @@ MLHIP_HD void cyclo_a1_fraction(E2& num, E2& den, const CycloComp<C, E2>& k) {
   fp2_one<C>(one);
   fp2_select<C>(den, z0, k.b1, t);
   fp2_select<C>(den, z0 & z1, one, den);  // f = A + C w^2 with B = 0 (e.g. f = 1): a1 = 0 / 1
+  fp2_norm<C>(num);  // 7
+  fp2_norm<C>(den);  // 4
 }
 
 template <class C, class E2>
@@ -289,10 +314,12 @@ MLHIP_HD void cyclo_decompress(Fp12<C, E2>& r, const CycloComp<C, E2>& k, const 
   fp2_mul<C>(u, k.b1, k.d0);
   fp2_sub<C>(t, t, u);
   fp2_dbl<C>(u, u);
-  fp2_sub<C>(t, t, u);  // 2 a1^2 + b0 d1 - 3 b1 d0
+  fp2_sub<C>(t, t, u);  // 2 a1^2 + b0 d1 - 3 b1 d0: 6
+  fp2_norm<C>(t);
   fp2_mul_xi<C>(t, t);
   fp2_one<C>(one);
   fp2_add<C>(r.c0.c0, t, one);
+  fp2_reduce<C>(r.c0.c0);  // value bound 13
   r.c1.c1 = a1;
   r.c1.c0 = k.b0;
   r.c0.c2 = k.b1;

@@ -7,6 +7,7 @@
 #include "mlhip_internal.h"
 #include "msm_body.h"
 #include "fp2_lanes.h"
+#include "fp2_lanes28.h"
 #include "pairing.h"
 
 namespace mlhip {
@@ -114,13 +115,75 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp(const Affine<FpF
       zq &= pair_xchg_u32(zq);
       live[k] = !(affine_is_inf<FpField<C>>(P) | (zq != 0));
     }
-    miller_loop_core<C, MAXP, E2>(f, px, py, qx, qy, live, ppp);
+    miller_loop_core<C, MAXP, E2, Fp<C>>(f, px, py, qx, qy, live, ppp);
   }
   if (WHAT == 0) {
     lp_store_gt<C>(out, i, f);
   } else {
     final_exp<C>(r, f);
     lp_store_gt<C>(out, i, r);
+  }
+}
+
+// ---- the same over lane pairs in the CARRY-FREE form (fp2_lanes28.h; BLS12-381): inputs are converted on entry (one
+// product per coordinate), the Fp12 result is brought back to the boundary form on exit (one product per coefficient +
+// the canonical representative), everything between runs on 28-bit limbs with v_mad_i64_i32 only.
+template <class C>
+__device__ __forceinline__ void lp28_store_gt(Fp12<C>* out, size_t i, const Fp12<C, Fp2L28<C>>& f) {
+  Fp<C>* o = reinterpret_cast<Fp<C>*>(out + i) + (lane_is_hi() ? 1 : 0);
+  const Fp2L28<C>* c = &f.c0.c0;
+#pragma unroll 1
+  for (int k = 0; k < 6; k++) {
+    Fp<C> t;
+    fp28_to_fp<C>(t, c[k].v);
+    o[2 * k] = t;
+  }
+}
+template <class C>
+__device__ __forceinline__ void lp28_load_gt(Fp12<C, Fp2L28<C>>& f, const Fp12<C>* in, size_t i) {
+  const Fp<C>* o = reinterpret_cast<const Fp<C>*>(in + i) + (lane_is_hi() ? 1 : 0);
+  Fp2L28<C>* c = &f.c0.c0;
+#pragma unroll 1
+  for (int k = 0; k < 6; k++) fp28_from_fp<C>(c[k].v, o[2 * k]);
+}
+
+template <class C, int WHAT, int MAXP>
+__global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp28(const Affine<FpField<C>>* __restrict__ g1,
+                                                                  const Affine<Fp2Field<C>>* __restrict__ g2, int ppp,
+                                                                  size_t n, const Fp12<C>* __restrict__ in,
+                                                                  Fp12<C>* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = t >> 1;  // both lanes of a pair share i, so this exit is pair-uniform
+  if (i >= n) return;
+  typedef Fp2L28<C> E2;
+  Fp12<C, E2> f, r;
+  if (WHAT == 1) {
+    lp28_load_gt<C>(f, in, i);
+  } else {
+    Fp28<C> px[MAXP], py[MAXP];
+    E2 qx[MAXP], qy[MAXP];
+    bool live[MAXP];
+    const int hi = lane_is_hi() ? 1 : 0;
+    for (int k = 0; k < ppp && k < MAXP; k++) {
+      const Affine<FpField<C>> P = g1[i * ppp + k];
+      const Fp<C>* q = reinterpret_cast<const Fp<C>*>(g2 + i * ppp + k);
+      const Fp<C> qxc = q[hi], qyc = q[2 + hi];
+      // Q is the point at infinity iff all four of its Fp components are zero (tested on the boundary form)
+      uint32_t zq = (fp_is_zero<C>(qxc) & fp_is_zero<C>(qyc)) ? 1u : 0u;
+      zq &= pair_xchg_u32(zq);
+      live[k] = !(affine_is_inf<FpField<C>>(P) | (zq != 0));
+      fp28_from_fp<C>(px[k], P.x);
+      fp28_from_fp<C>(py[k], P.y);
+      fp28_from_fp<C>(qx[k].v, qxc);
+      fp28_from_fp<C>(qy[k].v, qyc);
+    }
+    miller_loop_core<C, MAXP, E2, Fp28<C>>(f, px, py, qx, qy, live, ppp);
+  }
+  if (WHAT == 0) {
+    lp28_store_gt<C>(out, i, f);
+  } else {
+    final_exp<C>(r, f);
+    lp28_store_gt<C>(out, i, r);
   }
 }
 
@@ -133,6 +196,14 @@ __global__ void __launch_bounds__(256) k_fp_mul(const Fp<C>* __restrict__ a, con
   fp_mul<C>(r, x, y);
   for (int k = 1; k < repeat; k++) fp_mul<C>(r, r, y);
   out[i] = r;
+}
+
+// carry-free lane pairs: BLS12-381 unless MLHIP_PAIRING_SAT=1 (read per batch so a test can switch paths)
+template <class C>
+bool lp28_enabled() {
+  if (C::ID != 1) return false;
+  const char* e = getenv("MLHIP_PAIRING_SAT");
+  return !(e && e[0] == '1');
 }
 
 // The batched entry points run the lane-pair kernels (two lanes per pairing); the one-lane-per-pairing
@@ -157,6 +228,29 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
       default:
         k_pairing<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, (Fp12<C>*)d_out);
         break;
+    }
+  } else if (lp28_enabled<C>()) {
+    // BLS12-381: lane pairs in the carry-free form (MLHIP_PAIRING_SAT=1 selects the saturated lane-pair kernels below)
+    unsigned blocks = (unsigned)((2 * n + 63) / 64);
+    if constexpr (C::ID == 1) {
+      switch (what) {
+        case 0:
+          if (ppp == 1)
+            k_pairing_lp28<C, 0, 1><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr,
+                                                                      (Fp12<C>*)d_out);
+          else
+            k_pairing_lp28<C, 0, 4><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n,
+                                                                      nullptr, (Fp12<C>*)d_out);
+          break;
+        case 1:
+          k_pairing_lp28<C, 1, 1><<<dim3(blocks), dim3(64), 0, st>>>(nullptr, nullptr, 1, n, (const Fp12<C>*)d_in,
+                                                                    (Fp12<C>*)d_out);
+          break;
+        default:
+          k_pairing_lp28<C, 2, 1><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr,
+                                                                    (Fp12<C>*)d_out);
+          break;
+      }
     }
   } else {
     unsigned blocks = (unsigned)((2 * n + 63) / 64);

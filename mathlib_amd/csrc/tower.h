@@ -84,6 +84,15 @@ MLHIP_HD void fp2_select(Fp2<C>& r, bool c, const Fp2<C>& a, const Fp2<C>& b) {
   fp_select<C>(r.c1, c, a.c1, b.c1);
 }
 
+// Weight hooks of the carry-free element type (fp2_lanes28.h): fp2_norm carry-propagates a value whose lazily
+// accumulated additions would exceed a product's budget.  Saturated elements are always fully reduced: no-ops.
+template <class C>
+MLHIP_HD void fp2_norm(Fp2<C>&) {}
+template <class C>
+MLHIP_HD void fp2_reduce(Fp2<C>&) {}
+template <class C>
+MLHIP_HD int fp2_weight(const Fp2<C>&) { return 1; }
+
 // r = BETA * a  (BETA = -1 or -5)
 template <class C>
 MLHIP_HD void fp_mul_beta(Fp<C>& r, const Fp<C>& a) {
@@ -225,6 +234,24 @@ MLHIP_HD void fp6_dbl(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
   fp2_dbl<C>(r.c1, a.c1);
   fp2_dbl<C>(r.c2, a.c2);
 }
+template <class C, class E2>
+MLHIP_HD void fp6_norm(Fp6<C, E2>& r) {
+  fp2_norm<C>(r.c0);
+  fp2_norm<C>(r.c1);
+  fp2_norm<C>(r.c2);
+}
+template <class C, class E2>
+MLHIP_HD void fp6_reduce(Fp6<C, E2>& r) {
+  fp2_reduce<C>(r.c0);
+  fp2_reduce<C>(r.c1);
+  fp2_reduce<C>(r.c2);
+}
+// Weight discipline of the carry-free element (fp2_lanes28.h; the numbers in the comments below are weights): every
+// function from here on takes operands whose coefficients are normalized (weight 1) and leaves normalized results,
+// except the ones marked raw, whose results are combined by the caller before ONE carry propagation.  The Fp12-level
+// functions also bring the VALUE of every result coefficient back under p (fp6_reduce instead of fp6_norm), so that
+// each of them can be analysed by itself: operands of weight 1 and value bound 1 in, the same out.
+
 // r = v * a
 template <class C, class E2>
 MLHIP_HD void fp6_mul_v(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
@@ -265,6 +292,10 @@ MLHIP_HD void fp6_mul_i(Fp6<C, E2>& r, const Fp6<C, E2>& a, const Fp6<C, E2>& b)
   fp2_sub<C>(x2, x2, t0);
   fp2_sub<C>(x2, x2, t2);
   fp2_add<C>(x2, x2, t1);
+  // weights 7, 5, 4 (the operand sums have weight 2: their products are at the dual product's limit of 2 x 2 x 2)
+  fp2_norm<C>(x0);
+  fp2_norm<C>(x1);
+  fp2_norm<C>(x2);
   r.c0 = x0;
   r.c1 = x1;
   r.c2 = x2;
@@ -283,6 +314,7 @@ MLHIP_HD_NOINLINE void fp6_sqr(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
   fp2_dbl<C>(s1, s1);
   fp2_sub<C>(t, a.c0, a.c1);
   fp2_add<C>(t, t, a.c2);
+  fp2_norm<C>(t);  // 3 -> 1: the one-product square takes a normalized operand
   fp2_sqr<C>(s2, t);
   fp2_mul<C>(s3, a.c1, a.c2);
   fp2_dbl<C>(s3, s3);
@@ -296,9 +328,10 @@ MLHIP_HD_NOINLINE void fp6_sqr(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
   fp2_add<C>(t, t, s3);
   fp2_sub<C>(t, t, s0);
   fp2_sub<C>(r.c2, t, s4);
+  fp6_norm<C>(r);  // 5, 4, 7
 }
 
-// r = a * (b0 + b1 v)
+// r = a * (b0 + b1 v); raw: result weights 3, 3, 2
 template <class C, class E2>
 MLHIP_HD void fp6_mul_by_01(Fp6<C, E2>& r, const Fp6<C, E2>& a, const E2& b0, const E2& b1) {
   E2 t0, t1, t2, x0, x1, x2, s0, s1;
@@ -322,7 +355,7 @@ MLHIP_HD void fp6_mul_by_01(Fp6<C, E2>& r, const Fp6<C, E2>& a, const E2& b0, co
   r.c2 = x2;
 }
 
-// r = a * (b1 v)
+// r = a * (b1 v); raw: result weights 2, 1, 1
 template <class C, class E2>
 MLHIP_HD void fp6_mul_by_1(Fp6<C, E2>& r, const Fp6<C, E2>& a, const E2& b1) {
   E2 x0, x1, x2;
@@ -365,6 +398,7 @@ MLHIP_HD_NOINLINE void fp6_inv(Fp6<C, E2>& r, const Fp6<C, E2>& a) {
   fp2_mul_xi<C>(t, t);
   fp2_mul<C>(u, a.c0, c0);
   fp2_add<C>(t, t, u);
+  fp2_norm<C>(t);  // 5 -> 1
   fp2_inv<C>(t, t);
   fp2_mul<C>(r.c0, c0, t);
   fp2_mul<C>(r.c1, c1, t);
@@ -396,11 +430,15 @@ MLHIP_HD_NOINLINE void fp12_mul(Fp12<C, E2>& r, const Fp12<C, E2>& a, const Fp12
   fp6_mul_i<C>(t1, a.c1, b.c1);
   fp6_add<C>(s0, a.c0, a.c1);
   fp6_add<C>(s1, b.c0, b.c1);
+  fp6_norm<C>(s0);  // 2 -> 1
+  fp6_norm<C>(s1);
   fp6_mul_i<C>(x, s0, s1);
   fp6_sub<C>(x, x, t0);
   fp6_sub<C>(r.c1, x, t1);
+  fp6_reduce<C>(r.c1);  // 3
   fp6_mul_v<C>(t1, t1);
   fp6_add<C>(r.c0, t0, t1);
+  fp6_reduce<C>(r.c0);  // 3, 2, 2
 }
 
 template <class C, class E2>
@@ -409,13 +447,17 @@ MLHIP_HD_NOINLINE void fp12_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   Fp6<C, E2> ab, s0, s1, t;
   fp6_mul_i<C>(ab, a.c0, a.c1);
   fp6_add<C>(s0, a.c0, a.c1);
+  fp6_norm<C>(s0);  // 2 -> 1
   fp6_mul_v<C>(t, a.c1);
   fp6_add<C>(s1, a.c0, t);
+  fp6_norm<C>(s1);  // 3, 2, 2
   fp6_mul_i<C>(t, s0, s1);
   fp6_sub<C>(t, t, ab);
   fp6_mul_v<C>(s0, ab);
   fp6_sub<C>(r.c0, t, s0);
+  fp6_reduce<C>(r.c0);  // 4, 3, 3
   fp6_dbl<C>(r.c1, ab);
+  fp6_reduce<C>(r.c1);  // 2
 }
 
 template <class C, class E2>
@@ -425,6 +467,7 @@ MLHIP_HD_NOINLINE void fp12_inv(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   fp6_sqr<C>(t1, a.c1);
   fp6_mul_v<C>(t1, t1);
   fp6_sub<C>(t0, t0, t1);
+  fp6_reduce<C>(t0);  // 3, 2, 2 in weight; the values are sums of un-reduced Fp6 squares
   fp6_inv<C>(t0, t0);
   fp6_mul<C>(r.c0, a.c0, t0);
   fp6_mul<C>(t1, a.c1, t0);
@@ -466,18 +509,21 @@ MLHIP_HD_NOINLINE void fp12_cyclo_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   fp2_sqr<C>(t0, a.c1.c1);
   fp2_sqr<C>(t1, a.c0.c0);
   fp2_add<C>(s, a.c1.c1, a.c0.c0);
+  fp2_norm<C>(s);
   fp2_sqr<C>(t6, s);
   fp2_sub<C>(t6, t6, t0);
   fp2_sub<C>(t6, t6, t1);  // 2 a.c1.c1 a.c0.c0
   fp2_sqr<C>(t2, a.c0.c2);
   fp2_sqr<C>(t3, a.c1.c0);
   fp2_add<C>(s, a.c0.c2, a.c1.c0);
+  fp2_norm<C>(s);
   fp2_sqr<C>(t7, s);
   fp2_sub<C>(t7, t7, t2);
   fp2_sub<C>(t7, t7, t3);  // 2 a.c0.c2 a.c1.c0
   fp2_sqr<C>(t4, a.c1.c2);
   fp2_sqr<C>(t5, a.c0.c1);
   fp2_add<C>(s, a.c1.c2, a.c0.c1);
+  fp2_norm<C>(s);
   fp2_sqr<C>(t8, s);
   fp2_sub<C>(t8, t8, t4);
   fp2_sub<C>(t8, t8, t5);
@@ -488,6 +534,13 @@ MLHIP_HD_NOINLINE void fp12_cyclo_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   fp2_add<C>(t2, t2, t3);  // xi a.c0.c2^2 + a.c1.c0^2
   fp2_mul_xi<C>(t4, t4);
   fp2_add<C>(t4, t4, t5);  // xi a.c1.c2^2 + a.c0.c1^2
+  // weights 3 (t0, t2, t4, t6, t7) and 6 (t8): one propagation each before the 3 t -/+ 2 a combinations (5)
+  fp2_norm<C>(t0);
+  fp2_norm<C>(t2);
+  fp2_norm<C>(t4);
+  fp2_norm<C>(t6);
+  fp2_norm<C>(t7);
+  fp2_norm<C>(t8);
   Fp12<C, E2> o;
   // z = 3 t - 2 a (c0 part), 3 t + 2 a (c1 part)
   fp2_sub<C>(s, t0, a.c0.c0);
@@ -508,6 +561,14 @@ MLHIP_HD_NOINLINE void fp12_cyclo_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   fp2_add<C>(s, t7, a.c1.c2);
   fp2_dbl<C>(s, s);
   fp2_add<C>(o.c1.c2, s, t7);
+  // the +-2 a terms are linear in the input: reduce mod p (not only carry-propagate) so that a chain of squarings
+  // does not double the value each step
+  fp2_reduce<C>(o.c0.c0);
+  fp2_reduce<C>(o.c0.c1);
+  fp2_reduce<C>(o.c0.c2);
+  fp2_reduce<C>(o.c1.c0);
+  fp2_reduce<C>(o.c1.c1);
+  fp2_reduce<C>(o.c1.c2);
   r = o;
 }
 
@@ -516,15 +577,19 @@ template <class C, class E2>
 MLHIP_HD_NOINLINE void fp12_mul_by_014(Fp12<C, E2>& f, const E2& c0, const E2& c1, const E2& c4) {
   Fp6<C, E2> t0, t1, s, x;
   E2 d;
-  fp6_mul_by_01<C>(t0, f.c0, c0, c1);
-  fp6_mul_by_1<C>(t1, f.c1, c4);
+  fp6_mul_by_01<C>(t0, f.c0, c0, c1);  // raw: 3, 3, 2
+  fp6_mul_by_1<C>(t1, f.c1, c4);       // raw: 2, 1, 1
   fp6_add<C>(s, f.c0, f.c1);
+  fp6_norm<C>(s);  // 2 -> 1
   fp2_add<C>(d, c1, c4);
-  fp6_mul_by_01<C>(x, s, c0, d);
+  fp2_norm<C>(d);
+  fp6_mul_by_01<C>(x, s, c0, d);  // raw: 3, 3, 2
   fp6_sub<C>(x, x, t0);
   fp6_sub<C>(f.c1, x, t1);
+  fp6_reduce<C>(f.c1);  // 8, 7, 5
   fp6_mul_v<C>(t1, t1);
   fp6_add<C>(f.c0, t0, t1);
+  fp6_reduce<C>(f.c0);  // 5, 5, 3
 }
 
 // f *= (c0 + c3 w + c4 v w)   -- line of a D-twist curve (BN254, BLS12-377)
@@ -532,15 +597,19 @@ template <class C, class E2>
 MLHIP_HD_NOINLINE void fp12_mul_by_034(Fp12<C, E2>& f, const E2& c0, const E2& c3, const E2& c4) {
   Fp6<C, E2> t0, t1, s, x;
   E2 d;
-  fp6_mul_by_0<C>(t0, f.c0, c0);
-  fp6_mul_by_01<C>(t1, f.c1, c3, c4);
+  fp6_mul_by_0<C>(t0, f.c0, c0);       // 1, 1, 1
+  fp6_mul_by_01<C>(t1, f.c1, c3, c4);  // raw: 3, 3, 2
   fp6_add<C>(s, f.c0, f.c1);
+  fp6_norm<C>(s);
   fp2_add<C>(d, c0, c3);
-  fp6_mul_by_01<C>(x, s, d, c4);
+  fp2_norm<C>(d);
+  fp6_mul_by_01<C>(x, s, d, c4);  // raw: 3, 3, 2
   fp6_sub<C>(x, x, t0);
   fp6_sub<C>(f.c1, x, t1);
+  fp6_reduce<C>(f.c1);  // 7, 7, 5
   fp6_mul_v<C>(t1, t1);
   fp6_add<C>(f.c0, t0, t1);
+  fp6_reduce<C>(f.c0);  // 5, 4, 4
 }
 
 }  // namespace mlhip

@@ -12,6 +12,7 @@
 #include "../../mathlib_amd/csrc/ec_quad.h"
 #include "../../mathlib_amd/csrc/ec28_lp.h"
 #include "../../mathlib_amd/csrc/modinv.h"
+#include "../../mathlib_amd/csrc/fp2_lanes28.h"
 
 using namespace mlhip;
 
@@ -325,6 +326,107 @@ struct Ops {
   }
 };
 
+// ---- the carry-free lane-pair element (fp2_lanes28.h) through its host model Fp2H28: same tower / pairing templates
+// as the kernels, every operation checking its weight budget (aborts with a message when one is exceeded)
+struct Lp28 {
+  typedef Bls381 C;
+  typedef Fp2H28<C> E;
+  typedef Fp12<C, E> F12h;
+  static void to_h(E& r, const Fp2<C>& a) {
+    fp28_from_fp<C>(r.c[0], a.c0);
+    fp28_from_fp<C>(r.c[1], a.c1);
+    r.wt = 1;
+  }
+  static void from_h(Fp2<C>& r, const E& a) {
+    fp28_to_fp<C>(r.c0, a.c[0]);
+    fp28_to_fp<C>(r.c1, a.c[1]);
+  }
+  static void to_h12(F12h& r, const Fp12<C>& a) {
+    const Fp2<C>* s = &a.c0.c0;
+    E* d = &r.c0.c0;
+    for (int i = 0; i < 6; i++) to_h(d[i], s[i]);
+  }
+  static void from_h12(Fp12<C>& r, const F12h& a) {
+    Fp2<C>* d = &r.c0.c0;
+    const E* s = &a.c0.c0;
+    for (int i = 0; i < 6; i++) from_h(d[i], s[i]);
+  }
+  static int max_w(const F12h& a) {
+    const E* s = &a.c0.c0;
+    int w = 0;
+    for (int i = 0; i < 6; i++) w = s[i].wt > w ? s[i].wt : w;
+    return w;
+  }
+  // returns the largest weight left in the result's coefficients (the formulas promise 1)
+  static int fp12_op(int op, const void* a, const void* b, void* out) {
+    Fp12<C> x, y, r;
+    memcpy(&x, a, sizeof(x));
+    if (b) memcpy(&y, b, sizeof(y));
+    F12h hx, hy, hr;
+    to_h12(hx, x);
+    if (b && op != 12) to_h12(hy, y);
+    switch (op) {
+      case 0: fp12_mul<C>(hr, hx, hy); break;
+      case 1: fp12_sqr<C>(hr, hx); break;
+      case 2: fp12_inv<C>(hr, hx); break;
+      case 3: fp12_frob<C, 1>(hr, hx); break;
+      case 4: fp12_frob<C, 2>(hr, hx); break;
+      case 5: fp12_frob<C, 3>(hr, hx); break;
+      case 6: fp12_cyclo_sqr<C>(hr, hx); break;
+      case 7: fp12_conj<C>(hr, hx); break;
+      case 8: fp12_expt<C>(hr, hx); break;
+      case 9: final_exp<C>(hr, hx); break;
+      case 10: hr = hx; fp12_mul<C>(hr, hr, hy); break;  // in place
+      case 11: hr = hx; fp12_sqr<C>(hr, hr); break;
+      case 12: {  // one compressed cyclotomic squaring, decompressed with its own inversion
+        CycloComp<C, E> k;
+        k.b0 = hx.c1.c0;
+        k.b1 = hx.c0.c2;
+        k.d0 = hx.c0.c1;
+        k.d1 = hx.c1.c2;
+        cyclo_sqr_compressed<C>(k);
+        if (b) for (int i = 1; i < ((const uint8_t*)b)[0]; i++) cyclo_sqr_compressed<C>(k);
+        E num, den, inv, a1;
+        cyclo_a1_fraction<C>(num, den, k);
+        fp2_inv<C>(inv, den);
+        fp2_mul<C>(a1, num, inv);
+        cyclo_decompress<C>(hr, k, a1);
+        break;
+      }
+      default: return -1;
+    }
+    from_h12(r, hr);
+    memcpy(out, &r, sizeof(r));
+    return max_w(hr);
+  }
+  static int pairing(const void* g1s, const void* g2s, int n_pairs, int with_fexp, void* out) {
+    typedef Affine<FpField<C>> A1;
+    typedef Affine<Fp2Field<C>> A2;
+    const A1* P = (const A1*)g1s;
+    const A2* Q = (const A2*)g2s;
+    Fp28<C> px[4], py[4];
+    E qx[4], qy[4];
+    bool live[4];
+    for (int k = 0; k < n_pairs && k < 4; k++) {
+      live[k] = !(affine_is_inf<FpField<C>>(P[k]) | affine_is_inf<Fp2Field<C>>(Q[k]));
+      fp28_from_fp<C>(px[k], P[k].x);
+      fp28_from_fp<C>(py[k], P[k].y);
+      to_h(qx[k], Q[k].x);
+      to_h(qy[k], Q[k].y);
+    }
+    F12h f, r;
+    miller_loop_core<C, 4, E, Fp28<C>>(f, px, py, qx, qy, live, n_pairs);
+    if (with_fexp) {
+      final_exp<C>(r, f);
+      f = r;
+    }
+    Fp12<C> o;
+    from_h12(o, f);
+    memcpy(out, &o, sizeof(o));
+    return max_w(f);
+  }
+};
+
 #define DISPATCH(curve, call)                 \
   switch (curve) {                            \
     case 0: return Ops<Bn254>::call;          \
@@ -351,5 +453,7 @@ int hm_quad_chain(int curve, const void* pts, const void* zs, int n, void* out) 
 int hm_madd28_lp_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_lp_chain(pts, neg, n, out)) }
 int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g2dec(w, compressed, subgroup, out)) }
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }
+int hm_lp28_fp12_op(int op, const void* a, const void* b, void* out) { return Lp28::fp12_op(op, a, b, out); }
+int hm_lp28_pairing(const void* g1s, const void* g2s, int n_pairs, int with_fexp, void* out) { return Lp28::pairing(g1s, g2s, n_pairs, with_fexp, out); }
 int hm_miller(int curve, const void* g1s, const void* g2s, int n_pairs, void* out) { DISPATCH(curve, miller(g1s, g2s, n_pairs, out)) }
 }
