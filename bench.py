@@ -234,12 +234,12 @@ def main() -> None:
         units_per_step = npair * world
         achieved = PAIRING_BYTES_PER_UNIT * npair / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
         roofline = {
-            "bound": "hbm", "kernel": "k_pairing_lp<Bls381,2,1> (fused Miller loop + final exponentiation, one pairing per lane pair)",
+            "bound": "hbm", "kernel": "k_pairing_lp28<Bls381,2,1> (fused Miller loop + final exponentiation, one pairing per lane pair, carry-free 28-bit limbs)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "avg_kernel_ms": kernel_ms,
             "note": "864 algorithmic bytes per pairing; the kernel is integer-issue bound (DESIGN.md section 4)",
         }
-        pm = _pmc("k_pairing_lp")
+        pm = _pmc("k_pairing_lp28<Bls381, 2")
         if pm:
             roofline["traffic"] = pm[0]
             roofline["traffic_note"] = pm[1]

@@ -455,5 +455,13 @@ int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }
 int hm_lp28_fp12_op(int op, const void* a, const void* b, void* out) { return Lp28::fp12_op(op, a, b, out); }
 int hm_lp28_pairing(const void* g1s, const void* g2s, int n_pairs, int with_fexp, void* out) { return Lp28::pairing(g1s, g2s, n_pairs, with_fexp, out); }
+int hm_fp28_reduce(int curve, const int32_t* in, int32_t* out) {
+  if (curve != 1) return -2;
+  Fp28<Bls381> a, r;
+  memcpy(&a, in, sizeof(a));
+  fp28_reduce<Bls381>(r, a);
+  memcpy(out, &r, sizeof(r));
+  return 0;
+}
 int hm_miller(int curve, const void* g1s, const void* g2s, int n_pairs, void* out) { DISPATCH(curve, miller(g1s, g2s, n_pairs, out)) }
 }

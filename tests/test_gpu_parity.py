@@ -544,6 +544,42 @@ def test_pairing_one_lane_kernels_agree(lib, mlhip, curve, monkeypatch):
     assert out.raw == exp
 
 
+def test_pairing_saturated_lane_pair_kernels_agree(lib, mlhip, monkeypatch):
+    """BLS12-381 runs the carry-free lane-pair kernels (k_pairing_lp28) by default; MLHIP_PAIRING_SAT=1 selects the
+    saturated lane-pair kernels of round 1 (what BN254 and BLS12-377 run): Miller loop, final exponentiation, fused
+    pairing and Pairing2 must give the same bytes on both, on the goldens and on a random batch with infinities."""
+    from oracle import cref
+
+    g = load_golden("BLS12-381")
+    cid = g["curve_id"]
+    _, g1b, g2b, gtb = mlhip.sizes(cid)
+    n = 130  # ragged: the last wave is partly idle
+    p1 = bytearray(cref.gen_points(cid, 1, 808, 17, n))
+    p2 = bytearray(cref.gen_points(cid, 2, 909, 19, n))
+    p1[5 * g1b : 6 * g1b] = bytes(g1b)
+    p2[9 * g2b : 10 * g2b] = bytes(g2b)
+    p1, p2 = bytes(p1), bytes(p2)
+    want = cref.pairing_batch(cid, p1, p2, n, 8)
+    res = {}
+    for sat in ("0", "1"):
+        monkeypatch.setenv("MLHIP_PAIRING_SAT", sat)
+        out = ctypes.create_string_buffer(gtb * n)
+        mlhip.check(lib.mlhip_pairing_batch(cid, p1, p2, n, out))
+        assert out.raw == want, sat
+        ml = ctypes.create_string_buffer(gtb * (n // 2))
+        mlhip.check(lib.mlhip_miller_loop(cid, p1, p2, 2, n // 2, ml))
+        fe = ctypes.create_string_buffer(gtb * (n // 2))
+        mlhip.check(lib.mlhip_final_exp(cid, ml, n // 2, fe))
+        res[sat] = fe.raw
+        cases = g["pairing"]
+        q1 = b"".join(_h(c["g1"]) for c in cases)
+        q2 = b"".join(_h(c["g2"]) for c in cases)
+        out = ctypes.create_string_buffer(gtb * len(cases))
+        mlhip.check(lib.mlhip_pairing_batch(cid, q1, q2, len(cases), out))
+        assert out.raw == b"".join(_h(c["fexp"]) for c in cases)
+    assert res["0"] == res["1"] == cref.final_exp(cid, cref.miller_loop(cid, p1, p2, 2, n // 2, 8), n // 2, 8)
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_msm_differential_sweep(lib, mlhip, curve):
     """Seeded sweep over (n, window, scalar width, duplicates / negated duplicates / infinities) against the C

@@ -7,6 +7,7 @@ import random
 
 import pytest
 
+from conftest import load_golden
 from oracle import pyref as R
 
 CURVES = ["BN254", "BLS12-381", "BLS12-377"]
@@ -545,3 +546,94 @@ def test_g2_subgroup_test_by_psi(hostmath, name):
             got[mode] = st == 0
         assert got[1] == got[2] == want, (name, Q)
     assert any(not w_ for _, w_ in [(q_, R.g2_mul_unreduced(cp, q_, cp.r) is None) for q_ in bad])
+
+
+# ---- carry-free lane-pair element of the BLS12-381 pairing kernels (fp2_lanes28.h) through its host model ---------
+def test_lp28_tower_ops_and_weight_budget(hostmath):
+    """Every Fp12-level operation of the pairing on the carry-free element: the host model (Fp2H28: both lanes of a
+    pair + the weight and value bound of every value) runs the SAME tower templates as the kernels, aborts if any
+    product / square / stored value exceeds its budget, and returns the largest weight left in the result (the
+    formulas promise normalized results).  Values against the oracle."""
+    cp = R.CURVES["BLS12-381"]
+    T = R.tower(cp)
+    L = hostmath
+    d = R.Drbg("hm/lp28/ops")
+    rf = lambda: tuple((d.below(cp.p), d.below(cp.p)) for _ in range(6))  # noqa: E731
+    gb = lambda f: R.gt_to_mont_bytes(cp, f)  # noqa: E731
+    out = ctypes.create_string_buffer(576)
+    for _ in range(2):
+        f, g = rf(), rf()
+        c = T.f12_mul(T.f12_conj(f), T.f12_inv(f))
+        c = T.f12_mul(T.f12_frob(c, 2), c)  # cyclotomic subgroup element
+        cases = [(0, f, T.f12_mul(f, g)), (1, f, T.f12_sqr(f)), (10, f, T.f12_mul(f, g)), (11, f, T.f12_sqr(f)), (2, f, T.f12_inv(f)),
+                 (3, f, T.f12_frob(f, 1)), (4, f, T.f12_frob(f, 2)), (5, f, T.f12_frob(f, 3)), (7, f, T.f12_conj(f)),
+                 (6, c, T.f12_sqr(c)), (8, c, T.f12_pow(c, cp.x)), (9, f, R.final_exp(cp, f))]
+        for op, a, exp in cases:
+            assert L.hm_lp28_fp12_op(op, gb(a), gb(g), out) == 1, op
+            assert R.gt_from_mont_bytes(cp, out.raw) == exp, op
+    # chains of compressed cyclotomic squarings: the linear terms must not let the value grow (fp2_reduce)
+    for n in (1, 2, 17, 63):
+        assert L.hm_lp28_fp12_op(12, gb(c), bytes([n]) + bytes(575), out) == 1
+        exp = c
+        for _ in range(n):
+            exp = T.f12_sqr(exp)
+        assert R.gt_from_mont_bytes(cp, out.raw) == exp, n
+    # edge values: 1, and an element with B = C = 0 in the compressed form
+    one = tuple([(1, 0)] + [(0, 0)] * 5)
+    assert L.hm_lp28_fp12_op(8, gb(one), None, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
+    assert L.hm_lp28_fp12_op(9, gb(one), None, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
+
+
+def test_lp28_pairing_matches_oracle(hostmath):
+    """Whole pairings through the host model: Miller loop + final exponentiation (one pair, two pairs sharing the
+    squarings, a pair with a point at infinity) against oracle/pyref.py."""
+    cp = R.CURVES["BLS12-381"]
+    L = hostmath
+    d = R.Drbg("hm/lp28/pairing")
+    out = ctypes.create_string_buffer(576)
+    P, Q = R.random_g1(cp, d), R.random_g2(cp, d)
+    P2, Q2 = R.random_g1(cp, d), R.random_g2(cp, d)
+    g1 = R.g1_to_mont_bytes(cp, P) + R.g1_to_mont_bytes(cp, P2)
+    g2 = R.g2_to_mont_bytes(cp, Q) + R.g2_to_mont_bytes(cp, Q2)
+    assert L.hm_lp28_pairing(g1, g2, 1, 1, out) == 1
+    assert R.gt_from_mont_bytes(cp, out.raw) == R.pairing(cp, P, Q)
+    assert L.hm_lp28_pairing(g1, g2, 2, 1, out) == 1
+    assert R.gt_from_mont_bytes(cp, out.raw) == R.final_exp(cp, R.miller_loop(cp, [(P, Q), (P2, Q2)]))
+    # generator pairing = the golden GenGt; infinity on either side gives 1
+    g = load_golden("BLS12-381")
+    c0 = g["pairing"][0]
+    assert L.hm_lp28_pairing(bytes.fromhex(c0["g1"]), bytes.fromhex(c0["g2"]), 1, 1, out) == 1
+    assert out.raw.hex() == c0["fexp"]
+    one = tuple([(1, 0)] + [(0, 0)] * 5)
+    assert L.hm_lp28_pairing(bytes(96), R.g2_to_mont_bytes(cp, Q), 1, 1, out) == 1
+    assert R.gt_from_mont_bytes(cp, out.raw) == one
+    assert L.hm_lp28_pairing(R.g1_to_mont_bytes(cp, P) + bytes(96), R.g2_to_mont_bytes(cp, Q) + R.g2_to_mont_bytes(cp, Q2), 2, 1, out) == 1
+    assert R.gt_from_mont_bytes(cp, out.raw) == R.pairing(cp, P, Q)
+
+
+def test_fp28_reduce_range(hostmath):
+    """fp28_reduce: value -> value - round(value / p) p from a float estimate of the top limb; the result must be the
+    same residue with |result| < 0.6 p for every storable input (weight <= 8, |value| up to ~600 p)."""
+    cp = R.CURVES["BLS12-381"]
+    L = hostmath
+    d = R.Drbg("hm/reduce")
+    p = cp.p
+    out = (ctypes.c_int32 * 14)()
+    for trial in range(400):
+        scale = [1, 2, 7, 50, 300, 600][trial % 6]
+        v = (d.below(2 * scale * p) - scale * p)
+        # spread over 14 signed limbs of up to 3 extra bits
+        limbs, rest = [], v
+        for i in range(13):
+            l = rest & ((1 << 28) - 1)
+            if trial % 3 == 1:
+                l += (d.below(15) - 7) << 28  # un-normalized: weight up to 8
+            limbs.append(l)
+            rest = (rest - l) >> 28
+        limbs.append(rest)
+        assert sum(l << (28 * i) for i, l in enumerate(limbs)) == v
+        arr = (ctypes.c_int32 * 14)(*limbs)
+        assert L.hm_fp28_reduce(1, arr, out) == 0
+        got = sum(int(out[i]) << (28 * i) for i in range(14))
+        assert (got - v) % p == 0 and abs(got) < 0.6 * p, (trial, v / p, got / p)
+        assert all(0 <= int(out[i]) < (1 << 28) for i in range(13))
