@@ -120,12 +120,17 @@ int ilog2(size_t v) {
   return l;
 }
 
-// measured optimum on one MI355X (tools/sweep_window.py, profiles/r01_sweep_window.txt): the fixed cost per window
-// (sort passes, launch latencies) outweighs the bucket count early, so c = 16 wins from n = 2^14 upwards
-int pick_window(size_t n) {
+// measured optimum on one MI355X (tools/sweep_window.py, profiles/r02_sweep_window.txt).  With the balanced window
+// layout (msm_body.h: msm_win_layout) every width splits the scalar evenly, so the mid sizes no longer have to jump
+// from 8 to 16: 13-14 bits win from 2^11 to 2^15 points (2^14: 0.81 ms instead of 1.11), 16 from 2^16 on.  For large n on
+// the curves whose 254 / 255 scalar bits fit 15 windows of 17 bits (BLS12-377, BN254) one window less is one addition
+// per scalar less (BLS12-377 2^22: 12.5 ms instead of 13.5); BLS12-381's 256 bits need 16 windows either way.
+int pick_window(size_t n, int fr_bits) {
   if (n <= 128) return 4;
-  if (n <= 2048) return 8;
-  if (n <= 8192) return 12;
+  if (n <= 1024) return 8;
+  if (n <= 4096) return 13;
+  if (n <= 32768) return 14;
+  if (n >= ((size_t)1 << 22) && msm_num_windows(fr_bits, 17) < msm_num_windows(fr_bits, 16)) return 17;
   return 16;
 }
 
@@ -491,7 +496,7 @@ int msm_host_buffers(int curve, int group, const void* points, const void* scala
     const std::vector<int> devs = spread_devices(n, false);
     if (!devs.empty()) return msm_multi(devs, curve, group, points, scalars, mont, n, window_c, out, ptsz);
   }
-  if (window_c == 0) window_c = pick_window(n);
+  if (window_c == 0) window_c = pick_window(n, sz.fr_bits);
   int rc = ensure_device();
   if (rc) return rc;
   PoolEntry* e = pool_acquire(curve, group, window_c, n, ptsz, rc);
@@ -617,7 +622,7 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
   if (group != MLHIP_GROUP_G1 && group != MLHIP_GROUP_G2)
     return mlhip_rt::fail(MLHIP_EINVAL, "group must be 1 (G1) or 2 (G2)");
   if (max_n == 0 || max_n > ((size_t)1 << 27)) return mlhip_rt::fail(MLHIP_EINVAL, "max_n out of range (1 .. 2^27)");
-  if (window_c == 0) window_c = pick_window(max_n);
+  if (window_c == 0) window_c = pick_window(max_n, sz.fr_bits);
   if (window_c < 4 || window_c > 20) return mlhip_rt::fail(MLHIP_EINVAL, "window_c out of range (4 .. 20)");
   // sorted-entry offsets, cursors and scans are 32-bit: W * max_n entries must be addressable
   if ((size_t)msm_num_windows(sz.fr_bits, window_c) * max_n > 0xFFFFFFFFull)

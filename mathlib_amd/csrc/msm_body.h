@@ -61,36 +61,59 @@ MLHIP_HD void fr_canonical(uint32_t (&s)[8], const uint32_t* in, bool mont) {
 
 MLHIP_HD int msm_num_windows(int fr_bits, int c) { return (fr_bits + 1 + c - 1) / c; }
 
-// Signed window digits: value v_w = bits[wc, (w+1)c) + carry; v_w > 2^(c-1) => v_w -= 2^c, carry 1.
-// Encoded as 0 (skip) or (magnitude << 1) | sign with magnitude in [1, 2^(c-1)] -> bucket magnitude-1.
+// Window layout.  The FR_BITS + 1 bits of a scalar (the extra bit absorbs the last carry) are spread over
+// W = ceil((FR_BITS + 1) / c) windows as evenly as possible: the first `rem` windows are base + 1 bits wide, the others
+// base bits, base = (FR_BITS + 1) / W.  For 256 = 16 x 16 bits (BLS12-381 at c = 16) every window is c bits; where c
+// does not divide -- BLS12-377 and BN254 at c = 16 (254 / 255 bits), every curve at other widths -- this replaces a full
+// set of c-bit windows plus a sparse top window, whose few buckets were several times longer than all the others (one
+// thread per bucket: the accumulation waited for them), by windows that differ by one bit.
+struct WinLayout {
+  int W, base, rem;
+};
+MLHIP_HD WinLayout msm_win_layout(int fr_bits, int c) {
+  WinLayout l;
+  l.W = msm_num_windows(fr_bits, c);
+  l.base = (fr_bits + 1) / l.W;
+  l.rem = (fr_bits + 1) % l.W;
+  return l;
+}
+MLHIP_HD int msm_win_off(int wbase, int wrem, int w) { return w * wbase + (w < wrem ? w : wrem); }
+MLHIP_HD int msm_win_bits(int wbase, int wrem, int w) { return wbase + (w < wrem ? 1 : 0); }
+
+// Signed digit of window w: v = bits [off, off + width) + carry; v > 2^(width-1) => v -= 2^width, carry 1.
+// Returns the magnitude (0 = skip; bucket = magnitude - 1), sets neg and the carry into the next window.
+MLHIP_HD uint32_t msm_window_digit(const uint32_t (&s)[8], int off, int width, uint32_t& carry, uint32_t& neg) {
+  uint32_t v = 0;
+  if (off < 256) {
+    const int word = off >> 5, sh = off & 31;
+    uint64_t two = s[word];
+    if (word + 1 < 8) two |= (uint64_t)s[word + 1] << 32;
+    v = (uint32_t)((two >> sh) & ((1u << width) - 1));
+  }
+  v += carry;
+  const uint32_t half = 1u << (width - 1);
+  if (v > half) {
+    // v == 2^width (all-ones window plus carry) is digit 0 with a carry, not "minus zero"
+    carry = 1;
+    neg = 1;
+    return (1u << width) - v;
+  }
+  carry = 0;
+  neg = 0;
+  return v;
+}
+
+// Encoded as 0 (skip) or (magnitude << 1) | sign with magnitude in [1, 2^(width-1)] -> bucket magnitude-1.
 template <class C>
 MLHIP_HD void msm_digits_body(size_t i, size_t n, const uint32_t* scalars, bool mont, int c, int W,
                               uint32_t* digits /* [W][n] */) {
   uint32_t s[8];
   fr_canonical<C>(s, scalars + 8 * i, mont);
-  uint32_t carry = 0;
-  const uint32_t half = 1u << (c - 1);
+  const WinLayout l = msm_win_layout(C::FR_BITS, c);
+  uint32_t carry = 0, neg = 0;
   for (int w = 0; w < W; w++) {
-    int bit = w * c;
-    uint32_t v = 0;
-    if (bit < 256) {
-      int word = bit >> 5, sh = bit & 31;
-      uint64_t two = s[word];
-      if (word + 1 < 8) two |= (uint64_t)s[word + 1] << 32;
-      v = (uint32_t)((two >> sh) & ((1u << c) - 1));
-    }
-    v += carry;
-    uint32_t enc;
-    if (v > half) {
-      // v == 2^c (all-ones window plus carry) is digit 0 with a carry, not "minus zero"
-      uint32_t mag = (1u << c) - v;
-      enc = mag ? ((mag << 1) | 1u) : 0u;
-      carry = 1;
-    } else {
-      enc = v << 1;  // 0 when v == 0
-      carry = 0;
-    }
-    digits[(size_t)w * n + i] = enc;
+    const uint32_t mag = msm_window_digit(s, msm_win_off(l.base, l.rem, w), msm_win_bits(l.base, l.rem, w), carry, neg);
+    digits[(size_t)w * n + i] = mag ? ((mag << 1) | neg) : 0u;
   }
 }
 

@@ -40,7 +40,7 @@ int plan_alloc(mlhip_msm_plan* p) {
   HIPCHK(hipMalloc(&p->d_coarse_off, ((size_t)p->sort_nb + 1) * 4));
   HIPCHK(hipMalloc(&p->d_binprefix, ((size_t)p->sort_nb + 2) * 4));
   if (p->sort_nb) {
-    static_assert(SORT_TILE < 65536, "a block puts at most one entry per scalar into a coarse bin: the count fits 16 bits");
+    static_assert(SORT_TILE_MAX < 65536, "a block puts at most one entry per scalar into a coarse bin: the count fits 16 bits");
     const size_t blocks = (p->max_n + SORT_TILE - 1) / SORT_TILE;
     HIPCHK(hipMalloc(&p->d_blockhist, blocks * p->sort_nb * sizeof(uint16_t)));
   }
@@ -105,14 +105,18 @@ int plan_alloc(mlhip_msm_plan* p) {
 template <class F>
 void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
   const XYZZ<F>* o = reinterpret_cast<const XYZZ<F>*>(p->h_out);
-  const int npos = p->W * p->c;
+  // window w starts at bit off(w) (msm_win_layout: widths differ by at most one bit); its masked sums carry the weights
+  // 2^(lgL + k) relative to that, which may reach into the next window's positions -- slots accumulate
+  const WinLayout wl = msm_win_layout(F::Curve::FR_BITS, p->c);
+  const int npos = msm_win_off(wl.base, wl.rem, p->W - 1) + p->c + 1;
   std::vector<XYZZ<F>> slot(npos);
   for (int i = 0; i < npos; i++) xyzz_set_inf<F>(slot[i]);
   for (int w = 0; w < p->W; w++) {
+    const int off = msm_win_off(wl.base, wl.rem, w);
     XYZZ<F> s = o[w * p->nsel + 0];
     for (int h = 1; h < 4; h++) xyzz_add<F>(s, o[w * p->nsel + h]);
-    slot[w * p->c] = s;
-    for (int k = 0; k < p->nb; k++) slot[w * p->c + p->lgL + k] = o[w * p->nsel + 4 + k];
+    xyzz_add<F>(slot[off], s);
+    for (int k = 0; k < p->nb; k++) xyzz_add<F>(slot[off + p->lgL + k], o[w * p->nsel + 4 + k]);
   }
   xyzz_set_inf<F>(total);
   bool started = false;
@@ -153,15 +157,16 @@ int launch_sort(mlhip_msm_plan* p, const void* d_scalars, int mont, size_t n, hi
   const size_t nbuckets = (size_t)p->W * p->M;
   if (p->sort_low > 0) {
     // two-level LDS counting sort (no per-key global atomics)
-    const unsigned blocks = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+    const int tile = sort_tile_for(n);
+    const unsigned blocks = (unsigned)((n + tile - 1) / tile);
     const uint32_t NB = p->sort_nb;
     k_coarse_hist<C><<<dim3(blocks), dim3(256), NB * 4, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low, NB,
-                                                            p->d_coarse_count, p->d_blockhist);
+                                                            p->d_coarse_count, p->d_blockhist, tile);
     if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
     launch_scan(p->d_coarse_count, p->d_coarse_off, p->d_tilesums, NB, st);
     k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low,
                                                                p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
-                                                               p->d_digits, p->d_blockhist);
+                                                               p->d_digits, p->d_blockhist, tile);
     // bins more than 8x the mean (and at least 32768 entries) are sorted by many workgroups
     const uint32_t big_bin = (uint32_t)std::min<size_t>(std::max<size_t>(32768, 8 * ((size_t)p->W * n / NB)), 0x7fffffffu);
     k_fine_sort<<<dim3(NB), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->c, p->sort_low,

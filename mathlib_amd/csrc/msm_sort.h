@@ -102,46 +102,43 @@ static inline void launch_scan(const uint32_t* in, uint32_t* out, uint32_t* tile
 //                     (fine bucket bits | sign | point index)
 //   k_fine_sort       one block per coarse bin: LDS histogram of the 2^LOW fine buckets -> counts/offsets
 //                     of the real buckets (coalesced), then LDS-ranked placement of the point indices
-#ifndef MLHIP_SORT_TILE
-#define MLHIP_SORT_TILE 1024
-#endif
-constexpr int SORT_TILE = MLHIP_SORT_TILE;  // scalars per block in the coarse passes
+// Scalars per block in the coarse passes.  A block writes tile * W / NB entries into each coarse bin (8 at tile = 1024,
+// c = 16): short runs, so the scatter's write traffic is several times the bytes of the entries
+// (profiles/r01_pmc_traffic.json: 362 MB for 64 MB).  Large inputs have blocks to spare and take longer tiles
+// (sort_tile_for); the per-block histogram handed from k_coarse_hist to k_coarse_scatter is 16-bit, so tile < 65536.
+constexpr int SORT_TILE = 1024;      // smallest tile: sizes the per-block histogram buffer
+constexpr int SORT_TILE_MAX = 8192;
+static inline int sort_tile_for(size_t n) {
+  if (const char* e = getenv("MLHIP_SORT_TILE")) {
+    const int v = atoi(e);
+    if (v == 1024 || v == 2048 || v == 4096 || v == 8192) return v;
+  }
+  // keep at least ~4 blocks per CU (256 CUs) in flight
+  if (n >= ((size_t)1 << 23)) return 8192;
+  if (n >= ((size_t)1 << 22)) return 4096;
+  if (n >= ((size_t)1 << 21)) return 2048;
+  return 1024;
+}
 
 template <class C>
 __global__ void __launch_bounds__(256) k_coarse_hist(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
                                                      int low, uint32_t NB, uint32_t* __restrict__ coarse_count,
-                                                     uint16_t* __restrict__ blockhist) {
+                                                     uint16_t* __restrict__ blockhist, int tile) {
   extern __shared__ uint32_t lds_u32[];
   uint32_t* hist = lds_u32;
   for (uint32_t b = threadIdx.x; b < NB; b += 256) hist[b] = 0;
   __syncthreads();
   const uint32_t cb_shift = (uint32_t)(c - 1 - low);  // coarse bins per window = 1 << cb_shift
-  for (int k = 0; k < SORT_TILE / 256; k++) {
-    size_t i = (size_t)blockIdx.x * SORT_TILE + (size_t)k * 256 + threadIdx.x;
+  const WinLayout wl = msm_win_layout(C::FR_BITS, c);
+  for (int k = 0; k < tile / 256; k++) {
+    size_t i = (size_t)blockIdx.x * tile + (size_t)k * 256 + threadIdx.x;
     if (i >= n) break;
     // recompute the digit chain window by window (no per-lane array: keeps this in registers)
     uint32_t s[8];
     fr_canonical<C>(s, scalars + 8 * i, mont != 0);
-    uint32_t carry = 0;
-    const uint32_t half = 1u << (c - 1);
+    uint32_t carry = 0, neg = 0;
     for (int w = 0; w < W; w++) {
-      int bit = w * c;
-      uint32_t v = 0;
-      if (bit < 256) {
-        int word = bit >> 5, sh = bit & 31;
-        uint64_t two = s[word];
-        if (word + 1 < 8) two |= (uint64_t)s[word + 1] << 32;
-        v = (uint32_t)((two >> sh) & ((1u << c) - 1));
-      }
-      v += carry;
-      uint32_t mag;
-      if (v > half) {
-        mag = (1u << c) - v;
-        carry = 1;
-      } else {
-        mag = v;
-        carry = 0;
-      }
+      const uint32_t mag = msm_window_digit(s, msm_win_off(wl.base, wl.rem, w), msm_win_bits(wl.base, wl.rem, w), carry, neg);
       if (mag) atomicAdd(&hist[((uint32_t)w << cb_shift) + ((mag - 1) >> low)], 1u);
     }
   }
@@ -160,12 +157,12 @@ __global__ void __launch_bounds__(256) k_coarse_scatter(const uint32_t* __restri
                                                         int low, int idx_bits, uint32_t NB,
                                                         const uint32_t* __restrict__ coarse_off,
                                                         uint32_t* __restrict__ coarse_cursor, uint32_t* __restrict__ tmp,
-                                                        const uint16_t* __restrict__ blockhist) {
+                                                        const uint16_t* __restrict__ blockhist, int tile) {
   extern __shared__ uint32_t lds_u32[];
   uint32_t* hist = lds_u32;       // per-block count, then running rank
   uint32_t* base = lds_u32 + NB;  // global position of this block's slice of each bin
   const uint32_t cb_shift = (uint32_t)(c - 1 - low);
-  const uint32_t half = 1u << (c - 1);
+  const WinLayout wl = msm_win_layout(C::FR_BITS, c);
   // pass 1: this block's counts, computed by k_coarse_hist
   for (uint32_t b = threadIdx.x; b < NB; b += 256) hist[b] = blockhist[(size_t)blockIdx.x * NB + b];
   __syncthreads();
@@ -177,32 +174,14 @@ __global__ void __launch_bounds__(256) k_coarse_scatter(const uint32_t* __restri
   __syncthreads();
   // pass 2: place
   const uint32_t low_mask = (1u << low) - 1u;
-  for (int k = 0; k < SORT_TILE / 256; k++) {
-    size_t i = (size_t)blockIdx.x * SORT_TILE + (size_t)k * 256 + threadIdx.x;
+  for (int k = 0; k < tile / 256; k++) {
+    size_t i = (size_t)blockIdx.x * tile + (size_t)k * 256 + threadIdx.x;
     if (i >= n) break;
     uint32_t s[8];
     fr_canonical<C>(s, scalars + 8 * i, mont != 0);
-    uint32_t carry = 0;
+    uint32_t carry = 0, neg = 0;
     for (int w = 0; w < W; w++) {
-      int bit = w * c;
-      uint32_t v = 0;
-      if (bit < 256) {
-        int word = bit >> 5, sh = bit & 31;
-        uint64_t two = s[word];
-        if (word + 1 < 8) two |= (uint64_t)s[word + 1] << 32;
-        v = (uint32_t)((two >> sh) & ((1u << c) - 1));
-      }
-      v += carry;
-      uint32_t mag, neg;
-      if (v > half) {
-        mag = (1u << c) - v;
-        neg = 1;
-        carry = 1;
-      } else {
-        mag = v;
-        neg = 0;
-        carry = 0;
-      }
+      const uint32_t mag = msm_window_digit(s, msm_win_off(wl.base, wl.rem, w), msm_win_bits(wl.base, wl.rem, w), carry, neg);
       if (mag) {
         uint32_t bkt = mag - 1;
         uint32_t bin = ((uint32_t)w << cb_shift) + (bkt >> low);

@@ -124,35 +124,54 @@ def test_miller_loop_and_final_exp(hostmath, name):
     assert R.gt_from_mont_bytes(cp, ml.raw) == T.f12_one
 
 
+def _win_layout(cp, c):
+    """msm_body.h: msm_win_layout -- the r.bit_length() + 1 bits spread over W windows whose widths differ by <= 1"""
+    total = cp.r.bit_length() + 1
+    W = (total + c - 1) // c
+    base, rem = divmod(total, W)
+    widths = [base + 1 if w < rem else base for w in range(W)]
+    offs = [sum(widths[:w]) for w in range(W)]
+    assert max(widths) <= c and max(widths) - min(widths) <= 1 and offs[-1] + widths[-1] == total
+    return W, widths, offs
+
+
 @pytest.mark.parametrize("name", CURVES)
 def test_window_digits_reconstruct_the_scalar(hostmath, name):
-    """k_digits' body: sum_w d_w 2^(cw) == s mod r, |d_w| <= 2^(c-1), for plain and Montgomery inputs,
-    including the all-ones windows whose carry once produced a 'minus zero' digit."""
+    """k_digits' body: sum_w d_w 2^off(w) == s mod r, |d_w| <= 2^(width(w)-1), for plain and Montgomery inputs,
+    including the all-ones windows whose carry once produced a 'minus zero' digit, over the balanced window layout
+    (no sparse top window: BLS12-377 / BN254 at c = 16 get 14 + 2 resp. 15 + 1 windows of 16 / 15 bits)."""
     cp = R.CURVES[name]
     L = hostmath
     rnd = random.Random(1234)
-    for c in (4, 5, 7, 10, 12, 13, 16, 18, 20):
+    for c in (4, 5, 7, 10, 12, 13, 15, 16, 18, 20):
+        W, widths, offs = _win_layout(cp, c)
+        if name == "BLS12-381" and c == 16:
+            assert widths == [16] * 16  # BASELINE configs[1]: plain 16-bit windows
         half = 1 << (c - 1)
         cases = [0, 1, cp.r - 1, cp.r - 2, (1 << c) - 1, (1 << (2 * c)) - 1, (1 << 255) % cp.r, half, half + 1, 1 << c, ((1 << c) - 1) << c]
+        cases += [((1 << offs[k]) - 1) % cp.r for k in (1, 2, W // 2, W - 1)] + [((1 << (offs[k] + widths[k])) - 1) % cp.r for k in (0, W // 2)]
         cases += [((1 << (c * k)) - 1) % cp.r for k in (3, 5, 9)] + [rnd.randrange(cp.r) for _ in range(100)]
+
+        def value(out):
+            tot = 0
+            for w in range(W):
+                dgt = out[w]
+                if dgt:
+                    mag = dgt >> 1
+                    assert 1 <= mag <= (1 << (widths[w] - 1)), (name, c, w)
+                    tot += (-mag if dgt & 1 else mag) << offs[w]
+            return tot
+
         for mont in (0, 1):
             for s in cases:
                 enc = (s * (1 << 256) % cp.r) if mont else s
                 out = (ctypes.c_uint32 * 80)()
-                W = L.hm_digits(cp.curve_id, enc.to_bytes(32, "little"), mont, c, out, 80)
-                assert W == (cp.r.bit_length() + 1 + c - 1) // c
-                tot = 0
-                for w in range(W):
-                    dgt = out[w]
-                    if dgt:
-                        mag = dgt >> 1
-                        assert 1 <= mag <= half
-                        tot += (-mag if dgt & 1 else mag) << (c * w)
-                assert tot == s % cp.r, (name, c, s, mont)
+                assert L.hm_digits(cp.curve_id, enc.to_bytes(32, "little"), mont, c, out, 80) == W
+                assert value(out) == s % cp.r, (name, c, s, mont)
         for s in (cp.r, cp.r + 5, (1 << 256) - 1, 2 * cp.r + 3):  # BaseZr-style unreduced scalars
             out = (ctypes.c_uint32 * 80)()
-            W = L.hm_digits(cp.curve_id, s.to_bytes(32, "little"), 0, c, out, 80)
-            assert sum(((-(out[w] >> 1) if out[w] & 1 else (out[w] >> 1)) << (c * w)) for w in range(W)) == s % cp.r
+            assert L.hm_digits(cp.curve_id, s.to_bytes(32, "little"), 0, c, out, 80) == W
+            assert value(out) == s % cp.r
 
 
 @pytest.mark.parametrize("name", CURVES)
