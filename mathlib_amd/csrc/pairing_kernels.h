@@ -357,13 +357,54 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_gt_exp_lp(const Fp12<C>* __
   lp_store_gt<C>(out, i, acc);
 }
 
+// the same in the carry-free form (BLS12-381): 4-bit windows, the table of powers in scratch as 28-bit-limb values, the
+// accumulator too (an 84-word slot per lane would cost the eighth wave of a CU its LDS)
+template <class C>
+__global__ void __launch_bounds__(64) MLHIP_LP_OCC k_gt_exp_lp28(const Fp12<C>* __restrict__ in,
+                                                                 const uint32_t* __restrict__ scalars, int mont, size_t n,
+                                                                 Fp12<C>* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = t >> 1;  // pair-uniform exit
+  if (i >= n) return;
+  typedef Fp2L28<C> E2;
+  uint32_t s[8];
+  fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  Fp12<C, E2> tab[15], acc;
+  lp28_load_gt<C>(tab[0], in, i);
+#pragma unroll 1
+  for (int k = 1; k < 15; k++) fp12_mul<C>(tab[k], tab[k - 1], tab[0]);
+  fp12_one<C>(acc);
+  bool started = false;
+#pragma unroll 1
+  for (int w = 63; w >= 0; w--) {  // the scalar is the same on both lanes of a pair: every branch is pair-uniform
+    if (started) {
+#pragma unroll 1
+      for (int d = 0; d < 4; d++) fp12_sqr<C>(acc, acc);
+    }
+    const uint32_t nib = (s[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (nib) {
+      if (started)
+        fp12_mul<C>(acc, acc, tab[nib - 1]);
+      else {
+        acc = tab[nib - 1];
+        started = true;
+      }
+    }
+  }
+  lp28_store_gt<C>(out, i, acc);
+}
+
 template <class C>
 int gt_exp_device(const void* d_in, const void* d_scalars, int mont, size_t n, void* d_out, hipStream_t st) {
   const char* one_lane_env = getenv("MLHIP_PAIRING_ONE_LANE");
   if (one_lane_env && one_lane_env[0] == '1')
     k_gt_exp<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars, mont, n,
                                                                    (Fp12<C>*)d_out);
-  else
+  else if (lp28_enabled<C>()) {
+    if constexpr (C::ID == 1)
+      k_gt_exp_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in,
+                                                                              (const uint32_t*)d_scalars, mont, n, (Fp12<C>*)d_out);
+  } else
     k_gt_exp_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,
                                                                           mont, n, (Fp12<C>*)d_out);
   HIPCHK(hipGetLastError());

@@ -577,6 +577,17 @@ def test_pairing_saturated_lane_pair_kernels_agree(lib, mlhip, monkeypatch):
         out = ctypes.create_string_buffer(gtb * len(cases))
         mlhip.check(lib.mlhip_pairing_batch(cid, q1, q2, len(cases), out))
         assert out.raw == b"".join(_h(c["fexp"]) for c in cases)
+        # Gt.Exp on raw Miller-loop values (any Fp12 element is a valid input), 40 exponents incl. 0, 1, r - 1
+        m = 40
+        sc = _rand_scalars(m, 77, 254)
+        sc[0] = 0
+        sc[1] = (1, 0, 0, 0)
+        r_order = int(g["r"], 16) - 1
+        sc[2] = [(r_order >> (64 * j)) & (2**64 - 1) for j in range(4)]
+        ge = ctypes.create_string_buffer(gtb * m)
+        mlhip.check(lib.mlhip_gt_exp(cid, ml.raw[: gtb * m], sc.tobytes(), 0, m, ge))
+        res["gt_exp" + sat] = ge.raw
+    assert res["gt_exp0"] == res["gt_exp1"]
     assert res["0"] == res["1"] == cref.final_exp(cid, cref.miller_loop(cid, p1, p2, 2, n // 2, 8), n // 2, 8)
 
 
