@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmlhip.so")
+# MLHIP_LIB=<path> loads another build of the same library (A/B measurements of kernel variants on one box)
+LIB_PATH = os.environ.get("MLHIP_LIB") or os.path.join(HERE, "libmlhip.so")
 
 CURVE_BN254, CURVE_BLS12_381, CURVE_BLS12_377 = 0, 1, 2
 GROUP_G1, GROUP_G2 = 1, 2

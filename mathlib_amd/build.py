@@ -28,7 +28,7 @@ UNITS = [
     "tu_codec_bls381.hip",
     "tu_codec_bls377.hip",
 ]
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fno-gpu-rdc"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fno-gpu-rdc"] + os.environ.get("MLHIP_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -55,7 +55,7 @@ struct PairDevice {
   typedef Fp28<C> V;
   static __device__ __forceinline__ uint32_t x1(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]; bound_ctrl: no "old" value to materialize
 #else
     return v;
 #endif

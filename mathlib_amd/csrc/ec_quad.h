@@ -82,7 +82,7 @@ struct QuadDevice {
   template <int CTRL>
   static __device__ __forceinline__ uint32_t xlane(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);  // bound_ctrl: every quad_perm source lane is valid, and hipcc then needs no v_mov of the "old" value per move
 #else
     return v;
 #endif

@@ -37,7 +37,7 @@ MLHIP_HD bool lane_is_hi() {
 // value held by the other lane of the pair (quad_perm [1,0,3,2])
 MLHIP_HD uint32_t pair_xchg_u32(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);  // bound_ctrl: with it hipcc emits the move alone; without, a v_mov of the "old" value 0 in front of every one
 #else
   return x;
 #endif

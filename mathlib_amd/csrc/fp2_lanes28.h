@@ -53,6 +53,18 @@ MLHIP_HD void lp28_partner(Fp2L28<C>& r, const Fp2L28<C>& a) {
 #pragma unroll
   for (int i = 0; i < C::N28; i++) r.v.l[i] = (int32_t)pair_xchg_u32((uint32_t)a.v.l[i]);
 }
+// the even (real) lane's value on both lanes of the pair: quad_perm [0,0,2,2]
+template <class C>
+MLHIP_HD void lp28_real_on_both(Fp2L28<C>& r, const Fp2L28<C>& a) {
+#pragma unroll
+  for (int i = 0; i < C::N28; i++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    r.v.l[i] = __builtin_amdgcn_update_dpp(0, a.v.l[i], 0xA0, 0xF, 0xF, true);
+#else
+    r.v.l[i] = a.v.l[i];
+#endif
+  }
+}
 template <class C>
 MLHIP_HD bool lp28_both(const Fp2L28<C>&, const bool (&b)[1]) {
   const uint32_t z = b[0] ? 1u : 0u;
@@ -89,6 +101,14 @@ template <class C>
 inline void lp28_partner(Fp2H28<C>& r, const Fp2H28<C>& a) {
   const Fp28<C> t0 = a.c[0], t1 = a.c[1];
   r.c[0] = t1;
+  r.c[1] = t0;
+  r.wt = a.wt;
+  r.vbound = a.vbound;
+}
+template <class C>
+inline void lp28_real_on_both(Fp2H28<C>& r, const Fp2H28<C>& a) {
+  const Fp28<C> t0 = a.c[0];
+  r.c[0] = t0;
   r.c[1] = t0;
   r.wt = a.wt;
   r.vbound = a.vbound;
@@ -243,16 +263,17 @@ MLHIP_HD void lp28_mul(E& r, const E& a, const E& b) {
   static_assert(C::BETA == -1, "carry-free lane pairs: u^2 = -1 only");
   E::require(2 * a.w() * b.w() <= 8, "fp2_mul", a.w(), b.w());
   E::require(2 * a.vb() * b.vb() <= LP28_MAXU, "fp2_mul (value bound)", a.vb(), b.vb());
-  E ax, bx, o;
+  //   both lanes: own a * b0 + partner's a * (+-b1) -- b0 arrives by one broadcast (no select), the sign of b1 by one
+  //   negation of the exchanged value and one select
+  E ax, bx, b0, o;
   lp28_partner<C>(ax, a);
   lp28_partner<C>(bx, b);
+  lp28_real_on_both<C>(b0, b);
   for (int i = 0; i < E::LANES; i++) {
-    const bool hi = E::hi(i);
-    Fp28<C> nb, y1, y2;
+    Fp28<C> nb, y2;
     fp28_neg<C>(nb, bx.at(i));
-    fp28_select<C>(y1, hi, bx.at(i), b.at(i));
-    fp28_select<C>(y2, hi, b.at(i), nb);
-    fp28_mul2<C>(o.at(i), a.at(i), y1, ax.at(i), y2);
+    fp28_select<C>(y2, E::hi(i), b.at(i), nb);
+    fp28_mul2<C>(o.at(i), a.at(i), b0.at(i), ax.at(i), y2);
   }
   o.set_w(1);
   o.set_vb(1);
@@ -268,12 +289,11 @@ MLHIP_HD void lp28_sqr(E& r, const E& a) {
   lp28_partner<C>(ax, a);
   for (int i = 0; i < E::LANES; i++) {
     const bool hi = E::hi(i);
-    Fp28<C> s, d, dd, x, y;
-    fp28_add<C>(s, a.at(i), ax.at(i));
+    Fp28<C> t, d, x, y;
+    fp28_select<C>(t, hi, a.at(i), ax.at(i));
+    fp28_add<C>(x, a.at(i), t);  // a0 + a1 | 2 a1
     fp28_sub<C>(d, a.at(i), ax.at(i));
-    fp28_add<C>(dd, a.at(i), a.at(i));
-    fp28_select<C>(x, hi, dd, s);
-    fp28_select<C>(y, hi, ax.at(i), d);
+    fp28_select<C>(y, hi, ax.at(i), d);  // a0 - a1 | a0
     fp28_mul<C>(o.at(i), x, y);
   }
   o.set_w(1);
