@@ -46,8 +46,8 @@ import (
 var WindowC = 0
 
 // The GPU is a throughput device.  Measured on one MI355X through this ABI (tools/perf_latency.py): a
-// MultiScalarMul of 2 points takes 0.35 ms, of 2^20 points 4.6 ms; but ONE Miller loop takes 6.2 ms and ONE final
-// exponentiation 14.2 ms, because a single pairing occupies a single lane pair (65 536 of them take 23 ms).
+// MultiScalarMul of 2 points takes 0.35 ms, of 2^20 points 4.5 ms; but ONE Miller loop takes 4.0 ms and ONE final
+// exponentiation 8.5 ms, because a single pairing occupies a single lane pair (65 536 of them take 18.7 ms).
 // gnark on the CPU does a single pairing in about a millisecond.  Hence:
 //
 // MinDeviceMSM: MultiScalarMul with fewer pairs stays on the embedded gurvy driver.  A host-slice MSM costs the device
@@ -60,7 +60,7 @@ var WindowC = 0
 var MinDeviceMSM = 32
 
 // MinDevicePairingBatch: PairingBatch with fewer pairs stays on the embedded gurvy driver.  Any batch up to 32 768
-// pairs costs one wave time on the device (about 14 ms on an MI355X, profiles/r01_perf_hostapi_pairing.txt); a CPU
+// pairs costs one wave time on the device (8.6 ms on an MI355X, profiles/r02_perf_hostapi_pairing.txt); a CPU
 // core needs about a millisecond per pairing, so a few hundred pairs are where the device starts to win.
 var MinDevicePairingBatch = 256
 

@@ -36,7 +36,7 @@ while time.time() - t0 < budget:
         n = rnd.choice([1, 2, 5, 33, 100, 257, 1000, 1025, 3000, 5000, 20000, 70000, 300000]) if rnd.random() < 0.7 else rnd.randrange(1, 40000)
         if group == 2:
             n = min(n, 8000)
-        c = rnd.choice([0, 4, 6, 8, 9, 12, 13, 15, 16])
+        c = rnd.choice([0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20])  # every width: windows differ by <= 1 bit
         pts = bytearray(cref.gen_points(cid, group, rnd.getrandbits(40), rnd.getrandbits(40), n))
         bits = rnd.choice([8, 32, 128, 200, 253])
         vals = [rnd.getrandbits(bits) % r_order for _ in range(n)]
@@ -55,16 +55,29 @@ while time.time() - t0 < budget:
         # half of the calls stream the pairs in a random number of segments (the library reads the switch per call)
         segs = rnd.choice([0, 0, 0, 2, 3, 5, 16])
         os.environ["MLHIP_STREAM_SEGMENTS"] = str(segs)
-        _lib.check(fn(cid, pts, sc.tobytes(), 0, n, c, out))
+        if rnd.random() < 0.15:  # the device-list entry point: 1-4 shards, all on device 0
+            nd = rnd.randrange(1, 5)
+            devs = (ctypes.c_int * nd)(*([0] * nd))
+            _lib.check(lib.mlhip_msm_multi(cid, group, devs, nd, pts, sc.tobytes(), 0, n, c, out))
+            done["multi"] = done.get("multi", 0) + 1
+        else:
+            _lib.check(fn(cid, pts, sc.tobytes(), 0, n, c, out))
         if out.raw != exp:
             print("MISMATCH msm", name, group, n, c, bits, "segments", segs, "seed", seed, flush=True)
             sys.exit(1)
         done["msm"] += 1
         done["streamed"] += 1 if segs else 0
     else:
-        n = rnd.choice([1, 3, 64, 65, 500])
-        p1 = cref.gen_points(cid, 1, rnd.getrandbits(40), rnd.getrandbits(40), n)
-        p2 = cref.gen_points(cid, 2, rnd.getrandbits(40), rnd.getrandbits(40), n)
+        n = rnd.choice([1, 3, 64, 65, 500, 1500])
+        p1 = bytearray(cref.gen_points(cid, 1, rnd.getrandbits(40), rnd.getrandbits(40), n))
+        p2 = bytearray(cref.gen_points(cid, 2, rnd.getrandbits(40), rnd.getrandbits(40), n))
+        for k in range(n // 40 + (1 if rnd.random() < 0.3 else 0)):  # points at infinity on either side
+            j = rnd.randrange(n)
+            if k % 2:
+                p1[j * g1b : (j + 1) * g1b] = bytes(g1b)
+            else:
+                p2[j * g2b : (j + 1) * g2b] = bytes(g2b)
+        p1, p2 = bytes(p1), bytes(p2)
         exp = cref.pairing_batch(cid, p1, p2, n, 16)
         out = ctypes.create_string_buffer(gtb * n)
         _lib.check(lib.mlhip_pairing_batch(cid, p1, p2, n, out))
