@@ -8,7 +8,9 @@
 // and an Fp2 square is one single product per lane: c0 = (a0 + a1)(a0 - a1), c1 = (2 a1) a0.
 // Weight rules (fp28.h): a dual product needs w_a w_b <= 4, the single-product square needs w_a = 1 -- so P and
 // R are carry-propagated right after the subtraction, X3 and Y3 before they are stored: four propagations and
-// 8 dual + 2 single products per mixed addition.
+// 8 dual + 2 single products per mixed addition.  (Fusing Y3 = R (Q - X3) - Y1 PPP into one four-product reduction
+// saves 4 % of the multiplies but holds eight prepared operands live: 73 spilled registers instead of 49 and +1.8 %
+// kernel time measured -- DESIGN.md section 7.)
 // Written over a backend (device: one Fp28 per lane + DPP; host: a 2-entry array) like ec_quad.h.
 #pragma once
 #include "ec.h"
@@ -30,6 +32,11 @@ struct PairHost {
   static void sel_hi(V& r, const V& hi_val, const V& lo_val) {
     r.v[0] = lo_val.v[0];
     r.v[1] = hi_val.v[1];
+  }
+  static void real_on_both(V& r, const V& a) {
+    V t = a;
+    r.v[0] = t.v[0];
+    r.v[1] = t.v[0];
   }
   template <class FN>
   static void each(FN fn) {
@@ -67,6 +74,17 @@ struct PairDevice {
   }
   static __device__ __forceinline__ void sel_hi(V& r, const V& hi_val, const V& lo_val) {
     fp28_select<C>(r, hi(), hi_val, lo_val);
+  }
+  // the even (real) lane's value on both lanes: quad_perm [0,0,2,2]
+  static __device__ __forceinline__ void real_on_both(V& r, const V& a) {
+#pragma unroll
+    for (int i = 0; i < C::N28; i++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      r.l[i] = __builtin_amdgcn_update_dpp(0, a.l[i], 0xA0, 0xF, 0xF, true);
+#else
+      r.l[i] = a.l[i];
+#endif
+    }
   }
   template <class FN>
   static __device__ __forceinline__ void each(FN fn) {
@@ -130,25 +148,24 @@ MLHIP_HD bool lp28_is_zero_exact(const typename B::V& a) {
 template <class C, class B>
 MLHIP_HD void lp28_mul(typename B::V& r, const typename B::V& a, const typename B::V& b) {
   static_assert(C::BETA == -1, "lane-pair carry-free products assume u^2 = -1");
-  typename B::V ax, bx, nax, y1, x2, y2;
+  // both lanes: own a * b0 + partner's a * (+-b1): b0 by one broadcast, the sign of b1 by one negation and one select
+  typename B::V ax, bx, b0, nbx, y2;
   B::xchg(ax, a);
   B::xchg(bx, b);
-  lp28_neg<C, B>(nax, ax);
-  B::sel_hi(y1, bx, b);    // c0: b0 (own)   | c1: b0 (partner)
-  B::sel_hi(x2, ax, nax);  // c0: -a1        | c1: a0
-  B::sel_hi(y2, b, bx);    // c0: b1         | c1: b1 (own)
-  MLHIP_LP28_EACH(B, fp28_mul2<C>(B::at(r, li_), B::at(a, li_), B::at(y1, li_), B::at(x2, li_), B::at(y2, li_)));
+  B::real_on_both(b0, b);
+  lp28_neg<C, B>(nbx, bx);
+  B::sel_hi(y2, b, nbx);  // c0: -b1 | c1: b1 (own)
+  MLHIP_LP28_EACH(B, fp28_mul2<C>(B::at(r, li_), B::at(a, li_), B::at(b0, li_), B::at(ax, li_), B::at(y2, li_)));
 }
 
 // r = a^2, a normalized (weight 1): one single product per lane
 template <class C, class B>
 MLHIP_HD void lp28_sqr(typename B::V& r, const typename B::V& a) {
-  typename B::V ax, s, d, dd, x, y;
+  typename B::V ax, t, d, x, y;
   B::xchg(ax, a);
-  MLHIP_LP28_EACH(B, fp28_add<C>(B::at(s, li_), B::at(a, li_), B::at(ax, li_)));   // a0 + a1
+  B::sel_hi(t, a, ax);
+  MLHIP_LP28_EACH(B, fp28_add<C>(B::at(x, li_), B::at(a, li_), B::at(t, li_)));    // a0 + a1 | 2 a1
   MLHIP_LP28_EACH(B, fp28_sub<C>(B::at(d, li_), B::at(a, li_), B::at(ax, li_)));   // c0 lane: a0 - a1
-  MLHIP_LP28_EACH(B, fp28_add<C>(B::at(dd, li_), B::at(a, li_), B::at(a, li_)));   // c1 lane: 2 a1
-  B::sel_hi(x, dd, s);
   B::sel_hi(y, ax, d);
   MLHIP_LP28_EACH(B, fp28_mul<C>(B::at(r, li_), B::at(x, li_), B::at(y, li_)));
 }
@@ -244,7 +261,7 @@ MLHIP_HD void xyzz28_lp_madd(XYZZ28L<typename B::V>& acc, bool& inf, const Affin
   lp28_sub<C, B>(t, t, Q);
   lp28_sub<C, B>(t, t, Q);
   lp28_normalize<C, B>(X3, t);
-  lp28_sub<C, B>(e, Q, X3);            // weight 2
+  lp28_sub<C, B>(e, Q, X3);                      // weight 2
   lp28_mul<C, B>(Vv, R, e);            // 1 x 2
   lp28_mul<C, B>(T, acc.y, PPP);       // 1 x 1
   lp28_sub<C, B>(t, Vv, T);
