@@ -5,9 +5,28 @@
 
 namespace mlhip {
 
+// Signed 4-bit windows of a 256-bit integer: s + 0x88..8 has the nibbles d_w + 8 with d_w in [-8, 7] and
+// s = sum_w d_w 16^w + t[8] 16^64 (t[8] = the carry out of the addition: 0 for a scalar below 2^255).  The carries of the
+// recoding are the carries of one 256-bit addition -- no per-window branch; the table holds {1..8}P, half of the
+// unsigned form's, and every lane of a wave adds at the same loop positions (a windowed NAF would not: its non-zero
+// digits sit at data-dependent positions, which serialises the lanes).
+__device__ __forceinline__ void signed_windows4(uint32_t t[9], const uint32_t s[8]) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    c += (uint64_t)s[k] + 0x88888888u;
+    t[k] = (uint32_t)c;
+    c >>= 32;
+  }
+  t[8] = (uint32_t)c;
+}
+__device__ __forceinline__ int signed_window4_digit(const uint32_t t[9], int w) {
+  return w == 64 ? (int)t[8] : (int)((t[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
+}
+
 // out[i] = [s_i] P_i: batched single-scalar multiplication (the reference's G1.Mul / G2.Mul,
 // driver/gurvy/bls12381/bls12-381.go:238-247, :342-351; double-and-add shape of :920-932), one lane per
-// product, 4-bit fixed windows: 15-entry table in scratch, 4 doublings + 1 addition per window.
+// product, signed 4-bit fixed windows: 8-entry table in scratch, 4 doublings + 1 addition per window.
 template <class C, class F>
 __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__ points, size_t point_stride,
                                                    const uint32_t* __restrict__ scalars, int mont, size_t n,
@@ -22,9 +41,11 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
     fr_canonical<C>(s, scalars + 8 * i, mont != 0);
   }
   const Affine<F> P = points[i * point_stride];
-  XYZZ<F> tab[15];
+  uint32_t sw[9];
+  signed_windows4(sw, s);
+  XYZZ<F> tab[8];
   xyzz_from_affine<F>(tab[0], P);
-  for (int k = 1; k < 15; k++) {
+  for (int k = 1; k < 8; k++) {
     tab[k] = tab[k - 1];
     xyzz_madd_ool<F>(tab[k], P);
   }
@@ -33,7 +54,7 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
   bool started = false;
   constexpr bool kInline = std::is_same<F, FpField<C>>::value;  // G1: the running point stays in registers
 #pragma unroll 1
-  for (int w = 63; w >= 0; w--) {
+  for (int w = 64; w >= 0; w--) {
     if (started) {
 #pragma unroll 1
       for (int d = 0; d < 4; d++) {
@@ -45,14 +66,16 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
         acc = t;
       }
     }
-    uint32_t nib = (s[w >> 3] >> ((w & 7) * 4)) & 15u;
-    if (nib) {
-      if constexpr (kInline) {
-        const XYZZ<F> q = tab[nib - 1];
+    const int d = signed_window4_digit(sw, w);
+    if (d) {
+      XYZZ<F> q = tab[(d < 0 ? -d : d) - 1];
+      typename F::T ny;
+      F::neg(ny, q.y);
+      F::select(q.y, d < 0, ny, q.y);
+      if constexpr (kInline)
         xyzz_add<F>(acc, q);
-      } else {
-        xyzz_add_ool<F>(acc, tab[nib - 1]);
-      }
+      else
+        xyzz_add_ool<F>(acc, q);
       started = true;
     }
   }
@@ -150,10 +173,12 @@ __global__ void __launch_bounds__(64) k_scalar_mul_lp(const Affine<Fp2Field<C>>*
   }
   Affine<FL> P;
   lp_load_affine<C>(P, points, i * point_stride, hi);
-  XYZZ<FL> tab[15];
+  uint32_t sw[9];
+  signed_windows4(sw, s);
+  XYZZ<FL> tab[8];
   xyzz_from_affine<FL>(tab[0], P);
 #pragma unroll 1
-  for (int k = 1; k < 15; k++) {
+  for (int k = 1; k < 8; k++) {
     tab[k] = tab[k - 1];
     xyzz_madd<FL>(tab[k], P, false);
   }
@@ -161,7 +186,7 @@ __global__ void __launch_bounds__(64) k_scalar_mul_lp(const Affine<Fp2Field<C>>*
   xyzz_set_inf<FL>(acc);
   bool started = false;
 #pragma unroll 1
-  for (int w = 63; w >= 0; w--) {
+  for (int w = 64; w >= 0; w--) {
     if (started) {
 #pragma unroll 1
       for (int d = 0; d < 4; d++) {
@@ -170,9 +195,13 @@ __global__ void __launch_bounds__(64) k_scalar_mul_lp(const Affine<Fp2Field<C>>*
         acc = d2;
       }
     }
-    const uint32_t nib = (s[w >> 3] >> ((w & 7) * 4)) & 15u;
-    if (nib) {
-      xyzz_add_lp_ool<C>(acc, tab[nib - 1]);
+    const int d = signed_window4_digit(sw, w);  // pair-uniform
+    if (d) {
+      XYZZ<FL> q = tab[(d < 0 ? -d : d) - 1];
+      typename FL::T ny;
+      FL::neg(ny, q.y);
+      FL::select(q.y, d < 0, ny, q.y);
+      xyzz_add_lp_ool<C>(acc, q);
       started = true;
     }
   }
