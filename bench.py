@@ -329,13 +329,18 @@ def main() -> None:
             acc_kernel = ("k_accumulate<FpField<%s>>" if acc32 else "k_accumulate28<%s>") % cname
         else:
             acc_kernel = ("k_accumulate28_lp<%s>" if (CURVE == 1 and not acc32) else "k_accumulate_lp<%s>") % cname
+        # from 2^22 (G1) / 2^23 (G2) points on the library accumulates tile by tile (msm_plan.h: resident_tiles): the
+        # dominant kernel is then launched `tiles` times per MSM (its _seg form), each launch over n / tiles units
+        tiles = max(1, int(round(phase_avg.get((dom, "tiles"), 1.0))))
+        if tiles > 1 and not acc32:
+            acc_kernel = acc_kernel.replace("<", "_seg<", 1)
         bytes_unit = MSM_BYTES[(CURVE, dom)]
         achieved = bytes_unit * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         roofline = {
             "bound": "hbm", "kernel": acc_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": acc_ms,
-            "algorithmic_bytes_per_launch": bytes_unit * n,
-            "phase_ms": {("g1_" if g == G1 else "g2_") + k_: v for (g, k_), v in sorted(phase_avg.items())},
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": acc_ms / tiles,
+            "algorithmic_bytes_per_launch": bytes_unit * n // tiles, "launches_per_msm": tiles,
+            "phase_ms": {("g1_" if g == G1 else "g2_") + k_: v for (g, k_), v in sorted(phase_avg.items()) if k_ != "tiles"},
         }
         pm = _pmc(acc_kernel.split("<")[0] + "<" + cname) if args.config == 2 else None
         if pm:
@@ -353,7 +358,9 @@ def main() -> None:
             }
         if len(groups) > 1:
             g1_ms = phase_avg.get((G1, "accumulate"), 0.0)
-            roofline["g1_kernel"] = {"kernel": "k_accumulate28<%s>" % cname, "avg_kernel_ms": g1_ms,
+            g1_tiles = max(1, int(round(phase_avg.get((G1, "tiles"), 1.0))))
+            roofline["g1_kernel"] = {"kernel": ("k_accumulate28_seg<%s>" if g1_tiles > 1 else "k_accumulate28<%s>") % cname,
+                                     "avg_kernel_ms": g1_ms / g1_tiles, "launches_per_msm": g1_tiles,
                                      "achieved": MSM_BYTES[(CURVE, G1)] * n / (g1_ms * 1e-3) / 1e9 if g1_ms else 0.0}
         unit = "scalar-muls/s"
         if len(groups) > 1:

@@ -135,7 +135,9 @@ int mlhip_msm_launch(mlhip_msm_plan* plan, const void* d_points, const void* d_s
 int mlhip_msm_finish(mlhip_msm_plan* plan, void* out_affine, void* out_xyzz);
 /* Phase timings of the last run with profiling on (HIP events on the plan's stream), milliseconds:
  * [0] digits [1] sort (histogram scan + scatter) [2] bucket accumulation [3] bucket reduction
- * [4] device total [5] host tail.  Returns the number of values written. */
+ * [4] device total [5] host tail [6] the number of tiles the accumulation ran in (device-resident inputs from 2^22 / 2^23
+ * points on are accumulated tile by tile; [1] and [2] are then sums over the tiles' launches).  Returns the number of
+ * values written (at most `cap`). */
 int mlhip_msm_plan_set_profiling(mlhip_msm_plan* plan, int on);
 int mlhip_msm_plan_timings(mlhip_msm_plan* plan, float* ms, int cap);
 

@@ -196,9 +196,9 @@ class MsmPlan:
         check(load().mlhip_msm_plan_set_profiling(self._h, 1 if on else 0))
 
     def timings(self):
-        buf = (c_float * 6)()
-        k = load().mlhip_msm_plan_timings(self._h, buf, 6)
-        names = ["digits", "sort", "accumulate", "reduce", "device_total", "host_tail"]
+        buf = (c_float * 7)()
+        k = load().mlhip_msm_plan_timings(self._h, buf, 7)
+        names = ["digits", "sort", "accumulate", "reduce", "device_total", "host_tail", "tiles"]
         return {names[i]: float(buf[i]) for i in range(k)}
 
     def run(self, d_points: int, d_scalars: int, n: int, scalars_mont: bool, stream: int = 0, want_xyzz: bool = False):

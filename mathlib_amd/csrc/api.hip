@@ -676,6 +676,9 @@ int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   for (hipEvent_t e : p->ev_seg)
     if (e) (void)hipEventDestroy(e);
+  for (auto& tile : p->ev_tile)
+    for (hipEvent_t e : tile)
+      if (e) (void)hipEventDestroy(e);
   if (p->aux) (void)hipStreamDestroy(p->aux);
   delete p;
   return 0;
@@ -734,8 +737,9 @@ int mlhip_msm_plan_set_profiling(mlhip_msm_plan* p, int on) {
 
 int mlhip_msm_plan_timings(mlhip_msm_plan* p, float* ms, int cap) {
   if (!p || !ms) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
-  int k = cap < 6 ? cap : 6;
-  for (int i = 0; i < k; i++) ms[i] = p->ms[i];
+  int k = cap < 7 ? cap : 7;
+  for (int i = 0; i < k && i < 6; i++) ms[i] = p->ms[i];
+  if (k == 7) ms[6] = p->tiles_timed > 0 ? (float)p->tiles_timed : 1.0f;
   return k;
 }
 

@@ -56,6 +56,9 @@ struct mlhip_msm_plan {
   // streamed host-buffer MSMs (plan_stream): raw carry-free bucket accumulators between segments, one event per segment
   void* d_state28 = nullptr;
   hipEvent_t ev_seg[MLHIP_MAX_SEGMENTS] = {};
+  // tiles of device-resident inputs under profiling: before the sort / after it / after the accumulation of each tile
+  hipEvent_t ev_tile[MLHIP_MAX_SEGMENTS][3] = {};
+  int tiles_timed = 0;  // > 0: the last launch was tiled and recorded ev_tile[0 .. tiles_timed)
   bool pending = false;
   size_t pending_n = 0;
   float ms[6] = {0, 0, 0, 0, 0, 0};

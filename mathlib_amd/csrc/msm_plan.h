@@ -238,9 +238,42 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
 }
 
 template <class C, class F>
+int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points, const void* h_scalars, int mont,
+                size_t n, int K, hipStream_t st);
+
+// Number of tiles a device-resident MSM is cut into (1 = one pass over all points); see plan_stream.  Measured
+// (profiles/r02_tiles.txt): G1 from 2^22 points on in tiles of 2^21 (235 MB of points), G2 from 2^23 on in tiles of 2^20
+// (also 235 MB); at most MLHIP_MAX_SEGMENTS tiles.
+// MLHIP_TILE_LOG2 = t forces tiles of 2^t points for every n above that (0 = never tile).
+template <class C, class F>
+int resident_tiles(const mlhip_msm_plan* p, size_t n) {
+  constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
+  constexpr bool kBoundary = kG2 && !(C::BETA == -1 && C::N28 == 14);
+  if (!p->aux || (!kBoundary && !p->d_points28)) return 1;
+  int lg = kG2 ? 20 : 21;
+  size_t from = (size_t)1 << (kG2 ? 23 : 22);
+  if (const char* e = getenv("MLHIP_TILE_LOG2")) {
+    const int v = atoi(e);
+    if (v <= 0) return 1;
+    lg = v > 30 ? 30 : v;
+    from = ((size_t)1 << lg) + 1;
+  }
+  if (n < from) return 1;
+  size_t k = (n + ((size_t)1 << lg) - 1) >> lg;
+  if (k > MLHIP_MAX_SEGMENTS) k = MLHIP_MAX_SEGMENTS;
+  return k < 2 ? 1 : (int)k;
+}
+
+template <class C, class F>
 int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n, hipStream_t st) {
   typedef Affine<F> A;
   typedef XYZZ<F> X;
+  if (n != 0 && !p->upload_src) {
+    const int K = resident_tiles<C, F>(p, n);
+    if (K > 1)
+      return plan_stream<C, F>(p, const_cast<void*>(d_points), const_cast<void*>(d_scalars), nullptr, nullptr, mont, n, K, st);
+  }
+  p->tiles_timed = 0;
   p->pending_n = n;
   p->pending = true;
   if (n != 0) {
@@ -337,6 +370,14 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
 // buffers, d_points / d_scalars the plan-sized device buffers they are staged through.  Uploads and the point
 // conversion ride the auxiliary stream; the sort and the accumulation of segment s wait for its event on `st`.
 // The host thread blocks inside the pageable copies, which is exactly what overlaps them with the kernels queued before.
+//
+// The same train serves device-resident inputs cut into TILES (h_scalars == nullptr: the scalars are already at
+// d_scalars; h_points == nullptr: the points are already at d_points and are converted tile by tile unless the plan
+// holds their carry-free copy).  Every window gathers its points in a different random order, so an MSM re-reads the
+// whole point array once per window; once that array outgrows what the chip keeps close (Infinity Cache 256 MB, TLB
+// reach) each gather goes to HBM and the additions wait: 0.139 ns per G1 addition at 2^20-2^21 points, 0.165 at 2^24
+// (profiles/r02_tiles.txt).  A tile of 2^21-2^22 points keeps all W passes over its points near; the bucket
+// accumulators travel through d_state28 between tiles (0.2-0.5 GB per tile, streamed once).
 template <class C, class F>
 int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points, const void* h_scalars, int mont,
                 size_t n, int K, hipStream_t st) {
@@ -353,13 +394,19 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
   if (!kBoundary && !p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * kStateBytes));
   for (int s = 0; s < K; s++)
     if (!p->ev_seg[s]) HIPCHK(hipEventCreateWithFlags(&p->ev_seg[s], hipEventDisableTiming));
-  // resident bases (h_points == nullptr): only the scalars travel; the carry-free copy must already be there
+  // resident points (h_points == nullptr): only the scalars travel (or nothing: h_scalars == nullptr); their carry-free
+  // copy is either the plan's (resident bases) or made tile by tile below
   const bool resident = h_points == nullptr;
-  if (resident && !kBoundary && !(p->points_static && p->conv_src == d_points && n <= p->conv_n))
-    return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM over resident bases needs their converted copy");
+  const bool conv_cached = resident && p->points_static && p->conv_src == d_points && n <= p->conv_n;
+  const bool prof = p->profiling && h_scalars == nullptr;  // tiles of device-resident inputs: per-tile phase events
+  if (prof)
+    for (int s = 0; s < K; s++)
+      for (int j = 0; j < 3; j++)
+        if (!p->ev_tile[s][j]) HIPCHK(hipEventCreate(&p->ev_tile[s][j]));
+  p->tiles_timed = prof ? K : -1;  // -1: a streamed host-buffer MSM records no phase events
   p->pending_n = n;
   p->pending = true;
-  if (!resident) p->conv_src = nullptr;  // the carry-free copy no longer matches any resident buffer
+  if (!conv_cached) p->conv_src = nullptr;  // the carry-free copy is being rewritten
   const size_t seg = (n + K - 1) / K;
   const char* hp = (const char*)h_points;
   const char* hs = (const char*)h_scalars;
@@ -372,9 +419,9 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
     const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0);
     char* dsc = (char*)d_scalars + off * 32;
     A* dpt = (A*)d_points + off;
-    HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
-    if (!resident) {
-      HIPCHK(hipMemcpyAsync(dpt, hp + off * sizeof(A), len * sizeof(A), hipMemcpyHostToDevice, p->aux));
+    if (hs) HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
+    if (!conv_cached) {
+      if (!resident) HIPCHK(hipMemcpyAsync(dpt, hp + off * sizeof(A), len * sizeof(A), hipMemcpyHostToDevice, p->aux));
       if constexpr (kBoundary) {
         // the boundary-form kernel reads the uploaded points as they are
       } else if constexpr (kG2)
@@ -385,12 +432,16 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
                                                                                        (Affine28<C>*)p->d_points28 + off);
     }
     HIPCHK(hipEventRecord(p->ev_seg[s], p->aux));
-    HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));
+    if (prof && first) HIPCHK(hipEventRecord(p->ev[0], st));
     HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
+    if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][0], st));
+    if (hs || !resident) HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));  // uploads: the sort needs the scalars
     {
       int rc_sort = launch_sort<C>(p, dsc, mont, len, st, false);
       if (rc_sort) return rc_sort;
     }
+    if (!(hs || !resident)) HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));  // tiles: only the accumulation waits for the conversion
+    if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][1], st));
     uint32_t big_threshold = (uint32_t)std::min<size_t>((len >> (p->c - 1)) * 8, 1u << 30);
     if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
     if constexpr (kBoundary) {
@@ -420,11 +471,18 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
           p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28, flags,
           (X*)p->d_buckets);
     }
+    if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][2], st));
   }
+  if (resident && !conv_cached && p->points_static && !kBoundary) {  // every tile was converted: the copy is whole again
+    p->conv_src = d_points;
+    p->conv_n = n;
+  }
+  if (prof) HIPCHK(hipEventRecord(p->ev[3], st));
   {
     int rc_red = launch_reduce<C, F>(p, st);
     if (rc_red) return rc_red;
   }
+  if (prof) HIPCHK(hipEventRecord(p->ev[4], st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->W * p->nsel * sizeof(X), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(p->done, st));
@@ -444,7 +502,20 @@ int plan_finish(mlhip_msm_plan* p, void* out_affine, void* out_xyzz) {
     HIPCHK(hipEventSynchronize(p->done));
     auto t0 = std::chrono::steady_clock::now();
     host_tail<F>(p, total);
-    if (p->profiling) {
+    if (p->profiling && p->tiles_timed > 0) {
+      // tiles: digits are part of each tile's sort; accumulate = the sum over the tiles' accumulation kernels
+      p->ms[0] = p->ms[1] = p->ms[2] = 0;
+      for (int s = 0; s < p->tiles_timed; s++) {
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, p->ev_tile[s][0], p->ev_tile[s][1]));
+        HIPCHK(hipEventElapsedTime(&b, p->ev_tile[s][1], p->ev_tile[s][2]));
+        p->ms[1] += a;
+        p->ms[2] += b;
+      }
+      HIPCHK(hipEventElapsedTime(&p->ms[3], p->ev[3], p->ev[4]));
+      HIPCHK(hipEventElapsedTime(&p->ms[4], p->ev[0], p->ev[4]));
+      p->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } else if (p->profiling && p->tiles_timed == 0) {
       for (int i = 0; i < 4; i++) HIPCHK(hipEventElapsedTime(&p->ms[i], p->ev[i], p->ev[i + 1]));
       HIPCHK(hipEventElapsedTime(&p->ms[4], p->ev[0], p->ev[4]));
       p->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -751,3 +751,46 @@ def test_bases_shared_by_threads(lib, mlhip):
         t.join()
     assert lib.mlhip_bases_destroy(handle) == 0
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_resident_tiles(lib, mlhip, curve, group, monkeypatch):
+    """Device-resident MSMs above 2^23 points are accumulated tile by tile (plan_stream with no uploads: the bucket
+    accumulators travel between tiles).  MLHIP_TILE_LOG2 forces small tiles: ragged last tile, uniform and skewed
+    scalars (long buckets spanning tiles), infinities, the plan reused with another n, and one tile (= untiled)."""
+    import torch
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, g1b, g2b, _ = mlhip.sizes(cid)
+    sz = g1b if group == 1 else g2b
+    n = 5000
+    pts = bytearray(cref.gen_points(cid, group, 4242 + group, 99, n))
+    pts[7 * sz : 8 * sz] = bytes(sz)
+    pts[(n - 1) * sz : n * sz] = bytes(sz)
+    pts = bytes(pts)
+    uniform = _rand_scalars(n, 1234 + cid, 252)
+    import numpy as np
+
+    skew = np.zeros((n, 4), dtype=np.uint64)
+    skew[:, 0] = np.random.default_rng(77 + cid).integers(0, 1 << 20, size=n, dtype=np.uint64)
+    skew[::3] = skew[0]
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    dp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
+    for name, sc in (("uniform", uniform), ("skewed", skew)):
+        ds = torch.frombuffer(bytearray(sc.tobytes()), dtype=torch.uint8).to(dev)
+        want = cref.msm(cid, group, pts, sc, n, False, 0, 8)
+        want_head = cref.msm(cid, group, pts, sc, 3001, False, 0, 8)
+        for c in (8, 13):
+            plan = mlhip.MsmPlan(cid, group, n, c)
+            plan.set_profiling(True)
+            for tile in ("10", "9", "12", "13", "0"):  # 5 tiles (ragged), 10, 2, 1 (= untiled), off
+                monkeypatch.setenv("MLHIP_TILE_LOG2", tile)
+                assert plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st) == want, (curve, group, name, c, tile)
+                t = plan.timings()
+                assert t["accumulate"] > 0 and t["device_total"] >= t["accumulate"], (tile, t)
+                assert plan.run(dp.data_ptr(), ds.data_ptr(), 3001, False, st) == want_head, (curve, group, name, c, tile)
+            plan.close()
