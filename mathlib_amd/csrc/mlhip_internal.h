@@ -40,6 +40,7 @@ struct mlhip_msm_plan {
   void* d_points28 = nullptr;  // G1: the points in the carry-free 28-bit-limb form (ec28.h), rewritten every MSM
   bool profiling = false;
   bool reduce_one_lane = false;
+  bool reduce28 = false;  // G1: the reduction reads the carry-free bucket state (d_state28) -- k_chunks_q28 / k_masked_sums_q28
   int red_block = 256;  // workgroup size of k_chunks_q (MLHIP_RED_BLOCK)
   int acc_block = 64;  // workgroup size of the bucket-accumulation kernel (MLHIP_ACC_BLOCK)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

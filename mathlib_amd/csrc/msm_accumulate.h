@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate_big(const uint32_t* __rest
 // which makes the chain of additions identical to the unsegmented kernel's; the last segment writes the boundary form.
 #define MLHIP_SEG_FIRST 1
 #define MLHIP_SEG_LAST 2
+#define MLHIP_SEG_KEEP28 4  // the last segment leaves the raw accumulators too: the reduction reads them (k_chunks_q28)
 
 template <class C>
 __global__ void __launch_bounds__(256) k_accumulate28_seg(const Affine28<C>* __restrict__ points,
@@ -304,12 +305,13 @@ __global__ void __launch_bounds__(256) k_accumulate28_seg(const Affine28<C>* __r
   const size_t g = order[tid];
   const uint32_t cnt = counts[g];
   const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  const bool to_boundary = last && !(flags & MLHIP_SEG_KEEP28);
   if (cnt > big_threshold) {  // k_accumulate_big_seg adds this segment's entries to the bucket's state
     uint32_t pos = atomicAdd(big_count, 1u);
     big_list[pos] = (uint32_t)g;
     return;
   }
-  if (cnt == 0 && !first && !last) return;  // nothing to add, nothing to convert
+  if (cnt == 0 && !first && !to_boundary) return;  // nothing to add, nothing to convert
   XYZZ28<C> acc;
   bool inf = true;
   if (!first) {
@@ -332,7 +334,7 @@ __global__ void __launch_bounds__(256) k_accumulate28_seg(const Affine28<C>* __r
       p = pn;
     }
   }
-  if (last) {
+  if (to_boundary) {
     XYZZ<FpField<C>> r;
     xyzz28_to<C>(r, acc, inf);
     buckets[g] = r;
@@ -357,7 +359,8 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg(const uint32_t* __
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
   const uint32_t nbig = *big_count;
-  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0;
+  const bool last = (flags & MLHIP_SEG_LAST) != 0 && !(flags & MLHIP_SEG_KEEP28);
   for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
     const uint32_t g = big_list[bi];
     XYZZ<F> sum;

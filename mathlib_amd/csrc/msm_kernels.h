@@ -27,6 +27,7 @@
 #include "ec28.h"
 #include "ec28_lp.h"
 #include "ec_quad.h"
+#include "ec_quad28.h"
 #include "fp2_lanes.h"
 #include "mlhip_internal.h"
 #include "msm_body.h"

@@ -79,6 +79,11 @@ int plan_alloc(mlhip_msm_plan* p) {
     const char* acc32 = getenv("MLHIP_ACC32");
     const bool want28 = !(acc32 && acc32[0] == '1');
     if (want28) HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(Affine28<typename F::Curve>)));
+    // ... and so does the quad-lane reduction, on the accumulators as the kernel leaves them (MLHIP_REDUCE32=1: the
+    // boundary-form reduction kernels, kept as the second implementation)
+    const char* red32 = getenv("MLHIP_REDUCE32");
+    p->reduce28 = want28 && !p->reduce_one_lane && !(red32 && red32[0] == '1');
+    if (p->reduce28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * sizeof(XYZZ28<typename F::Curve>)));
   }
   if constexpr (std::is_same<F, Fp2Field<typename F::Curve>>::value && F::Curve::BETA == -1 && F::Curve::N28 == 14) {
     // G2 in the carry-free form: BLS12-381 only (-14 % accumulation time); u^2 = -5 does not fit the weight budget
@@ -87,8 +92,13 @@ int plan_alloc(mlhip_msm_plan* p) {
     if (!(acc32 && acc32[0] == '1')) HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(AffineG2_28<typename F::Curve>)));
   }
   HIPCHK(hipMalloc(&p->d_buckets, nbuckets * p->xyzz_size));
-  HIPCHK(hipMalloc(&p->d_A, (size_t)p->W * p->T * p->xyzz_size));
-  HIPCHK(hipMalloc(&p->d_W0, (size_t)p->W * p->T * p->xyzz_size));
+  {
+    size_t chunk_size = p->xyzz_size;
+    if constexpr (std::is_same<F, FpField<typename F::Curve>>::value)
+      chunk_size = std::max(chunk_size, sizeof(XYZZ28<typename F::Curve>));
+    HIPCHK(hipMalloc(&p->d_A, (size_t)p->W * p->T * chunk_size));
+    HIPCHK(hipMalloc(&p->d_W0, (size_t)p->W * p->T * chunk_size));
+  }
   HIPCHK(hipMalloc(&p->d_out, (size_t)p->W * p->nsel * p->xyzz_size));
   HIPCHK(hipHostMalloc(&p->h_out, (size_t)p->W * p->nsel * p->xyzz_size, hipHostMallocDefault));
   for (int i = 0; i < 5; i++) HIPCHK(hipEventCreate(&p->ev[i]));
@@ -218,7 +228,15 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
       k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 2) * sizeof(X), st>>>(
           (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
     } else {
-      if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created
+      if (p->reduce28) {
+        // the accumulation left its carry-free bucket state in d_state28 (MLHIP_SEG_KEEP28)
+        typedef XYZZ28<C> X28;
+        k_chunks_q28<C><<<dim3((unsigned)((4 * n_chunks + p->red_block - 1) / p->red_block)), dim3(p->red_block), 0, st>>>(
+            (const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
+        constexpr int RB = 512;  // 128 quads, 28 KB of LDS per block
+        k_masked_sums_q28<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X28), st>>>(
+            (const X28*)p->d_A, (const X28*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      } else if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created
         k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
                                                                                      p->L, (X*)p->d_A, (X*)p->d_W0);
         constexpr int RB = 256;  // 48 KB of LDS per block
@@ -339,9 +357,15 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
             p->d_bigcount, (X*)p->d_buckets);
     } else if (p->d_points28) {
       HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
-      k_accumulate28<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-          (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
-          p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
+      if (p->reduce28)  // one segment that is first and last, leaving the raw accumulators for k_chunks_q28
+        k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+            (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
+            p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28,
+            (X*)p->d_buckets);
+      else
+        k_accumulate28<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+            (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
+            p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
     } else {
       k_accumulate<F><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
           (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
@@ -351,8 +375,18 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     {
       constexpr int BB = sizeof(X) <= 192 ? 256 : 128;  // 48 KB of LDS per block
       launch_big_slices<F, BB>(p, (const A*)d_points, st);
-      k_accumulate_big<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
-                                                                            (const X*)p->d_bigpart, (X*)p->d_buckets);
+      bool folded = false;
+      if constexpr (!kLanePairs) {
+        if (p->reduce28) {
+          k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+              p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28,
+              MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
+          folded = true;
+        }
+      }
+      if (!folded)
+        k_accumulate_big<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
+                                                                              (const X*)p->d_bigpart, (X*)p->d_buckets);
     }
     {
       int rc_red = launch_reduce<C, F>(p, st);
@@ -416,7 +450,7 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
   for (size_t off = 0; off < n; off += seg, s++) {
     const size_t len = std::min(seg, n - off);
     const bool first = off == 0, last = off + len >= n;
-    const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0);
+    const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0) | (!kG2 && p->reduce28 ? MLHIP_SEG_KEEP28 : 0);
     char* dsc = (char*)d_scalars + off * 32;
     A* dpt = (A*)d_points + off;
     if (hs) HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));

@@ -117,4 +117,94 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums_q(const XYZZ<FpField<C>>*
   if (quad == 0) quad_store<C>(out, blockIdx.x, acc);
 }
 
+// ---- the quad-lane reduction on the accumulation kernels' own bucket state (XYZZ28, ec_quad28.h) ------------------
+// Buckets come as the carry-free accumulators (ZZ all-zero limbs = empty), the chunk sums stay in that form, and only
+// the W x nsel sums that travel to the host are converted to the boundary form (one conversion per lane).
+template <class C>
+__device__ __forceinline__ void quad28_load(Fp28<C>& v, const XYZZ28<C>* arr, size_t idx) {
+  v = reinterpret_cast<const Fp28<C>*>(arr + idx)[threadIdx.x & 3u];
+}
+template <class C>
+__device__ __forceinline__ void quad28_store(XYZZ28<C>* arr, size_t idx, const Fp28<C>& v) {
+  reinterpret_cast<Fp28<C>*>(arr + idx)[threadIdx.x & 3u] = v;
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_chunks_q28(const XYZZ28<C>* __restrict__ buckets, size_t n_chunks, int l_eff,
+                                                    XYZZ28<C>* __restrict__ A, XYZZ28<C>* __restrict__ W0) {
+  typedef QuadDevice28<C> B;
+  const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (g >= n_chunks) return;  // quad-uniform
+  const XYZZ28<C>* b = buckets + g * (size_t)l_eff;
+  Fp28<C> acc, w0, cur, x, y;
+  fp28_zero<C>(acc);
+  fp28_zero<C>(w0);
+  quad28_load<C>(cur, b, l_eff - 1);
+  const int steps = 2 * (l_eff - 1) + 1;  // acc += b[i]; w0 += acc; ... ; acc += b[0]
+#pragma unroll 1
+  for (int s = 0; s < steps; s++) {
+    const bool odd = (s & 1) != 0;
+    const int i = l_eff - 1 - (s >> 1);
+    fp28_select<C>(x, odd, w0, acc);
+    fp28_select<C>(y, odd, acc, cur);
+    if (!odd && i > 0) quad28_load<C>(cur, b, i - 1);  // the next bucket arrives under this addition
+    quad28_xyzz_add<C, B>(x, y);
+    fp28_select<C>(w0, odd, x, w0);
+    fp28_select<C>(acc, odd, acc, x);
+  }
+  quad28_store<C>(A, g, acc);
+  quad28_store<C>(W0, g, w0);
+}
+
+// same selections as k_masked_sums; BLOCK / 4 quads per block; the result leaves in the boundary form
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_masked_sums_q28(const XYZZ28<C>* __restrict__ A, const XYZZ28<C>* __restrict__ W0,
+                                                           uint32_t T, int nsel, XYZZ<FpField<C>>* __restrict__ out) {
+  typedef QuadDevice28<C> B;
+  typedef XYZZ28<C> X;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  X* sh = reinterpret_cast<X*>(smem);
+  constexpr uint32_t NQ = BLOCK / 4;
+  const uint32_t quad = threadIdx.x >> 2;
+  const uint32_t w = blockIdx.x / nsel;
+  const int sel = blockIdx.x % nsel;
+  const X* src = (sel < 2 ? W0 : A) + (size_t)w * T;
+  Fp28<C> acc, v;
+  fp28_zero<C>(acc);
+  uint32_t count, lo = 0;
+  int k = 0;
+  if (sel < 4) {
+    const uint32_t half = (T + 1) / 2;
+    lo = (sel & 1) ? half : 0u;
+    count = ((sel & 1) ? T : half) - lo;
+  } else {
+    k = sel - 4;
+    count = T / 2;
+  }
+  const uint32_t lowmask = (1u << k) - 1u;
+#pragma unroll 1
+  for (uint32_t j = quad; j < count; j += NQ) {
+    const uint32_t t = sel < 4 ? lo + j : (((j >> k) << (k + 1)) | (1u << k) | (j & lowmask));
+    quad28_load<C>(v, src, t);
+    quad28_xyzz_add<C, B>(acc, v);
+  }
+  quad28_store<C>(sh, quad, acc);
+  __syncthreads();
+#pragma unroll 1
+  for (uint32_t s = NQ / 2; s > 0; s >>= 1) {
+    if (quad < s) {  // quad-uniform
+      quad28_load<C>(v, sh, quad + s);
+      quad28_xyzz_add<C, B>(acc, v);
+      quad28_store<C>(sh, quad, acc);
+    }
+    __syncthreads();
+  }
+  if (quad == 0) {
+    // (an empty sum is ZZ = 0 limbs, which converts to the boundary form's ZZ = 0)
+    Fp<C> r;
+    fp28_to_fp<C>(r, acc);
+    quad_store<C>(out, blockIdx.x, r);
+  }
+}
+
 }  // namespace mlhip

@@ -10,6 +10,7 @@
 #include "../../mathlib_amd/csrc/codec.h"
 #include "../../mathlib_amd/csrc/ec28.h"
 #include "../../mathlib_amd/csrc/ec_quad.h"
+#include "../../mathlib_amd/csrc/ec_quad28.h"
 #include "../../mathlib_amd/csrc/ec28_lp.h"
 #include "../../mathlib_amd/csrc/modinv.h"
 #include "../../mathlib_amd/csrc/fp2_lanes28.h"
@@ -270,6 +271,48 @@ struct Ops {
     memcpy(out, &a, sizeof(A1));
     return 0;
   }
+  // the same fold through the carry-free quad addition (ec_quad28.h, QuadHost28)
+  static int quad28_chain(const void* pts, const void* zs, int n, void* out) {
+    typedef QuadHost28<C> B;
+    const A1* p = (const A1*)pts;
+    const F* z = (const F*)zs;
+    typename B::V acc;
+    for (int i = 0; i < 4; i++) fp28_zero<C>(acc.v[i]);
+    for (int i = 0; i < n; i++) {
+      X1 q;
+      xyzz_from_affine<FpField<C>>(q, p[i]);
+      typename B::V b;
+      if (xyzz_is_inf<FpField<C>>(q)) {
+        for (int k = 0; k < 4; k++) fp28_zero<C>(b.v[k]);
+      } else {
+        if (!fp_is_zero<C>(z[i])) {
+          F z2, z3;
+          fp_sqr<C>(z2, z[i]);
+          fp_mul<C>(z3, z2, z[i]);
+          fp_mul<C>(q.x, q.x, z2);
+          fp_mul<C>(q.y, q.y, z3);
+          q.zz = z2;
+          q.zzz = z3;
+        }
+        fp28_from_fp<C>(b.v[0], q.x);
+        fp28_from_fp<C>(b.v[1], q.y);
+        fp28_from_fp<C>(b.v[2], q.zz);
+        fp28_from_fp<C>(b.v[3], q.zzz);
+      }
+      quad28_xyzz_add<C, B>(acc, b);
+      for (int k = 0; k < 4; k++)  // every stored coordinate stays normalized
+        for (int j = 0; j < C::N28 - 1; j++)
+          if (acc.v[k].l[j] < 0 || acc.v[k].l[j] >= (1 << 28)) return -3;
+    }
+    XYZZ28<C> r28;
+    B::gather(r28, acc);
+    X1 r;
+    xyzz28_to<C>(r, r28, fp28_all_zero<C>(r28.zz));
+    A1 a;
+    xyzz_to_affine<FpField<C>>(a, r);
+    memcpy(out, &a, sizeof(A1));
+    return 0;
+  }
   // G2 bucket accumulation in the carry-free lane-pair form (ec28_lp.h) through the host emulation backend
   static int madd28_lp_chain(const void* pts, const uint8_t* neg, int n, void* out) {
     if constexpr (C::BETA == -1) {
@@ -450,6 +493,7 @@ int hm_g1_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPAT
 int hm_fp28_op(int curve, int op, const void* a, const void* b, const void* c, const void* d, void* out) { DISPATCH(curve, fp28_op(op, a, b, c, d, out)) }
 int hm_madd28_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_chain(pts, neg, n, out)) }
 int hm_quad_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, quad_chain(pts, zs, n, out)) }
+int hm_quad28_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, quad28_chain(pts, zs, n, out)) }
 int hm_madd28_lp_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_lp_chain(pts, neg, n, out)) }
 int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g2dec(w, compressed, subgroup, out)) }
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }

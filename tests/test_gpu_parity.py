@@ -475,18 +475,18 @@ def test_g2_wire_codec_vs_oracle(lib, mlhip, curve):
 # every one must give the same bytes as the default path
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("switch", ["MLHIP_LEGACY_SORT", "MLHIP_ACC32", "MLHIP_REDUCE_ONE_LANE", "MLHIP_NO_PLAN_CACHE",
-                                    "MLHIP_ACC_BLOCK=256", "MLHIP_RED_BLOCK=64", "MLHIP_CHUNK_LOG2=3",
-                                    "MLHIP_STREAM_SEGMENTS=2", "MLHIP_STREAM_SEGMENTS=5"])
+@pytest.mark.parametrize("switch", ["MLHIP_LEGACY_SORT", "MLHIP_ACC32", "MLHIP_REDUCE_ONE_LANE", "MLHIP_REDUCE32",
+                                    "MLHIP_NO_PLAN_CACHE", "MLHIP_ACC_BLOCK=256", "MLHIP_RED_BLOCK=64", "MLHIP_CHUNK_LOG2=3",
+                                    "MLHIP_STREAM_SEGMENTS=2", "MLHIP_STREAM_SEGMENTS=5", "MLHIP_REDUCE32+MLHIP_STREAM_SEGMENTS=3"])
 def test_msm_alternate_paths(lib, mlhip, curve, switch, monkeypatch):
     g = load_golden(curve)
     cid = g["curve_id"]
     fpb, g1b, _, _ = mlhip.sizes(cid)
     pts, scs, exp = load_msm1000(curve, fpb)
-    name, _, value = switch.partition("=")
-    monkeypatch.setenv(name, value or "1")
-    if "=" in switch:
-        monkeypatch.setenv("MLHIP_NO_PLAN_CACHE", "1")  # the knob is read when a plan is created
+    for sw in switch.split("+"):
+        name, _, value = sw.partition("=")
+        monkeypatch.setenv(name, value or "1")
+    monkeypatch.setenv("MLHIP_NO_PLAN_CACHE", "1")  # the knobs are read when a plan is created: no pooled plan
     for window_c in (9, 16):
         out = ctypes.create_string_buffer(g1b)
         mlhip.check(lib.mlhip_msm_g1(cid, pts, scs, 0, 1000, window_c, out))

@@ -424,6 +424,9 @@ def test_quad_lane_xyzz_add(hostmath, name):
         out = ctypes.create_string_buffer(2 * n)
         assert L.hm_quad_chain(cid, pts, zs, len(seq), out) == 0
         assert out.raw == R.g1_to_mont_bytes(cp, want)
+        out = ctypes.create_string_buffer(2 * n)  # the carry-free form of the same schedule (ec_quad28.h)
+        assert L.hm_quad28_chain(cid, pts, zs, len(seq), out) == 0
+        assert out.raw == R.g1_to_mont_bytes(cp, want)
 
 
 @pytest.mark.parametrize("name", ["BN254", "BLS12-381"])
