@@ -105,6 +105,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pairing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip protocol (b)/(c), the skewed run and the two-deep run")
+    ap.add_argument("--separate-sorts", action="store_true", help="config 4: launch the G1 and the G2 MSM of a step as two independent MSMs (each sorts the shared scalars itself) instead of mlhip_msm_launch_shared")
     ap.add_argument("--pipelined", action="store_true", help="issue the timed steps two-deep (launch of step i+1 before finish of step i); default: one step in flight")
     # accepted for compatibility with round-1 command lines
     ap.add_argument("--sequential", action="store_true", help=argparse.SUPPRESS)
@@ -254,7 +255,14 @@ def main() -> None:
         for pl in plans.values():
             pl.set_profiling(True)
 
+        # config 4: the G1 and the G2 MSM of a step share their scalars -- one sort per tile for both (mlhip_msm_launch_shared)
+        shared = len(groups) > 1 and not args.separate_sorts
+
         def launch(slot):
+            if shared:
+                plans[(slot, G1)].launch_shared(plans[(slot, G2)], points[G1].data_ptr(), points[G2].data_ptr(), scalars.data_ptr(),
+                                                n, False, streams[(slot, G1)].cuda_stream)
+                return
             for g in groups:
                 plans[(slot, g)].launch(points[g].data_ptr(), scalars.data_ptr(), n, False, streams[(slot, g)].cuda_stream)
 
@@ -308,12 +316,15 @@ def main() -> None:
         steps_n = max(args.steps, 1)
         # per-kernel times: unshared only when one MSM is in flight -- config 4 (G1 and G2 of a step overlap) and
         # --pipelined take them from a separate pass, one MSM at a time
-        if len(groups) > 1 or args.pipelined:
+        if (len(groups) > 1 and not shared) or args.pipelined:
             phase.clear()
             reps = 3
             for _ in range(reps):
+                if shared:
+                    launch(0)
                 for g in groups:
-                    plans[(0, g)].launch(points[g].data_ptr(), scalars.data_ptr(), n, False, streams[(0, g)].cuda_stream)
+                    if not shared:
+                        plans[(0, g)].launch(points[g].data_ptr(), scalars.data_ptr(), n, False, streams[(0, g)].cuda_stream)
                     plans[(0, g)].finish()
                     for kname, v in plans[(0, g)].timings().items():
                         phase[(g, kname)] = phase.get((g, kname), 0.0) + v
@@ -543,7 +554,8 @@ def main() -> None:
                 "pairs_per_gpu": n,
                 "window_c": WINDOW_C,
                 "parallelism": par,
-                "protocol": "SURVEY 8d (a): inputs resident in HBM; kernels + D2H of the window sums + host tail" + ("" if args.config == 3 else "; %d step(s) in flight" % (2 if args.pipelined else 1)),
+                "protocol": "SURVEY 8d (a): inputs resident in HBM; kernels + D2H of the window sums + host tail" + ("" if args.config == 3 else "; %d step(s) in flight" % (2 if args.pipelined else 1))
+                + ("; G1 and G2 share their scalars: one sort per tile for both (mlhip_msm_launch_shared)" if args.config == 4 and not args.separate_sorts else ""),
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

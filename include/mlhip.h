@@ -133,6 +133,14 @@ int mlhip_msm_run(mlhip_msm_plan* plan, const void* d_points, const void* d_scal
 int mlhip_msm_launch(mlhip_msm_plan* plan, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
                      void* stream);
 int mlhip_msm_finish(mlhip_msm_plan* plan, void* out_affine, void* out_xyzz);
+/* The G1 MSM and the G2 MSM of ONE scalar vector (additive: BASELINE configs[3] "G1 + G2 MSM, shared scalars"; in the
+ * reference's terms MultiScalarMul(a1, b) -- driver/gurvy/bls12381/bls12-381.go:766-783 -- and the G2 sum of
+ * g2.Mul(b[i]) -- :342-358 -- over the same b).  Both plans: same curve, device and window width; the (window, bucket)
+ * entry lists depend on the scalars only, so they are sorted once and both groups accumulate from them.  Finish each
+ * plan with mlhip_msm_finish.  Plans that cannot share (different widths, a second-implementation path) run one after
+ * the other with the same results. */
+int mlhip_msm_launch_shared(mlhip_msm_plan* g1_plan, mlhip_msm_plan* g2_plan, const void* d_points_g1,
+                            const void* d_points_g2, const void* d_scalars, int scalars_mont, size_t n, void* stream);
 /* Phase timings of the last run with profiling on (HIP events on the plan's stream), milliseconds:
  * [0] digits [1] sort (histogram scan + scatter) [2] bucket accumulation [3] bucket reduction
  * [4] device total [5] host tail [6] the number of tiles the accumulation ran in (device-resident inputs from 2^22 / 2^23

@@ -41,6 +41,7 @@ SYMBOLS = [
     "mlhip_msm_plan_destroy",
     "mlhip_msm_run",
     "mlhip_msm_launch",
+    "mlhip_msm_launch_shared",
     "mlhip_msm_finish",
     "mlhip_msm_plan_set_profiling",
     "mlhip_msm_plan_timings",
@@ -120,6 +121,7 @@ def load() -> ctypes.CDLL:
     lib.mlhip_msm_plan_destroy.argtypes = [vp]
     lib.mlhip_msm_run.argtypes = [vp, vp, vp, ci, sz, vp, vp, vp]
     lib.mlhip_msm_launch.argtypes = [vp, vp, vp, ci, sz, vp]
+    lib.mlhip_msm_launch_shared.argtypes = [vp, vp, vp, vp, vp, ci, sz, vp]
     lib.mlhip_msm_finish.argtypes = [vp, vp, vp]
     lib.mlhip_msm_plan_set_profiling.argtypes = [vp, ci]
     lib.mlhip_msm_plan_timings.argtypes = [vp, POINTER(c_float), ci]
@@ -213,6 +215,12 @@ class MsmPlan:
 
     def launch(self, d_points: int, d_scalars: int, n: int, scalars_mont: bool, stream: int = 0) -> None:
         check(load().mlhip_msm_launch(self._h, c_void_p(d_points), c_void_p(d_scalars), 1 if scalars_mont else 0, n, c_void_p(stream)))
+
+    def launch_shared(self, g2_plan: "MsmPlan", d_points_g1: int, d_points_g2: int, d_scalars: int, n: int, scalars_mont: bool,
+                      stream: int = 0) -> None:
+        """self = the G1 plan: the G1 and the G2 MSM of one scalar vector, sorted once (finish both plans afterwards)"""
+        check(load().mlhip_msm_launch_shared(self._h, g2_plan._h, c_void_p(d_points_g1), c_void_p(d_points_g2), c_void_p(d_scalars),
+                                             1 if scalars_mont else 0, n, c_void_p(stream)))
 
     def finish(self, want_xyzz: bool = False):
         out = ctypes.create_string_buffer(self.point_bytes)

@@ -711,6 +711,51 @@ int mlhip_msm_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scal
   return rc;
 }
 
+// can this plan run the segment train (plan_stream / plan_stream_shared)?  The condition stream_begin checks.
+static bool plan_can_stream(const mlhip_msm_plan* p) {
+  const bool carry_free_state = p->group == MLHIP_GROUP_G1 || p->curve == MLHIP_CURVE_BLS12_381;
+  return p->aux && !(carry_free_state && !p->d_points28);
+}
+
+int mlhip_msm_launch_shared(mlhip_msm_plan* g1, mlhip_msm_plan* g2, const void* d_points_g1, const void* d_points_g2,
+                            const void* d_scalars, int scalars_mont, size_t n, void* stream) {
+  if (!g1 || !g2) return mlhip_rt::fail(MLHIP_EINVAL, "null plan");
+  if (g1->group != MLHIP_GROUP_G1 || g2->group != MLHIP_GROUP_G2 || g1->curve != g2->curve || g1->device != g2->device)
+    return mlhip_rt::fail(MLHIP_EINVAL, "shared-scalar MSM needs a G1 plan and a G2 plan of one curve on one device");
+  if (g1->pending || g2->pending)
+    return mlhip_rt::fail(MLHIP_EINVAL, "plan already has a pending launch; call mlhip_msm_finish first");
+  if (n > g1->max_n || n > g2->max_n) return mlhip_rt::fail(MLHIP_EINVAL, "n exceeds a plan's max_n");
+  if (n && (!d_points_g1 || !d_points_g2 || !d_scalars)) return mlhip_rt::fail(MLHIP_EINVAL, "null device pointer");
+  const bool share = n != 0 && g1->c == g2->c && plan_can_stream(g1) && plan_can_stream(g2);
+  if (!share) {  // nothing to share (or a plan on a second-implementation path): two ordinary launches, one after the other
+    int rc = mlhip_msm_launch(g1, d_points_g1, d_scalars, scalars_mont, n, stream);
+    if (rc) return rc;
+    rc = mlhip_msm_launch(g2, d_points_g2, d_scalars, scalars_mont, n, stream);
+    if (rc) {  // leave neither plan pending: the caller gets one error for the pair
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      g1->pending = false;
+    }
+    return rc;
+  }
+  HIPCHK(hipSetDevice(g1->device));
+  hipStream_t st = (hipStream_t)stream;
+  void *p1 = const_cast<void*>(d_points_g1), *p2 = const_cast<void*>(d_points_g2), *sc = const_cast<void*>(d_scalars);
+  int rc;
+  switch (g1->curve) {
+    case MLHIP_CURVE_BN254: rc = mlhip_tu_plan_shared_Bn254(g1, g2, p1, p2, sc, scalars_mont, n, st); break;
+    case MLHIP_CURVE_BLS12_381: rc = mlhip_tu_plan_shared_Bls381(g1, g2, p1, p2, sc, scalars_mont, n, st); break;
+    default: rc = mlhip_tu_plan_shared_Bls377(g1, g2, p1, p2, sc, scalars_mont, n, st); break;
+  }
+  if (rc) {  // as mlhip_msm_launch: drain what was queued and leave both plans reusable
+    (void)hipStreamSynchronize(st);
+    if (g1->aux) (void)hipStreamSynchronize(g1->aux);
+    if (g2->aux) (void)hipStreamSynchronize(g2->aux);
+    (void)hipGetLastError();
+    g1->pending = g2->pending = false;
+  }
+  return rc;
+}
+
 int mlhip_msm_finish(mlhip_msm_plan* p, void* out_affine, void* out_xyzz) {
   if (!p || !out_affine) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
   HIPCHK(hipSetDevice(p->device));

@@ -146,16 +146,17 @@ void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
 // slice sums of the long buckets listed by the accumulation kernel (nothing to do, two near-empty launches, when
 // there are none)
 template <class F, int BB>
-void launch_big_slices(mlhip_msm_plan* p, const Affine<F>* d_points, hipStream_t st) {
+void launch_big_slices(mlhip_msm_plan* p, const Affine<F>* d_points, hipStream_t st, const mlhip_msm_plan* sv = nullptr) {
   typedef typename F::Curve C;
-  k_big_prefix<<<dim3(1), dim3(1024), 0, st>>>(p->d_counts, p->d_biglist, p->d_bigcount, p->d_bigprefix);
+  if (!sv) sv = p;  // the plan whose entry lists (sorted / offsets / counts) describe this tile
+  k_big_prefix<<<dim3(1), dim3(1024), 0, st>>>(sv->d_counts, p->d_biglist, p->d_bigcount, p->d_bigprefix);
   if constexpr (std::is_same<F, Fp2Field<C>>::value) {
     // G2: 128 lane pairs per slice (48 KB of LDS)
-    k_big_slices_lp<C, 256><<<dim3(1024), dim3(256), 128 * sizeof(XYZZ<F>), st>>>(d_points, p->d_sorted, p->d_offsets,
-                                                                                  p->d_counts, p->d_biglist, p->d_bigcount,
+    k_big_slices_lp<C, 256><<<dim3(1024), dim3(256), 128 * sizeof(XYZZ<F>), st>>>(d_points, sv->d_sorted, sv->d_offsets,
+                                                                                  sv->d_counts, p->d_biglist, p->d_bigcount,
                                                                                   p->d_bigprefix, (XYZZ<F>*)p->d_bigpart);
   } else {
-    k_big_slices<F, BB><<<dim3(1024), dim3(BB), BB * sizeof(XYZZ<F>), st>>>(d_points, p->d_sorted, p->d_offsets, p->d_counts,
+    k_big_slices<F, BB><<<dim3(1024), dim3(BB), BB * sizeof(XYZZ<F>), st>>>(d_points, sv->d_sorted, sv->d_offsets, sv->d_counts,
                                                                           p->d_biglist, p->d_bigcount, p->d_bigprefix,
                                                                           (XYZZ<F>*)p->d_bigpart);
   }
@@ -412,115 +413,209 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
 // reach) each gather goes to HBM and the additions wait: 0.139 ns per G1 addition at 2^20-2^21 points, 0.165 at 2^24
 // (profiles/r02_tiles.txt).  A tile of 2^21-2^22 points keeps all W passes over its points near; the bucket
 // accumulators travel through d_state28 between tiles (0.2-0.5 GB per tile, streamed once).
+// one streamed / tiled MSM in flight on a plan: what stream_begin fixes for its tiles
+struct StreamCtx {
+  void* d_points = nullptr;
+  void* d_scalars = nullptr;
+  const void* h_points = nullptr;
+  const void* h_scalars = nullptr;
+  int mont = 0;
+  size_t n = 0, seg = 0;
+  int K = 0;
+  bool resident = false, conv_cached = false, prof = false;
+};
+
 template <class C, class F>
-int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points, const void* h_scalars, int mont,
-                size_t n, int K, hipStream_t st) {
-  typedef Affine<F> A;
-  typedef XYZZ<F> X;
+int stream_begin(mlhip_msm_plan* p, StreamCtx& cx, hipStream_t st, int min_K) {
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
   // G2 on the curves without the carry-free lane-pair kernel keeps its bucket state in the boundary form
   constexpr bool kBoundary = kG2 && !(C::BETA == -1 && C::N28 == 14);
   if (!p->aux || (!kBoundary && !p->d_points28))
     return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM needs the auxiliary stream (and, for G1, the carry-free path)");
   constexpr size_t kStateBytes = kG2 ? 2 * sizeof(XYZZ28L<Fp28<C>>) : sizeof(XYZZ28<C>);
-  if (n == 0 || K < 2 || K > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "bad segment count");
+  if (cx.n == 0 || cx.K < min_K || cx.K > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "bad segment count");
   const size_t nbuckets = (size_t)p->W * p->M;
   if (!kBoundary && !p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * kStateBytes));
-  for (int s = 0; s < K; s++)
+  for (int s = 0; s < cx.K; s++)
     if (!p->ev_seg[s]) HIPCHK(hipEventCreateWithFlags(&p->ev_seg[s], hipEventDisableTiming));
   // resident points (h_points == nullptr): only the scalars travel (or nothing: h_scalars == nullptr); their carry-free
-  // copy is either the plan's (resident bases) or made tile by tile below
-  const bool resident = h_points == nullptr;
-  const bool conv_cached = resident && p->points_static && p->conv_src == d_points && n <= p->conv_n;
-  const bool prof = p->profiling && h_scalars == nullptr;  // tiles of device-resident inputs: per-tile phase events
-  if (prof)
-    for (int s = 0; s < K; s++)
+  // copy is either the plan's (resident bases) or made tile by tile
+  cx.resident = cx.h_points == nullptr;
+  cx.conv_cached = cx.resident && p->points_static && p->conv_src == cx.d_points && cx.n <= p->conv_n;
+  cx.prof = p->profiling && cx.h_scalars == nullptr;  // tiles of device-resident inputs: per-tile phase events
+  if (cx.prof)
+    for (int s = 0; s < cx.K; s++)
       for (int j = 0; j < 3; j++)
         if (!p->ev_tile[s][j]) HIPCHK(hipEventCreate(&p->ev_tile[s][j]));
-  p->tiles_timed = prof ? K : -1;  // -1: a streamed host-buffer MSM records no phase events
-  p->pending_n = n;
+  p->tiles_timed = cx.prof ? cx.K : -1;  // -1: a streamed host-buffer MSM records no phase events
+  p->pending_n = cx.n;
   p->pending = true;
-  if (!conv_cached) p->conv_src = nullptr;  // the carry-free copy is being rewritten
-  const size_t seg = (n + K - 1) / K;
-  const char* hp = (const char*)h_points;
-  const char* hs = (const char*)h_scalars;
+  if (!cx.conv_cached) p->conv_src = nullptr;  // the carry-free copy is being rewritten
+  cx.seg = (cx.n + cx.K - 1) / cx.K;
   HIPCHK(hipEventRecord(p->ev_fork, st));  // the staging buffers are free once the work queued before us is done
   HIPCHK(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
-  int s = 0;
-  for (size_t off = 0; off < n; off += seg, s++) {
-    const size_t len = std::min(seg, n - off);
-    const bool first = off == 0, last = off + len >= n;
-    const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0) | (!kG2 && p->reduce28 ? MLHIP_SEG_KEEP28 : 0);
-    char* dsc = (char*)d_scalars + off * 32;
-    A* dpt = (A*)d_points + off;
-    if (hs) HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
-    if (!conv_cached) {
-      if (!resident) HIPCHK(hipMemcpyAsync(dpt, hp + off * sizeof(A), len * sizeof(A), hipMemcpyHostToDevice, p->aux));
-      if constexpr (kBoundary) {
-        // the boundary-form kernel reads the uploaded points as they are
-      } else if constexpr (kG2)
-        k_points_to28_g2<C><<<dim3((unsigned)((4 * len + 255) / 256)), dim3(256), 0, p->aux>>>(
-            dpt, len, (AffineG2_28<C>*)p->d_points28 + off);
-      else
-        k_points_to28<C><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, p->aux>>>(dpt, len,
-                                                                                       (Affine28<C>*)p->d_points28 + off);
-    }
-    HIPCHK(hipEventRecord(p->ev_seg[s], p->aux));
-    if (prof && first) HIPCHK(hipEventRecord(p->ev[0], st));
-    HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
-    if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][0], st));
-    if (hs || !resident) HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));  // uploads: the sort needs the scalars
-    {
-      int rc_sort = launch_sort<C>(p, dsc, mont, len, st, false);
-      if (rc_sort) return rc_sort;
-    }
-    if (!(hs || !resident)) HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));  // tiles: only the accumulation waits for the conversion
-    if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][1], st));
-    uint32_t big_threshold = (uint32_t)std::min<size_t>((len >> (p->c - 1)) * 8, 1u << 30);
-    if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
+  return 0;
+}
+
+// tile s = pairs [off, off + len): uploads / conversion on the auxiliary stream, then sort and accumulation on `st`.
+// `sorter` != nullptr: the tile was already sorted in ANOTHER plan of the same window geometry over the same scalars
+// (mlhip_msm_launch_shared: the G1 and the G2 MSM of one scalar vector) -- its entry lists are read, nothing is sorted.
+template <class C, class F>
+int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, const mlhip_msm_plan* sorter) {
+  typedef Affine<F> A;
+  typedef XYZZ<F> X;
+  constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
+  constexpr bool kBoundary = kG2 && !(C::BETA == -1 && C::N28 == 14);
+  const size_t nbuckets = (size_t)p->W * p->M;
+  const size_t off = (size_t)s * cx.seg;
+  const size_t len = std::min(cx.seg, cx.n - off);
+  const bool first = off == 0, last = off + len >= cx.n;
+  const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0) | (!kG2 && p->reduce28 ? MLHIP_SEG_KEEP28 : 0);
+  const char* hp = (const char*)cx.h_points;
+  const char* hs = (const char*)cx.h_scalars;
+  char* dsc = (char*)cx.d_scalars + off * 32;
+  A* dpt = (A*)cx.d_points + off;
+  const bool prof = cx.prof;
+  if (hs) HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
+  if (!cx.conv_cached) {
+    if (!cx.resident) HIPCHK(hipMemcpyAsync(dpt, hp + off * sizeof(A), len * sizeof(A), hipMemcpyHostToDevice, p->aux));
     if constexpr (kBoundary) {
-      k_accumulate_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-          dpt, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist, p->d_bigcount, flags,
-          (X*)p->d_buckets);
-      constexpr int BB = 128;
-      launch_big_slices<F, BB>(p, dpt, st);
-      k_accumulate_big_fold<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
-                                                                             (const X*)p->d_bigpart, flags, (X*)p->d_buckets);
-    } else if constexpr (kG2) {
-      k_accumulate28_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-          (const AffineG2_28<C>*)p->d_points28 + off, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
-          big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
-      constexpr int BB = 128;
-      launch_big_slices<F, BB>(p, dpt, st);
-      k_accumulate_big_seg_g2<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
-          p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28L<Fp28<C>>*)p->d_state28, flags,
-          (X*)p->d_buckets);
-    } else {
-      k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-          (const Affine28<C>*)p->d_points28 + off, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
-          big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
-      constexpr int BB = 256;
-      launch_big_slices<F, BB>(p, dpt, st);
-      k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
-          p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28, flags,
-          (X*)p->d_buckets);
-    }
-    if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][2], st));
+      // the boundary-form kernel reads the uploaded points as they are
+    } else if constexpr (kG2)
+      k_points_to28_g2<C><<<dim3((unsigned)((4 * len + 255) / 256)), dim3(256), 0, p->aux>>>(
+          dpt, len, (AffineG2_28<C>*)p->d_points28 + off);
+    else
+      k_points_to28<C><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, p->aux>>>(dpt, len,
+                                                                                     (Affine28<C>*)p->d_points28 + off);
   }
-  if (resident && !conv_cached && p->points_static && !kBoundary) {  // every tile was converted: the copy is whole again
-    p->conv_src = d_points;
-    p->conv_n = n;
+  HIPCHK(hipEventRecord(p->ev_seg[s], p->aux));
+  if (prof && first) HIPCHK(hipEventRecord(p->ev[0], st));
+  HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
+  if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][0], st));
+  const bool uploads = hs || !cx.resident;
+  if (uploads) HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));  // the sort needs the uploaded scalars
+  if (!sorter) {
+    int rc_sort = launch_sort<C>(p, dsc, cx.mont, len, st, false);
+    if (rc_sort) return rc_sort;
   }
-  if (prof) HIPCHK(hipEventRecord(p->ev[3], st));
+  if (!uploads) HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));  // tiles: only the accumulation waits for the conversion
+  if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][1], st));
+  const mlhip_msm_plan* sv = sorter ? sorter : p;  // whose entry lists the kernels read
+  uint32_t big_threshold = (uint32_t)std::min<size_t>((len >> (p->c - 1)) * 8, 1u << 30);
+  if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
+  if constexpr (kBoundary) {
+    k_accumulate_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+        dpt, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order, big_threshold, p->d_biglist, p->d_bigcount, flags,
+        (X*)p->d_buckets);
+    constexpr int BB = 128;
+    launch_big_slices<F, BB>(p, dpt, st, sv);
+    k_accumulate_big_fold<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
+                                                                           (const X*)p->d_bigpart, flags, (X*)p->d_buckets);
+  } else if constexpr (kG2) {
+    k_accumulate28_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+        (const AffineG2_28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+        big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
+    constexpr int BB = 128;
+    launch_big_slices<F, BB>(p, dpt, st, sv);
+    k_accumulate_big_seg_g2<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+        p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28L<Fp28<C>>*)p->d_state28, flags,
+        (X*)p->d_buckets);
+  } else {
+    k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+        (const Affine28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+        big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
+    constexpr int BB = 256;
+    launch_big_slices<F, BB>(p, dpt, st, sv);
+    k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+        p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28, flags,
+        (X*)p->d_buckets);
+  }
+  if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][2], st));
+  return 0;
+}
+
+template <class C, class F>
+int stream_end(mlhip_msm_plan* p, const StreamCtx& cx, hipStream_t st) {
+  typedef XYZZ<F> X;
+  constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
+  constexpr bool kBoundary = kG2 && !(C::BETA == -1 && C::N28 == 14);
+  if (cx.resident && !cx.conv_cached && p->points_static && !kBoundary) {  // every tile was converted: the copy is whole again
+    p->conv_src = cx.d_points;
+    p->conv_n = cx.n;
+  }
+  if (cx.prof) HIPCHK(hipEventRecord(p->ev[3], st));
   {
     int rc_red = launch_reduce<C, F>(p, st);
     if (rc_red) return rc_red;
   }
-  if (prof) HIPCHK(hipEventRecord(p->ev[4], st));
+  if (cx.prof) HIPCHK(hipEventRecord(p->ev[4], st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->W * p->nsel * sizeof(X), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(p->done, st));
   return 0;
+}
+
+template <class C, class F>
+int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points, const void* h_scalars, int mont,
+                size_t n, int K, hipStream_t st) {
+  StreamCtx cx;
+  cx.d_points = d_points;
+  cx.d_scalars = d_scalars;
+  cx.h_points = h_points;
+  cx.h_scalars = h_scalars;
+  cx.mont = mont;
+  cx.n = n;
+  cx.K = K;
+  int rc = stream_begin<C, F>(p, cx, st, 2);
+  if (rc) return rc;
+  for (int s = 0; (size_t)s * cx.seg < n; s++) {
+    rc = stream_tile<C, F>(p, cx, s, st, nullptr);
+    if (rc) return rc;
+  }
+  return stream_end<C, F>(p, cx, st);
+}
+
+// The G1 MSM and the G2 MSM of ONE scalar vector (device-resident inputs; BASELINE configs[3], a Groth16 prover's
+// B-query): the entry lists of a tile depend on the scalars and the window geometry only, so every tile is sorted once
+// (in the G1 plan) and accumulated twice.  One stream, tile by tile: sort, G1 accumulation, G2 accumulation.
+template <class C>
+int plan_stream_shared(mlhip_msm_plan* p1, mlhip_msm_plan* p2, void* d_points_g1, void* d_points_g2, void* d_scalars, int mont,
+                       size_t n, hipStream_t st) {
+  typedef FpField<C> F1;
+  typedef Fp2Field<C> F2;
+  if (p1->c != p2->c || p1->W != p2->W || p1->M != p2->M)
+    return mlhip_rt::fail(MLHIP_EINVAL, "the two plans of a shared-scalar MSM need the same window width");
+  int K = 1;  // tiles of 2^20 pairs from 2^22 on (see resident_tiles: G1 gains from 2^22, G2 from 2^23, neither loses)
+  if (n >= ((size_t)1 << 22)) K = (int)std::min<size_t>((n + ((size_t)1 << 20) - 1) >> 20, MLHIP_MAX_SEGMENTS);
+  if (const char* e = getenv("MLHIP_TILE_LOG2")) {
+    const int v = atoi(e);
+    K = 1;
+    if (v > 0 && v < 31 && n > ((size_t)1 << v)) K = (int)std::min<size_t>((n + ((size_t)1 << v) - 1) >> v, MLHIP_MAX_SEGMENTS);
+  }
+  StreamCtx c1, c2;
+  c1.d_points = d_points_g1;
+  c2.d_points = d_points_g2;
+  c1.d_scalars = c2.d_scalars = d_scalars;
+  c1.mont = c2.mont = mont;
+  c1.n = c2.n = n;
+  c1.K = c2.K = K;
+  int rc = stream_begin<C, F1>(p1, c1, st, 1);
+  if (rc) return rc;
+  rc = stream_begin<C, F2>(p2, c2, st, 1);
+  if (rc) return rc;
+  for (int s = 0; (size_t)s * c1.seg < n; s++) {
+    rc = stream_tile<C, F1>(p1, c1, s, st, nullptr);
+    if (rc) return rc;
+    if ((size_t)(s + 1) * c1.seg >= n) {
+      // G1 is complete: its reduction and its copy to the host go ahead of G2's last accumulation, so that the host
+      // tail of the G1 result runs under it
+      rc = stream_end<C, F1>(p1, c1, st);
+      if (rc) return rc;
+    }
+    rc = stream_tile<C, F2>(p2, c2, s, st, p1);
+    if (rc) return rc;
+  }
+  return stream_end<C, F2>(p2, c2, st);
 }
 
 template <class C, class F>

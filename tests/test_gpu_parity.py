@@ -794,3 +794,54 @@ def test_msm_resident_tiles(lib, mlhip, curve, group, monkeypatch):
                 assert t["accumulate"] > 0 and t["device_total"] >= t["accumulate"], (tile, t)
                 assert plan.run(dp.data_ptr(), ds.data_ptr(), 3001, False, st) == want_head, (curve, group, name, c, tile)
             plan.close()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_shared_scalars(lib, mlhip, curve, monkeypatch):
+    """mlhip_msm_launch_shared: the G1 and the G2 MSM of one scalar vector, sorted once in the G1 plan and accumulated
+    by both -- one pass and tile by tile, uniform and skewed scalars (long buckets), infinities; plans of different
+    widths and plans on the boundary-form accumulation cannot share and must fall back to two launches."""
+    import numpy as np
+    import torch
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, g1b, g2b, _ = mlhip.sizes(cid)
+    n = 4000
+    p1 = bytearray(cref.gen_points(cid, 1, 31, 5, n))
+    p2 = bytearray(cref.gen_points(cid, 2, 32, 6, n))
+    p1[3 * g1b : 4 * g1b] = bytes(g1b)
+    p2[(n - 2) * g2b : (n - 1) * g2b] = bytes(g2b)
+    p1, p2 = bytes(p1), bytes(p2)
+    uniform = _rand_scalars(n, 4321 + cid, 252)
+    skew = np.zeros((n, 4), dtype=np.uint64)
+    skew[:, 0] = np.random.default_rng(5 + cid).integers(0, 1 << 18, size=n, dtype=np.uint64)
+    skew[::2] = skew[1]
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    d1 = torch.frombuffer(bytearray(p1), dtype=torch.uint8).to(dev)
+    d2 = torch.frombuffer(bytearray(p2), dtype=torch.uint8).to(dev)
+    for name, sc in (("uniform", uniform), ("skewed", skew)):
+        ds = torch.frombuffer(bytearray(sc.tobytes()), dtype=torch.uint8).to(dev)
+        want1 = cref.msm(cid, 1, p1, sc, n, False, 0, 8)
+        want2 = cref.msm(cid, 2, p2, sc, n, False, 0, 8)
+        for env, c1, c2 in (({}, 12, 12), ({"MLHIP_TILE_LOG2": "10"}, 12, 12), ({"MLHIP_TILE_LOG2": "9"}, 8, 8), ({}, 12, 9),
+                            ({"MLHIP_ACC32": "1"}, 12, 12)):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            a = mlhip.MsmPlan(cid, 1, n, c1)
+            b = mlhip.MsmPlan(cid, 2, n, c2)
+            for m in (n, 1777, 0, n):  # the plans are reused, also with fewer pairs and with none
+                a.launch_shared(b, d1.data_ptr(), d2.data_ptr(), ds.data_ptr(), m, False, st)
+                r1, r2 = a.finish(), b.finish()
+                if m == n:
+                    assert (r1, r2) == (want1, want2), (curve, name, env, c1, c2)
+                elif m == 0:
+                    assert r1 == bytes(g1b) and r2 == bytes(g2b)
+                else:
+                    assert r1 == cref.msm(cid, 1, p1, sc, m, False, 0, 8) and r2 == cref.msm(cid, 2, p2, sc, m, False, 0, 8)
+            a.close()
+            b.close()
+            for k in env:
+                monkeypatch.delenv(k)
