@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak against the C oracle: MSMs (all curves, G1 and G2, random n / window / scalar widths, duplicated
-and negated points, infinities) and pairing batches, for a given number of seconds.  Prints a progress line every
+and negated points, infinities) device-resident plans (one pass / tiles / the shared-scalar G1+G2 launch) and pairing batches, for a given number of
+seconds.  Prints a progress line every
 20 s; exits non-zero on the first mismatch."""
 import ctypes
 import os
@@ -55,7 +56,43 @@ while time.time() - t0 < budget:
         # half of the calls stream the pairs in a random number of segments (the library reads the switch per call)
         segs = rnd.choice([0, 0, 0, 2, 3, 5, 16])
         os.environ["MLHIP_STREAM_SEGMENTS"] = str(segs)
-        if rnd.random() < 0.15:  # the device-list entry point: 1-4 shards, all on device 0
+        mode = rnd.random()
+        if mode < 0.2:  # device-resident inputs through a plan: one pass or tiles (MLHIP_TILE_LOG2 is read per launch)
+            import torch
+
+            dev = torch.device("cuda", 0)
+            st = torch.cuda.current_stream().cuda_stream
+            tile = rnd.choice([0, 0, 7, 8, 9, 10, 11, 12])
+            os.environ["MLHIP_TILE_LOG2"] = str(tile)
+            dp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
+            ds = torch.frombuffer(bytearray(sc.tobytes()), dtype=torch.uint8).to(dev)
+            cc = c if c else 12
+            plan = _lib.MsmPlan(cid, group, n, cc)
+            if rnd.random() < 0.5:
+                got = plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st)
+            else:  # the G1 and the G2 MSM of the same scalars, sorted once
+                og = 3 - group
+                osz = g1b if og == 1 else g2b
+                opts = cref.gen_points(cid, og, rnd.getrandbits(40), rnd.getrandbits(40), n)
+                dop = torch.frombuffer(bytearray(opts), dtype=torch.uint8).to(dev)
+                other = _lib.MsmPlan(cid, og, n, cc if rnd.random() < 0.8 else max(4, cc - 1))
+                a, b = (plan, other) if group == 1 else (other, plan)
+                pa, pb = (dp, dop) if group == 1 else (dop, dp)
+                a.launch_shared(b, pa.data_ptr(), pb.data_ptr(), ds.data_ptr(), n, False, st)
+                ra, rb = a.finish(), b.finish()
+                got, got_other = (ra, rb) if group == 1 else (rb, ra)
+                if got_other != cref.msm(cid, og, opts, sc, n, False, 0, 16):
+                    print("MISMATCH shared msm (other group)", name, og, n, cc, bits, "tile", tile, "seed", seed, flush=True)
+                    sys.exit(1)
+                other.close()
+                done["shared"] = done.get("shared", 0) + 1
+            plan.close()
+            os.environ.pop("MLHIP_TILE_LOG2", None)
+            out = ctypes.create_string_buffer(got, sz)
+            done["resident"] = done.get("resident", 0) + 1
+            if tile:
+                done["tiled"] = done.get("tiled", 0) + 1
+        elif mode < 0.32:  # the device-list entry point: 1-4 shards, all on device 0
             nd = rnd.randrange(1, 5)
             devs = (ctypes.c_int * nd)(*([0] * nd))
             _lib.check(lib.mlhip_msm_multi(cid, group, devs, nd, pts, sc.tobytes(), 0, n, c, out))
