@@ -499,9 +499,18 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums_lp(const XYZZ<Fp2Field<C>
       xyzz_add_lp_ool<C>(acc, b);
     }
   }
-  lp_store_xyzz<C>(sh, pid, acc, hi);
+  // the upper half of the pairs hands its sums to the lower half first, so the tree needs PAIRS / 2 slots only (48 KB for
+  // 512 threads: twice the pairs per block, half the strided additions per pair, one more tree level)
+  if (pid >= PAIRS / 2) lp_store_xyzz<C>(sh, pid - PAIRS / 2, acc, hi);
   __syncthreads();
-  for (uint32_t s = PAIRS / 2; s > 0; s >>= 1) {
+  if (pid < PAIRS / 2) {
+    lp_load_xyzz<C>(b, sh, pid, hi);
+    xyzz_add_lp_ool<C>(acc, b);
+  }
+  __syncthreads();
+  if (pid < PAIRS / 2) lp_store_xyzz<C>(sh, pid, acc, hi);
+  __syncthreads();
+  for (uint32_t s = PAIRS / 4; s > 0; s >>= 1) {
     if (pid < s) {  // pair-uniform
       XYZZ<FL> a;
       lp_load_xyzz<C>(a, sh, pid, hi);

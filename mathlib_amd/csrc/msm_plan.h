@@ -225,8 +225,8 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
     if constexpr (kLanePairs) {
       k_chunks_lp<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
                                                                                         p->L, (X*)p->d_A, (X*)p->d_W0);
-      constexpr int RB = 256;  // 128 lane pairs x 384 B = 48 KB of LDS per block
-      k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 2) * sizeof(X), st>>>(
+      constexpr int RB = 512;  // 256 lane pairs, 128 slots x 384 B = 48 KB of LDS per block
+      k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
           (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
     } else {
       if (p->reduce28) {
