@@ -105,4 +105,37 @@ MLHIP_HD void xyzz28_madd(XYZZ28<C>& acc, bool& inf, const Affine28<C>& q_in, bo
   fp28_mul<C>(acc.zzz, acc.zzz, PPP);
 }
 
+// r = 2 p (dbl-2008-s-1, a = 0) in the carry-free form, p finite with normalized coordinates; the result is normalized,
+// or all-zero limbs (infinity) when p has order two (y = 0 mod p, however it is represented: BLS12-377's curve has such
+// a point).  Weights: U = 2Y (2), M = 3 X^2 (3, carry-propagated before it is squared), X3 = M^2 - 2S (3, propagated).
+template <class C>
+MLHIP_HD void xyzz28_dbl(XYZZ28<C>& r, const XYZZ28<C>& p) {
+  Fp28<C> U, V, W, S, M, X3, t, nW;
+  fp28_add<C>(U, p.y, p.y);
+  if (fp28_maybe_zero<C>(U) && fp28_is_zero_exact<C>(U)) {
+    fp28_zero<C>(r.x);
+    fp28_zero<C>(r.y);
+    fp28_zero<C>(r.zz);
+    fp28_zero<C>(r.zzz);
+    return;
+  }
+  fp28_sqr<C>(V, U);       // weight 2 squared
+  fp28_mul<C>(W, U, V);    // 2 x 1
+  fp28_mul<C>(S, p.x, V);  // 1 x 1
+  fp28_sqr<C>(M, p.x);
+  fp28_add<C>(t, M, M);
+  fp28_add<C>(t, t, M);     // weight 3
+  fp28_normalize<C>(M, t);  // weight 1, |value| < 3.6 p
+  fp28_sqr<C>(t, M);
+  fp28_sub<C>(t, t, S);
+  fp28_sub<C>(t, t, S);      // weight 3
+  fp28_normalize<C>(X3, t);  // weight 1
+  fp28_sub<C>(t, S, X3);     // weight 2
+  fp28_neg<C>(nW, W);
+  fp28_mul2<C>(r.y, M, t, nW, p.y);  // M (S - X3) - W Y1: 1 x 2 + 1 x 1
+  fp28_mul<C>(r.zz, V, p.zz);
+  fp28_mul<C>(r.zzz, W, p.zzz);
+  r.x = X3;
+}
+
 }  // namespace mlhip

@@ -9,9 +9,9 @@
 // as 2 x 2 = 4 <= 8; X3 = RR - PPP - 2Q (weight 4) and Y3 = V - T (weight 2) are carry-propagated once each.
 //
 // Infinity is "ZZ has all limbs zero" -- the encoding of the accumulation kernels' bucket state (msm_accumulate.h).  A
-// regular addition never produces it (ZZ3 = ZZ1 ZZ2 PP with P != 0 mod p), the exceptional cases (same x: the same
-// point or opposite points, found by the exact test fp28_is_zero_exact behind the one-multiply filter
-// fp28_maybe_zero) go through the boundary form, which decides them exactly and writes canonical zeros.
+// regular addition never produces it (ZZ3 = ZZ1 ZZ2 PP with P != 0 mod p); the exceptional cases (same x, found by the
+// exact test fp28_is_zero_exact behind the one-multiply filter fp28_maybe_zero) write it as canonical zeros: opposite
+// points directly, the same point through xyzz28_dbl, which tests 2Y = 0 exactly (a point of order two).
 #pragma once
 #include "ec28.h"
 #include "ec_quad.h"
@@ -119,27 +119,12 @@ struct QuadDevice28 {
 };
 #endif
 
-// the exceptional cases of the addition, decided exactly in the boundary form by every lane on the gathered points:
-// r = a + b where a and b share their x (the same point: doubling; opposite points: infinity).  Out of line -- it is
-// reached after empty buckets (w0 += acc right after w0 = acc) and on degenerate inputs, not on the bulk of the work.
+// the doubling that replaces the addition when both operands are the same point -- reached after empty buckets
+// (w0 += acc right after w0 = acc) and on degenerate inputs: every lane doubles the gathered point with the one-lane
+// carry-free formulas.  Out of line: its registers do not count against the addition.
 template <class C>
-MLHIP_HD_NOINLINE void quad28_add_exact(XYZZ28<C>& r, const XYZZ28<C>& a, const XYZZ28<C>& b) {
-  typedef FpField<C> F;
-  XYZZ<F> pa, pb;
-  xyzz28_to<C>(pa, a, false);
-  xyzz28_to<C>(pb, b, false);
-  xyzz_add<F>(pa, pb);
-  if (xyzz_is_inf<F>(pa)) {
-    fp28_zero<C>(r.x);
-    fp28_zero<C>(r.y);
-    fp28_zero<C>(r.zz);
-    fp28_zero<C>(r.zzz);
-  } else {
-    fp28_from_fp<C>(r.x, pa.x);
-    fp28_from_fp<C>(r.y, pa.y);
-    fp28_from_fp<C>(r.zz, pa.zz);
-    fp28_from_fp<C>(r.zzz, pa.zzz);
-  }
+MLHIP_HD_NOINLINE void quad28_dbl_slow(XYZZ28<C>& r, const XYZZ28<C>& p) {
+  xyzz28_dbl<C>(r, p);
 }
 
 // a += b; both hold coordinate `lane` of an XYZZ28 point, normalized; infinity: ZZ all limbs zero
@@ -158,11 +143,18 @@ MLHIP_HD void quad28_xyzz_add(typename B::V& a, const typename B::V& b) {
   B::sel(x, 0x3u, o, m1);
   B::sel(y, 0x3u, m1, o);
   B::sub(d, x, y);  // P | R | P | R                                                  weight 2
-  if (B::zero_mask(d) & 1u) {  // same x
-    XYZZ28<C> pa, pb, r;
-    B::gather(pa, a);
-    B::gather(pb, b);
-    quad28_add_exact<C>(r, pa, pb);
+  const unsigned zd = B::zero_mask(d);
+  if (zd & 1u) {  // same x: the same point (double it) or opposite points (infinity)
+    XYZZ28<C> pb, r;
+    if (zd & 2u) {
+      B::gather(pb, b);
+      quad28_dbl_slow<C>(r, pb);
+    } else {
+      fp28_zero<C>(r.x);
+      fp28_zero<C>(r.y);
+      fp28_zero<C>(r.zz);
+      fp28_zero<C>(r.zzz);
+    }
     B::scatter(a, r);
     return;
   }

@@ -415,6 +415,9 @@ def test_quad_lane_xyzz_add(hostmath, name):
         [P[2], neg(P[2])],
         [P[i % 5] for i in range(23)],
     ]
+    if name == "BLS12-377":  # y^2 = x^3 + 1 has a point of order two, (-1, 0): doubling it must give infinity
+        T2 = (cp.p - 1, 0)
+        cases += [[T2, T2], [P[0], T2, T2, P[1]], [T2, P[0], T2]]
     for seq in cases:
         pts = b"".join(R.g1_to_mont_bytes(cp, q) for q in seq)
         zs = b"".join(R.fp_to_mont_bytes(cp, 1 + d.below(cp.p - 1)) for _ in seq)
