@@ -336,14 +336,17 @@ def main() -> None:
         acc_ms = phase_avg.get((dom, "accumulate"), 0.0)
         acc32 = os.environ.get("MLHIP_ACC32", "") == "1"
         cname = {0: "Bn254", 1: "Bls381", 2: "Bls377"}[CURVE]
+        red32 = os.environ.get("MLHIP_REDUCE32", "") == "1"  # the boundary-form reduction: the accumulation then converts its buckets itself
         if dom == G1:
-            acc_kernel = ("k_accumulate<FpField<%s>>" if acc32 else "k_accumulate28<%s>") % cname
+            # (the carry-free reduction reads the accumulators as the kernel leaves them: the segment form of the kernel
+            # runs even for one pass)
+            acc_kernel = ("k_accumulate<FpField<%s>>" if acc32 else ("k_accumulate28<%s>" if red32 else "k_accumulate28_seg<%s>")) % cname
         else:
             acc_kernel = ("k_accumulate28_lp<%s>" if (CURVE == 1 and not acc32) else "k_accumulate_lp<%s>") % cname
         # from 2^22 (G1) / 2^23 (G2) points on the library accumulates tile by tile (msm_plan.h: resident_tiles): the
         # dominant kernel is then launched `tiles` times per MSM (its _seg form), each launch over n / tiles units
         tiles = max(1, int(round(phase_avg.get((dom, "tiles"), 1.0))))
-        if tiles > 1 and not acc32:
+        if tiles > 1 and not acc32 and "_seg<" not in acc_kernel:
             acc_kernel = acc_kernel.replace("<", "_seg<", 1)
         bytes_unit = MSM_BYTES[(CURVE, dom)]
         achieved = bytes_unit * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
@@ -370,7 +373,7 @@ def main() -> None:
         if len(groups) > 1:
             g1_ms = phase_avg.get((G1, "accumulate"), 0.0)
             g1_tiles = max(1, int(round(phase_avg.get((G1, "tiles"), 1.0))))
-            roofline["g1_kernel"] = {"kernel": ("k_accumulate28_seg<%s>" if g1_tiles > 1 else "k_accumulate28<%s>") % cname,
+            roofline["g1_kernel"] = {"kernel": ("k_accumulate28<%s>" if (red32 and g1_tiles == 1) else "k_accumulate28_seg<%s>") % cname,
                                      "avg_kernel_ms": g1_ms / g1_tiles, "launches_per_msm": g1_tiles,
                                      "achieved": MSM_BYTES[(CURVE, G1)] * n / (g1_ms * 1e-3) / 1e9 if g1_ms else 0.0}
         unit = "scalar-muls/s"
