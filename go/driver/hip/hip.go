@@ -205,6 +205,31 @@ func (c *Curve) MultiScalarMulG2(a []driver.G2, b []driver.Zr) driver.G2 {
 	return out
 }
 
+// MultiScalarMulG1G2 = (MultiScalarMul(a1, b), MultiScalarMulG2(a2, b)) for ONE scalar vector (BASELINE configs[3]: a
+// prover's G1 and G2 MSM over the same witness): the scalars travel and are sorted once, both groups accumulate from
+// the same bucket lists.  Mismatched lengths give the identities, as MultiScalarMul does (bls12-381.go:777).
+func (c *Curve) MultiScalarMulG1G2(a1 []driver.G1, a2 []driver.G2, b []driver.Zr) (driver.G1, driver.G2) {
+	n := len(a1)
+	o1, o2 := &gurvy381.G1{}, &gurvy381.G2{}
+	if len(a2) != n || len(b) != n || n == 0 {
+		return o1, o2
+	}
+	p1 := make([]bls12381.G1Affine, n)
+	p2 := make([]bls12381.G2Affine, n)
+	scalars := make([]fr.Element, n)
+	for i := 0; i < n; i++ {
+		p1[i] = a1[i].(*gurvy381.G1).G1Affine
+		p2[i] = a2[i].(*gurvy381.G2).G2Affine
+		scalars[i] = gurvy381.ZrValue(b[i])
+	}
+	check(func() C.int {
+		return C.mlhip_msm_g1g2(C.MLHIP_CURVE_BLS12_381,
+			unsafe.Pointer(&p1[0]), unsafe.Pointer(&p2[0]), unsafe.Pointer(&scalars[0]), 1, C.size_t(n), C.int(WindowC),
+			unsafe.Pointer(&o1.G1Affine), unsafe.Pointer(&o2.G2Affine))
+	})
+	return o1, o2
+}
+
 // PairingBatch returns FExp(Pairing(g2s[i], g1s[i])) for every i with one kernel launch.
 func (c *Curve) PairingBatch(g2s []driver.G2, g1s []driver.G1) []driver.Gt {
 	n := len(g1s)

@@ -95,6 +95,12 @@ int mlhip_msm_g1(int curve, const void* points, const void* scalars, int scalars
                  void* out_affine);
 int mlhip_msm_g2(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
                  void* out_affine);
+/* out_g1 = sum_i [scalars[i]] points_g1[i] and out_g2 = sum_i [scalars[i]] points_g2[i] over ONE scalar vector
+ * (additive: BASELINE configs[3]; in the reference's terms MultiScalarMul(a1, b), driver/gurvy/bls12381/bls12-381.go:766-783,
+ * and the G2 sum of g2.Mul(b[i]), :342-358, over the same b): the scalars travel and are sorted once, both groups
+ * accumulate from the same entry lists.  Same results as mlhip_msm_g1 + mlhip_msm_g2. */
+int mlhip_msm_g1g2(int curve, const void* points_g1, const void* points_g2, const void* scalars, int scalars_mont, size_t n,
+                   int window_c, void* out_g1, void* out_g2);
 
 /* out[k] = prod_{j < pairs_per_product} MillerLoop(g1[k*ppp + j], g2[k*ppp + j]); Pairing = 1, Pairing2 = 2
  * (pairs_per_product <= 4).  Pairs holding an infinity contribute 1.  NOT final-exponentiated: like gurvy's

@@ -16,13 +16,14 @@
 //   Curve::FExp(gt)                      driver/math.go:56-57                         -> mlhip_final_exp
 //   G1::Mul / Mul2 / Add / Sub / Neg     driver/math.go:249-288
 //   G2::Mul / Add, Gt::Mul / Exp / IsUnity, Zr::Plus / Minus / Mul / ...             driver/math.go:191-360
-//   additive: MultiScalarMulG2, PairingBatch, PairingProduct
+//   additive: MultiScalarMulG2, MultiScalarMulG1G2, PairingBatch, PairingProduct
 #pragma once
 #include <array>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "mlhip.h"
@@ -434,6 +435,18 @@ class Curve {
     Bytes pts, sc;
     pack(a, b, pts, sc);
     check(mlhip_msm_g2(id, pts.data(), sc.data(), scalars_mont ? 1 : 0, a.size(), window_c, out.raw.data()));
+    return out;
+  }
+  // (MultiScalarMul(a1, b), MultiScalarMulG2(a2, b)) over ONE scalar vector: one sort on the device for both groups
+  std::pair<G1, G2> MultiScalarMulG1G2(const std::vector<G1>& a1, const std::vector<G2>& a2, const std::vector<Zr>& b) const {
+    if (b.size() < a1.size() || b.size() < a2.size()) throw std::out_of_range("MultiScalarMulG1G2: fewer scalars than points");
+    std::pair<G1, G2> out(NewG1(), NewG2());
+    if (a1.size() != a2.size() || b.size() != a1.size() || a1.empty()) return out;
+    Bytes p1, p2, sc, sc2;
+    pack(a1, b, p1, sc);
+    pack(a2, b, p2, sc2);
+    check(mlhip_msm_g1g2(id, p1.data(), p2.data(), sc.data(), scalars_mont ? 1 : 0, a1.size(), window_c, out.first.raw.data(),
+                         out.second.raw.data()));
     return out;
   }
   Gt Pairing(const G2& p2, const G1& p1) const {  // Miller loop only, like gurvy (bls12-381.go:448-455)

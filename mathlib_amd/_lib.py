@@ -42,6 +42,7 @@ SYMBOLS = [
     "mlhip_msm_run",
     "mlhip_msm_launch",
     "mlhip_msm_launch_shared",
+    "mlhip_msm_g1g2",
     "mlhip_msm_finish",
     "mlhip_msm_plan_set_profiling",
     "mlhip_msm_plan_timings",
@@ -110,6 +111,7 @@ def load() -> ctypes.CDLL:
     lib.mlhip_sizes.argtypes = [ci, POINTER(sz), POINTER(sz), POINTER(sz), POINTER(sz)]
     for f in (lib.mlhip_msm_g1, lib.mlhip_msm_g2):
         f.argtypes = [ci, vp, vp, ci, sz, ci, vp]
+    lib.mlhip_msm_g1g2.argtypes = [ci, vp, vp, vp, ci, sz, ci, vp, vp]
     lib.mlhip_miller_loop.argtypes = [ci, vp, vp, sz, sz, vp]
     lib.mlhip_final_exp.argtypes = [ci, vp, sz, vp]
     lib.mlhip_pairing_batch.argtypes = [ci, vp, vp, sz, vp]

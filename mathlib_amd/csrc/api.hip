@@ -717,6 +717,25 @@ static bool plan_can_stream(const mlhip_msm_plan* p) {
   return p->aux && !(carry_free_state && !p->d_points28);
 }
 
+// the shared-scalar train on two plans; h_* = nullptr: everything is already at the d_* pointers
+static int tu_plan_shared(mlhip_msm_plan* g1, mlhip_msm_plan* g2, void* d1, void* d2, void* dsc, const void* h1, const void* h2,
+                          const void* hsc, int mont, size_t n, hipStream_t st) {
+  int rc;
+  switch (g1->curve) {
+    case MLHIP_CURVE_BN254: rc = mlhip_tu_plan_shared_Bn254(g1, g2, d1, d2, dsc, h1, h2, hsc, mont, n, st); break;
+    case MLHIP_CURVE_BLS12_381: rc = mlhip_tu_plan_shared_Bls381(g1, g2, d1, d2, dsc, h1, h2, hsc, mont, n, st); break;
+    default: rc = mlhip_tu_plan_shared_Bls377(g1, g2, d1, d2, dsc, h1, h2, hsc, mont, n, st); break;
+  }
+  if (rc) {  // as mlhip_msm_launch: drain what was queued (copies from the caller's buffers too) and leave both plans reusable
+    (void)hipStreamSynchronize(st);
+    if (g1->aux) (void)hipStreamSynchronize(g1->aux);
+    if (g2->aux) (void)hipStreamSynchronize(g2->aux);
+    (void)hipGetLastError();
+    g1->pending = g2->pending = false;
+  }
+  return rc;
+}
+
 int mlhip_msm_launch_shared(mlhip_msm_plan* g1, mlhip_msm_plan* g2, const void* d_points_g1, const void* d_points_g2,
                             const void* d_scalars, int scalars_mont, size_t n, void* stream) {
   if (!g1 || !g2) return mlhip_rt::fail(MLHIP_EINVAL, "null plan");
@@ -740,20 +759,55 @@ int mlhip_msm_launch_shared(mlhip_msm_plan* g1, mlhip_msm_plan* g2, const void* 
   HIPCHK(hipSetDevice(g1->device));
   hipStream_t st = (hipStream_t)stream;
   void *p1 = const_cast<void*>(d_points_g1), *p2 = const_cast<void*>(d_points_g2), *sc = const_cast<void*>(d_scalars);
-  int rc;
-  switch (g1->curve) {
-    case MLHIP_CURVE_BN254: rc = mlhip_tu_plan_shared_Bn254(g1, g2, p1, p2, sc, scalars_mont, n, st); break;
-    case MLHIP_CURVE_BLS12_381: rc = mlhip_tu_plan_shared_Bls381(g1, g2, p1, p2, sc, scalars_mont, n, st); break;
-    default: rc = mlhip_tu_plan_shared_Bls377(g1, g2, p1, p2, sc, scalars_mont, n, st); break;
+  return tu_plan_shared(g1, g2, p1, p2, sc, nullptr, nullptr, nullptr, scalars_mont, n, st);
+}
+
+int mlhip_msm_g1g2(int curve, const void* points_g1, const void* points_g2, const void* scalars, int scalars_mont, size_t n,
+                   int window_c, void* out_g1, void* out_g2) {
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (!out_g1 || !out_g2) return mlhip_rt::fail(MLHIP_EINVAL, "null output pointer");
+  if (n == 0) {  // the points at infinity, as for mlhip_msm_g1 / _g2
+    memset(out_g1, 0, sz.g1);
+    memset(out_g2, 0, sz.g2);
+    return 0;
   }
-  if (rc) {  // as mlhip_msm_launch: drain what was queued and leave both plans reusable
-    (void)hipStreamSynchronize(st);
-    if (g1->aux) (void)hipStreamSynchronize(g1->aux);
-    if (g2->aux) (void)hipStreamSynchronize(g2->aux);
-    (void)hipGetLastError();
-    g1->pending = g2->pending = false;
+  if (!points_g1 || !points_g2 || !scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  if (window_c == 0) window_c = pick_window(n, sz.fr_bits);
+  if (!spread_devices(n, false).empty()) {
+    // spread over the device list: every device sorts its own shard anyway -- two sharded MSMs
+    int rc = msm_host_buffers(curve, MLHIP_GROUP_G1, points_g1, scalars, scalars_mont, n, window_c, out_g1);
+    if (rc) return rc;
+    return msm_host_buffers(curve, MLHIP_GROUP_G2, points_g2, scalars, scalars_mont, n, window_c, out_g2);
   }
-  return rc;
+  int rc = ensure_device();
+  if (rc) return rc;
+  PoolEntry* e1 = pool_acquire(curve, MLHIP_GROUP_G1, window_c, n, sz.g1, rc);
+  if (!e1) return rc;
+  PoolEntry* e2 = pool_acquire(curve, MLHIP_GROUP_G2, window_c, n, sz.g2, rc);
+  if (!e2) {
+    pool_release(e1, false);
+    return rc;
+  }
+  if (plan_can_stream(e1->plan) && plan_can_stream(e2->plan)) {
+    rc = tu_plan_shared(e1->plan, e2->plan, e1->d_pts, e2->d_pts, e1->d_sc, points_g1, points_g2, scalars, scalars_mont, n,
+                        e1->stream);
+    if (!rc) rc = mlhip_msm_finish(e1->plan, out_g1, nullptr);
+    if (!rc) rc = mlhip_msm_finish(e2->plan, out_g2, nullptr);
+    if (rc) {  // whatever is still queued reads the caller's buffers: let it drain, leave the plans reusable
+      (void)hipDeviceSynchronize();
+      e1->plan->pending = e2->plan->pending = false;
+    }
+    pool_release(e2, rc != 0);
+    pool_release(e1, rc != 0);
+    return rc;
+  }
+  // a second-implementation path (MLHIP_ACC32=1 ...): nothing to share
+  pool_release(e2, false);
+  pool_release(e1, false);
+  rc = msm_host_buffers(curve, MLHIP_GROUP_G1, points_g1, scalars, scalars_mont, n, window_c, out_g1);
+  if (rc) return rc;
+  return msm_host_buffers(curve, MLHIP_GROUP_G2, points_g2, scalars, scalars_mont, n, window_c, out_g2);
 }
 
 int mlhip_msm_finish(mlhip_msm_plan* p, void* out_affine, void* out_xyzz) {

@@ -75,7 +75,8 @@ struct mlhip_msm_plan {
   int mlhip_tu_plan_stream_##NAME(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points,         \
                                   const void* h_scalars, int mont, size_t n, int segments, hipStream_t st);         \
   int mlhip_tu_plan_shared_##NAME(mlhip_msm_plan* g1, mlhip_msm_plan* g2, void* d_points_g1, void* d_points_g2,     \
-                                  void* d_scalars, int mont, size_t n, hipStream_t st);                            \
+                                  void* d_scalars, const void* h_points_g1, const void* h_points_g2,                \
+                                  const void* h_scalars, int mont, size_t n, hipStream_t st);                       \
   int mlhip_tu_pairing_##NAME(int what, const void* d_g1, const void* d_g2, size_t ppp, size_t n, const void* d_in, \
                               void* d_out, hipStream_t st);                                                         \
   int mlhip_tu_fp_mul_##NAME(const void* d_a, const void* d_b, size_t n, int repeat, void* d_out, hipStream_t st);   \

@@ -578,24 +578,40 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
 // The G1 MSM and the G2 MSM of ONE scalar vector (device-resident inputs; BASELINE configs[3], a Groth16 prover's
 // B-query): the entry lists of a tile depend on the scalars and the window geometry only, so every tile is sorted once
 // (in the G1 plan) and accumulated twice.  One stream, tile by tile: sort, G1 accumulation, G2 accumulation.
+// Host buffers (h_* != nullptr: the caller's pageable memory, staged through d_*): the scalars and the G1 points of a
+// tile travel on the G1 plan's auxiliary stream, the G2 points on the G2 plan's, under the kernels of the tile before.
 template <class C>
-int plan_stream_shared(mlhip_msm_plan* p1, mlhip_msm_plan* p2, void* d_points_g1, void* d_points_g2, void* d_scalars, int mont,
-                       size_t n, hipStream_t st) {
+int plan_stream_shared(mlhip_msm_plan* p1, mlhip_msm_plan* p2, void* d_points_g1, void* d_points_g2, void* d_scalars,
+                       const void* h_points_g1, const void* h_points_g2, const void* h_scalars, int mont, size_t n,
+                       hipStream_t st) {
   typedef FpField<C> F1;
   typedef Fp2Field<C> F2;
   if (p1->c != p2->c || p1->W != p2->W || p1->M != p2->M)
     return mlhip_rt::fail(MLHIP_EINVAL, "the two plans of a shared-scalar MSM need the same window width");
-  int K = 1;  // tiles of 2^20 pairs from 2^22 on (see resident_tiles: G1 gains from 2^22, G2 from 2^23, neither loses)
-  if (n >= ((size_t)1 << 22)) K = (int)std::min<size_t>((n + ((size_t)1 << 20) - 1) >> 20, MLHIP_MAX_SEGMENTS);
-  if (const char* e = getenv("MLHIP_TILE_LOG2")) {
-    const int v = atoi(e);
-    K = 1;
-    if (v > 0 && v < 31 && n > ((size_t)1 << v)) K = (int)std::min<size_t>((n + ((size_t)1 << v) - 1) >> v, MLHIP_MAX_SEGMENTS);
+  int K = 1;
+  if (h_scalars) {
+    // uploads to hide: segments of 2^17 pairs, as a host-buffer G2 MSM (api.hip: stream_segments)
+    K = (int)std::min<size_t>(std::max<size_t>(n >> 17, 1), MLHIP_MAX_SEGMENTS);
+    if (const char* e = getenv("MLHIP_STREAM_SEGMENTS")) {
+      const int v = atoi(e);
+      K = v < 2 ? 1 : (int)std::min<size_t>(std::min<size_t>((size_t)v, n), MLHIP_MAX_SEGMENTS);
+    }
+  } else {
+    // tiles of 2^20 pairs from 2^22 on (see resident_tiles: G1 gains from 2^22, G2 from 2^23, neither loses)
+    if (n >= ((size_t)1 << 22)) K = (int)std::min<size_t>((n + ((size_t)1 << 20) - 1) >> 20, MLHIP_MAX_SEGMENTS);
+    if (const char* e = getenv("MLHIP_TILE_LOG2")) {
+      const int v = atoi(e);
+      K = 1;
+      if (v > 0 && v < 31 && n > ((size_t)1 << v)) K = (int)std::min<size_t>((n + ((size_t)1 << v) - 1) >> v, MLHIP_MAX_SEGMENTS);
+    }
   }
   StreamCtx c1, c2;
   c1.d_points = d_points_g1;
   c2.d_points = d_points_g2;
   c1.d_scalars = c2.d_scalars = d_scalars;
+  c1.h_points = h_points_g1;
+  c2.h_points = h_points_g2;
+  c1.h_scalars = h_scalars;  // uploaded once, by the G1 plan's tiles
   c1.mont = c2.mont = mont;
   c1.n = c2.n = n;
   c1.K = c2.K = K;

@@ -19,8 +19,9 @@ int mlhip_tu_plan_stream_Bls377(mlhip_msm_plan* p, void* d_points, void* d_scala
   return plan_stream<Bls377, Fp2Field<Bls377>>(p, d_points, d_scalars, h_points, h_scalars, mont, n, segments, st);
 }
 int mlhip_tu_plan_shared_Bls377(mlhip_msm_plan* g1, mlhip_msm_plan* g2, void* d_points_g1, void* d_points_g2, void* d_scalars,
-                            int mont, size_t n, hipStream_t st) {
-  return plan_stream_shared<Bls377>(g1, g2, d_points_g1, d_points_g2, d_scalars, mont, n, st);
+                            const void* h_points_g1, const void* h_points_g2, const void* h_scalars, int mont, size_t n,
+                            hipStream_t st) {
+  return plan_stream_shared<Bls377>(g1, g2, d_points_g1, d_points_g2, d_scalars, h_points_g1, h_points_g2, h_scalars, mont, n, st);
 }
 int mlhip_tu_scalar_mul_Bls377(int group, const void* d_points, size_t point_stride, const void* d_scalars, int mont,
                               size_t n, void* d_out, hipStream_t st) {

@@ -395,6 +395,19 @@ class Curve:
         check(load().mlhip_msm_g2(self.id, pts, self._scalars(b), 1 if self.scalars_mont else 0, len(a), self.window_c, out))
         return G2(out.raw, self)
 
+    def MultiScalarMulG1G2(self, a1: Sequence[G1], a2: Sequence[G2], b: Sequence[Zr]):
+        """(MultiScalarMul(a1, b), MultiScalarMulG2(a2, b)) for ONE scalar vector: sorted once on the device, both groups
+        accumulate from the same lists (additive; BASELINE configs[3]).  Same length rules as MultiScalarMul."""
+        if len(b) < len(a1) or len(b) < len(a2):
+            raise IndexError("MultiScalarMulG1G2: fewer scalars than points")
+        if len(a1) != len(a2) or len(b) != len(a1):
+            return self.NewG1(), self.NewG2()
+        o1 = ctypes.create_string_buffer(self.g1_bytes)
+        o2 = ctypes.create_string_buffer(self.g2_bytes)
+        check(load().mlhip_msm_g1g2(self.id, b"".join(p.raw for p in a1), b"".join(p.raw for p in a2), self._scalars(b),
+                                    1 if self.scalars_mont else 0, len(a1), self.window_c, o1, o2))
+        return G1(o1.raw, self), G2(o2.raw, self)
+
     def NewBases(self, points: Sequence[G1]) -> "Bases":
         """Upload a G1 point table once; Bases.MultiScalarMul(scalars) then moves only the scalars."""
         return Bases(self, points)

@@ -167,6 +167,14 @@ static void runPairingTest(const Curve& c, const G2& g2, uint64_t& st) {
   G2 sum = g2.Mul(r1);
   sum.Add(g2.Mul(r2));
   EXPECT(c.MultiScalarMulG2({g2, g2}, {r1, r2}).Equals(sum));
+  {  // the shared-scalar call = the two reference-shaped calls; mismatched lengths give the identities
+    G1 g1 = c.GenG1();
+    auto both = c.MultiScalarMulG1G2({g1, g1.Mul(r2)}, {g2, g2.Mul(r1)}, {r1, r2});
+    EXPECT(both.first.Equals(c.MultiScalarMul({g1, g1.Mul(r2)}, {r1, r2})));
+    EXPECT(both.second.Equals(c.MultiScalarMulG2({g2, g2.Mul(r1)}, {r1, r2})));
+    auto none = c.MultiScalarMulG1G2({g1}, {g2}, {r1, r2});
+    EXPECT(none.first.IsInfinity() && none.second.IsInfinity());
+  }
   // G2 wire round trips (math_test.go:511-589 for G2)
   EXPECT(c.NewG2FromBytes(sum.ToBytes()).Equals(sum));
   EXPECT(c.NewG2FromCompressed(sum.Compressed()).Equals(sum));

@@ -100,6 +100,21 @@ def test_PairingBatch_equals_elementwise(curve):
     assert out[5].IsUnity()
 
 
+def test_MultiScalarMulG1G2(curve):
+    """the additive shared-scalar call equals the two reference-shaped calls, including the length rules"""
+    c = curve
+    n = 37
+    g1s = [c.GenG1().Mul(c.NewRandomZr(c._rng)) for _ in range(n - 1)] + [c.NewG1()]
+    g2s = [c._gen_g2.Mul(c.NewRandomZr(c._rng)) for _ in range(n)]
+    zrs = [c.NewRandomZr(c._rng) for _ in range(n)]
+    r1, r2 = c.MultiScalarMulG1G2(g1s, g2s, zrs)
+    assert r1.Equals(c.MultiScalarMul(g1s, zrs)) and r2.Equals(c.MultiScalarMulG2(g2s, zrs))
+    e1, e2 = c.MultiScalarMulG1G2(g1s[:3], g2s[:3], zrs[:5])  # more scalars than points: identity, like MultiScalarMul
+    assert e1.IsInfinity() and e2.Equals(c.NewG2())
+    with pytest.raises(IndexError):
+        c.MultiScalarMulG1G2(g1s, g2s, zrs[:2])
+
+
 def test_MultiScalarMulG2(curve):
     c = curve
     g2s = [c._gen_g2.Mul(c.NewRandomZr(c._rng)) for _ in range(4)]

@@ -4,6 +4,7 @@ Mirrors the reference's own checks: MSM == sum of scalar multiples (math_test.go
 FExp(Pairing(..)) equalities (math_test.go:423-470), serialized-byte comparison (math_test.go:879-911).
 """
 import ctypes
+import os
 
 import pytest
 
@@ -845,3 +846,38 @@ def test_msm_shared_scalars(lib, mlhip, curve, monkeypatch):
             b.close()
             for k in env:
                 monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_g1g2_host_buffers(lib, mlhip, curve, monkeypatch):
+    """mlhip_msm_g1g2 (host slices, one scalar vector for the G1 and the G2 MSM) equals the oracle's two MSMs: one pass,
+    forced segments (ragged), and a size the library streams by itself; n = 0 gives both identities."""
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, g1b, g2b, _ = mlhip.sizes(cid)
+
+    def run(p1, p2, sc, n, c):
+        o1, o2 = ctypes.create_string_buffer(g1b), ctypes.create_string_buffer(g2b)
+        mlhip.check(lib.mlhip_msm_g1g2(cid, p1, p2, sc.tobytes() if n else None, 0, n, c, o1, o2))
+        return o1.raw, o2.raw
+
+    n = 4000
+    p1 = cref.gen_points(cid, 1, 71, 3, n)
+    p2 = cref.gen_points(cid, 2, 72, 4, n)
+    sc = _rand_scalars(n, 99 + cid, 252)
+    want = (cref.msm(cid, 1, p1, sc, n, False, 0, 8), cref.msm(cid, 2, p2, sc, n, False, 0, 8))
+    assert run(p1, p2, sc, n, 0) == want
+    for seg in ("3", "7"):
+        monkeypatch.setenv("MLHIP_STREAM_SEGMENTS", seg)
+        assert run(p1, p2, sc, n, 11) == want, (curve, seg)
+    monkeypatch.delenv("MLHIP_STREAM_SEGMENTS")
+    assert run(None, None, sc, 0, 0) == (bytes(g1b), bytes(g2b))
+    if curve == "BLS12-381":  # 2 segments of 2^17 pairs chosen by the library
+        n = (1 << 18) + 5
+        p1 = cref.gen_points(cid, 1, 73, 3, n)
+        p2 = cref.gen_points(cid, 2, 74, 4, n)
+        sc = _rand_scalars(n, 100 + cid, 252)
+        threads = max(1, min(64, len(os.sched_getaffinity(0))))
+        assert run(p1, p2, sc, n, 16) == (cref.msm(cid, 1, p1, sc, n, False, 16, threads), cref.msm(cid, 2, p2, sc, n, False, 16, threads))
