@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MLHIP_LIB") or os.path.join(HERE, "libmlhip.so")
 
 CURVE_BN254, CURVE_BLS12_381, CURVE_BLS12_377 = 0, 1, 2
 GROUP_G1, GROUP_G2 = 1, 2
+EINVAL = -1
 ENODEVICE = -2
 
 # every symbol include/mlhip.h declares (tests/test_abi.py checks the library exports them all)

@@ -846,6 +846,18 @@ def test_msm_shared_scalars(lib, mlhip, curve, monkeypatch):
             b.close()
             for k in env:
                 monkeypatch.delenv(k)
+    # argument checks: the plans in the wrong order, a plan with a launch still pending, more pairs than a plan holds
+    a, b = mlhip.MsmPlan(cid, 1, n, 12), mlhip.MsmPlan(cid, 2, 100, 12)
+    args = (ctypes.c_void_p(d1.data_ptr()), ctypes.c_void_p(d2.data_ptr()), ctypes.c_void_p(ds.data_ptr()), 0)
+    assert lib.mlhip_msm_launch_shared(b._h, a._h, *args, 10, ctypes.c_void_p(st)) == mlhip.EINVAL
+    assert lib.mlhip_msm_launch_shared(a._h, b._h, *args, 101, ctypes.c_void_p(st)) == mlhip.EINVAL
+    a.launch(d1.data_ptr(), ds.data_ptr(), 50, False, st)
+    assert lib.mlhip_msm_launch_shared(a._h, b._h, *args, 50, ctypes.c_void_p(st)) == mlhip.EINVAL
+    assert a.finish() == cref.msm(cid, 1, p1, sc, 50, False, 0, 8)  # the pending launch is untouched
+    a.launch_shared(b, d1.data_ptr(), d2.data_ptr(), ds.data_ptr(), 100, False, st)
+    assert a.finish() == cref.msm(cid, 1, p1, sc, 100, False, 0, 8) and b.finish() == cref.msm(cid, 2, p2, sc, 100, False, 0, 8)
+    a.close()
+    b.close()
 
 
 @pytest.mark.parametrize("curve", CURVES)
