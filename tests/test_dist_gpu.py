@@ -75,3 +75,37 @@ def test_gpu_shards_combine_to_the_single_msm():
     for r in range(world):
         ok, msgs = ret.get(r, (False, ["rank %d did not report" % r]))
         assert ok, msgs
+
+
+def _rccl_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from mathlib_amd import dist as mdist
+
+    ok = True
+    for rep in range(3):  # the staging tensors are created once and reused
+        for nb in (96, 288):
+            local = bytes((7 * i + rep + nb) & 255 for i in range(nb))
+            ok &= mdist._all_gather_bytes(local, None) == local * world
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_over_rccl_one_rank():
+    """The exchange step's device branch (pinned staging -> all-gather on RCCL -> pinned staging) with the nccl backend:
+    one rank, because this box has one GPU and RCCL wants one device per rank -- the collective, the stream ordering
+    around it and the buffer reuse are the ones every rank of an N-GPU run executes."""
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
+    assert ret.get(0, False)
