@@ -273,4 +273,86 @@ MLHIP_HD void xyzz28_lp_madd(XYZZ28L<typename B::V>& acc, bool& inf, const Affin
   acc.zzz = t;
 }
 
+// ---- full addition XYZZ + XYZZ (add-2008-s) for the bucket reduction --------------------------------------------------
+// the exceptional cases (same x: doubling or cancellation; decided exactly), every lane on the rebuilt Fp2 points
+template <class C, class B>
+MLHIP_HD_NOINLINE void xyzz28_lp_add_exact(XYZZ28L<typename B::V>& acc, bool& inf, const XYZZ28L<typename B::V>& q) {
+  typedef Fp2Field<C> F2;
+  XYZZ<F2> a, b;
+  auto to2 = [](Fp2<C>& out, const typename B::V& v) {
+    Fp<C> own[B::LANES];
+    MLHIP_LP28_EACH(B, fp28_to_fp<C>(own[li_], B::at(v, li_)));
+    B::gather(out, own);
+  };
+  auto from2 = [](typename B::V& v, const Fp2<C>& in) {
+    Fp<C> own[B::LANES];
+    B::scatter(own, in);
+    MLHIP_LP28_EACH(B, fp28_from_fp<C>(B::at(v, li_), own[li_]));
+  };
+  to2(a.x, acc.x);
+  to2(a.y, acc.y);
+  to2(a.zz, acc.zz);
+  to2(a.zzz, acc.zzz);
+  to2(b.x, q.x);
+  to2(b.y, q.y);
+  to2(b.zz, q.zz);
+  to2(b.zzz, q.zzz);
+  xyzz_add<F2>(a, b);
+  inf = xyzz_is_inf<F2>(a);
+  if (!inf) {
+    from2(acc.x, a.x);
+    from2(acc.y, a.y);
+    from2(acc.zz, a.zz);
+    from2(acc.zzz, a.zzz);
+  }
+}
+
+// acc += q, both finite-or-flagged XYZZ28L with normalized coordinates; pair-uniform control flow.  12 dual + 2 single
+// products per lane and four carry propagations (P, R, X3, Y3: the dual product needs w_a w_b <= 4, the square w = 1).
+template <class C, class B>
+MLHIP_HD void xyzz28_lp_add(XYZZ28L<typename B::V>& acc, bool& inf, const XYZZ28L<typename B::V>& q, bool q_inf) {
+  typedef typename B::V V;
+  if (q_inf) return;
+  if (inf) {
+    acc = q;
+    inf = false;
+    return;
+  }
+  V U1, U2, S1, S2, P, R, PP, PPP, Q, X3, t, e, Vv, T;
+  lp28_mul<C, B>(U1, acc.x, q.zz);
+  lp28_mul<C, B>(U2, q.x, acc.zz);
+  lp28_mul<C, B>(S1, acc.y, q.zzz);
+  lp28_mul<C, B>(S2, q.y, acc.zzz);
+  lp28_sub<C, B>(t, U2, U1);
+  lp28_normalize<C, B>(P, t);
+  lp28_sub<C, B>(t, S2, S1);
+  lp28_normalize<C, B>(R, t);
+  if (lp28_is_zero_exact<C, B>(P)) {
+    XYZZ28L<V> ta = acc, tq = q;  // cold-path copies: keep the caller's values in registers
+    bool ti = inf;
+    xyzz28_lp_add_exact<C, B>(ta, ti, tq);
+    acc = ta;
+    inf = ti;
+    return;
+  }
+  lp28_sqr<C, B>(PP, P);
+  lp28_mul<C, B>(PPP, P, PP);
+  lp28_mul<C, B>(Q, U1, PP);
+  lp28_sqr<C, B>(t, R);
+  lp28_sub<C, B>(t, t, PPP);
+  lp28_sub<C, B>(t, t, Q);
+  lp28_sub<C, B>(t, t, Q);
+  lp28_normalize<C, B>(X3, t);
+  lp28_sub<C, B>(e, Q, X3);       // weight 2
+  lp28_mul<C, B>(Vv, R, e);       // 1 x 2
+  lp28_mul<C, B>(T, S1, PPP);     // 1 x 1
+  lp28_sub<C, B>(t, Vv, T);
+  lp28_normalize<C, B>(acc.y, t);
+  acc.x = X3;
+  lp28_mul<C, B>(t, acc.zz, q.zz);
+  lp28_mul<C, B>(acc.zz, t, PP);
+  lp28_mul<C, B>(t, acc.zzz, q.zzz);
+  lp28_mul<C, B>(acc.zzz, t, PPP);
+}
+
 }  // namespace mlhip

@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     return;
   }
-  if (cnt == 0 && !first && !last) return;
+  const bool to_boundary = last && !(flags & MLHIP_SEG_KEEP28);
+  if (cnt == 0 && !first && !to_boundary) return;
   XYZZ28L<Fp28<C>> acc;
   bool inf = true;
   if (!first) {
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
       p = pn;
     }
   }
-  if (last) {
+  if (to_boundary) {
     XYZZ<Fp2LField<C>> r;
     if (inf) {
       xyzz_set_inf<Fp2LField<C>>(r);
@@ -396,7 +397,8 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_g2(const uint32_t*
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
   const uint32_t nbig = *big_count;
-  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0;
+  const bool last = (flags & MLHIP_SEG_LAST) != 0 && !(flags & MLHIP_SEG_KEEP28);
   for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
     const uint32_t g = big_list[bi];
     XYZZ<F> sum;
@@ -521,6 +523,111 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums_lp(const XYZZ<Fp2Field<C>
     __syncthreads();
   }
   if (pid == 0) lp_store_xyzz<C>(out, blockIdx.x, [&] { XYZZ<FL> a; lp_load_xyzz<C>(a, sh, 0, hi); return a; }(), hi);
+}
+
+// ---- the G2 reduction on the carry-free bucket state (BLS12-381; ec28_lp.h: xyzz28_lp_add) -----------------------------
+// As k_chunks_q28 / k_masked_sums_q28 for G1: the buckets come as the accumulation kernel keeps them (two XYZZ28L per
+// bucket, one per lane; ZZ = 0 limbs in both for an empty bucket), the chunk sums stay in that form, the W x nsel sums that
+// travel to the host leave in the boundary form.
+template <class C>
+__device__ __noinline__ void xyzz28_lp_add_ool(XYZZ28L<Fp28<C>>& acc, bool& inf, const XYZZ28L<Fp28<C>>& q, bool q_inf) {
+  xyzz28_lp_add<C, PairDevice<C>>(acc, inf, q, q_inf);
+}
+template <class C>
+__device__ __forceinline__ bool lp28_load_state(XYZZ28L<Fp28<C>>& r, const XYZZ28L<Fp28<C>>* src, size_t idx, int hi) {
+  r = src[2 * idx + hi];
+  return lp28_all_zero<C, PairDevice<C>>(r.zz);  // infinity
+}
+template <class C>
+__device__ __forceinline__ void lp28_store_state(XYZZ28L<Fp28<C>>* dst, size_t idx, XYZZ28L<Fp28<C>> r, bool inf, int hi) {
+  if (inf) {
+#pragma unroll
+    for (int i = 0; i < C::N28; i++) r.x.l[i] = r.y.l[i] = r.zz.l[i] = r.zzz.l[i] = 0;
+  }
+  dst[2 * idx + hi] = r;
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_chunks_lp28(const XYZZ28L<Fp28<C>>* __restrict__ buckets, size_t n_chunks, int l_eff,
+                                                     XYZZ28L<Fp28<C>>* __restrict__ A, XYZZ28L<Fp28<C>>* __restrict__ W0) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t g = t >> 1;
+  if (g >= n_chunks) return;
+  const int hi = (int)(threadIdx.x & 1u);
+  XYZZ28L<Fp28<C>> acc, w0, b;
+  bool acc_inf = true, w0_inf = true;
+  for (int i = l_eff - 1; i >= 1; i--) {
+    const bool b_inf = lp28_load_state<C>(b, buckets, g * (size_t)l_eff + i, hi);
+    xyzz28_lp_add_ool<C>(acc, acc_inf, b, b_inf);
+    xyzz28_lp_add_ool<C>(w0, w0_inf, acc, acc_inf);
+  }
+  const bool b_inf = lp28_load_state<C>(b, buckets, g * (size_t)l_eff, hi);
+  xyzz28_lp_add_ool<C>(acc, acc_inf, b, b_inf);
+  lp28_store_state<C>(A, g, acc, acc_inf, hi);
+  lp28_store_state<C>(W0, g, w0, w0_inf, hi);
+}
+
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_masked_sums_lp28(const XYZZ28L<Fp28<C>>* __restrict__ A,
+                                                            const XYZZ28L<Fp28<C>>* __restrict__ W0, uint32_t T, int nsel,
+                                                            XYZZ<Fp2Field<C>>* __restrict__ out) {
+  typedef XYZZ28L<Fp28<C>> X;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  X* sh = reinterpret_cast<X*>(smem);  // PAIRS / 2 slots of two lane entries
+  constexpr uint32_t PAIRS = BLOCK / 2;
+  const uint32_t pid = threadIdx.x >> 1;
+  const int hi = (int)(threadIdx.x & 1u);
+  const uint32_t w = blockIdx.x / nsel;
+  const int sel = blockIdx.x % nsel;
+  const X* src = (sel < 2 ? W0 : A) + (size_t)2 * w * T;
+  X acc, b;
+  bool inf = true;
+  if (sel < 4) {
+    const uint32_t half = (T + 1) / 2;
+    const uint32_t lo = (sel & 1) ? half : 0u, hi_t = (sel & 1) ? T : half;
+    for (uint32_t t = lo + pid; t < hi_t; t += PAIRS) {
+      const bool b_inf = lp28_load_state<C>(b, src, t, hi);
+      xyzz28_lp_add_ool<C>(acc, inf, b, b_inf);
+    }
+  } else {
+    const int k = sel - 4;
+    const uint32_t lowmask = (1u << k) - 1u;
+    for (uint32_t j = pid; j < T / 2; j += PAIRS) {
+      const uint32_t t = ((j >> k) << (k + 1)) | (1u << k) | (j & lowmask);
+      const bool b_inf = lp28_load_state<C>(b, src, t, hi);
+      xyzz28_lp_add_ool<C>(acc, inf, b, b_inf);
+    }
+  }
+  // the upper half of the pairs hands its sums to the lower half, then a tree over PAIRS / 2 slots
+  if (pid >= PAIRS / 2) lp28_store_state<C>(sh, pid - PAIRS / 2, acc, inf, hi);
+  __syncthreads();
+  if (pid < PAIRS / 2) {
+    const bool b_inf = lp28_load_state<C>(b, sh, pid, hi);
+    xyzz28_lp_add_ool<C>(acc, inf, b, b_inf);
+  }
+  __syncthreads();
+  if (pid < PAIRS / 2) lp28_store_state<C>(sh, pid, acc, inf, hi);
+  __syncthreads();
+  for (uint32_t s = PAIRS / 4; s > 0; s >>= 1) {
+    if (pid < s) {  // pair-uniform
+      const bool b_inf = lp28_load_state<C>(b, sh, pid + s, hi);
+      xyzz28_lp_add_ool<C>(acc, inf, b, b_inf);
+      lp28_store_state<C>(sh, pid, acc, inf, hi);
+    }
+    __syncthreads();
+  }
+  if (pid == 0) {
+    XYZZ<Fp2LField<C>> r;
+    if (inf) {
+      xyzz_set_inf<Fp2LField<C>>(r);
+    } else {
+      fp28_to_fp<C>(r.x.v, acc.x);
+      fp28_to_fp<C>(r.y.v, acc.y);
+      fp28_to_fp<C>(r.zz.v, acc.zz);
+      fp28_to_fp<C>(r.zzz.v, acc.zzz);
+    }
+    lp_store_xyzz<C>(out, blockIdx.x, r, hi);
+  }
 }
 
 }  // namespace mlhip

@@ -89,13 +89,21 @@ int plan_alloc(mlhip_msm_plan* p) {
     // G2 in the carry-free form: BLS12-381 only (-14 % accumulation time); u^2 = -5 does not fit the weight budget
     // (BLS12-377) and the 10-limb BN254 form gains nothing over its 8 saturated limbs on lane pairs
     const char* acc32 = getenv("MLHIP_ACC32");
-    if (!(acc32 && acc32[0] == '1')) HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(AffineG2_28<typename F::Curve>)));
+    if (!(acc32 && acc32[0] == '1')) {
+      HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(AffineG2_28<typename F::Curve>)));
+      // ... and the lane-pair reduction reads the accumulators as the kernel leaves them (MLHIP_REDUCE32=1: boundary form)
+      const char* red32 = getenv("MLHIP_REDUCE32");
+      p->reduce28 = !(red32 && red32[0] == '1');
+      if (p->reduce28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * 2 * sizeof(XYZZ28L<Fp28<typename F::Curve>>)));
+    }
   }
   HIPCHK(hipMalloc(&p->d_buckets, nbuckets * p->xyzz_size));
   {
     size_t chunk_size = p->xyzz_size;
     if constexpr (std::is_same<F, FpField<typename F::Curve>>::value)
       chunk_size = std::max(chunk_size, sizeof(XYZZ28<typename F::Curve>));
+    else
+      chunk_size = std::max(chunk_size, 2 * sizeof(XYZZ28L<Fp28<typename F::Curve>>));
     HIPCHK(hipMalloc(&p->d_A, (size_t)p->W * p->T * chunk_size));
     HIPCHK(hipMalloc(&p->d_W0, (size_t)p->W * p->T * chunk_size));
   }
@@ -223,11 +231,25 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
   {
     size_t n_chunks = (size_t)p->W * p->T;
     if constexpr (kLanePairs) {
-      k_chunks_lp<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
-                                                                                        p->L, (X*)p->d_A, (X*)p->d_W0);
-      constexpr int RB = 512;  // 256 lane pairs, 128 slots x 384 B = 48 KB of LDS per block
-      k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
-          (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      bool done28 = false;
+      if constexpr (C::BETA == -1 && C::N28 == 14) {
+        if (p->reduce28) {
+          typedef XYZZ28L<Fp28<C>> X28;
+          k_chunks_lp28<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>(
+              (const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
+          constexpr int RB = 512;  // 256 lane pairs, 128 slots x 448 B = 56 KB of LDS per block
+          k_masked_sums_lp28<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * 2 * sizeof(X28), st>>>(
+              (const X28*)p->d_A, (const X28*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+          done28 = true;
+        }
+      }
+      if (!done28) {
+        k_chunks_lp<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                          p->L, (X*)p->d_A, (X*)p->d_W0);
+        constexpr int RB = 512;  // 256 lane pairs, 128 slots x 384 B = 48 KB of LDS per block
+        k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
+            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      }
     } else {
       if (p->reduce28) {
         // the accumulation left its carry-free bucket state in d_state28 (MLHIP_SEG_KEEP28)
@@ -346,9 +368,19 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
       if constexpr (C::BETA == -1) {
         if (p->d_points28) {
           HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
-          k_accumulate28_lp<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-              (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
-              big_threshold, p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
+          if constexpr (C::N28 == 14) {
+            if (p->reduce28) {  // one segment that is first and last, leaving the raw accumulators for k_chunks_lp28
+              k_accumulate28_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+                  (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+                  big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28,
+                  MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
+              done28 = true;
+            }
+          }
+          if (!done28)
+            k_accumulate28_lp<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+                (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+                big_threshold, p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
           done28 = true;
         }
       }
@@ -381,6 +413,13 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
         if (p->reduce28) {
           k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
               p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28,
+              MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
+          folded = true;
+        }
+      } else if constexpr (C::BETA == -1 && C::N28 == 14) {
+        if (p->reduce28 && p->d_points28) {
+          k_accumulate_big_seg_g2<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+              p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28L<Fp28<C>>*)p->d_state28,
               MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
           folded = true;
         }
@@ -470,7 +509,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   const size_t off = (size_t)s * cx.seg;
   const size_t len = std::min(cx.seg, cx.n - off);
   const bool first = off == 0, last = off + len >= cx.n;
-  const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0) | (!kG2 && p->reduce28 ? MLHIP_SEG_KEEP28 : 0);
+  const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0) | (!kBoundary && p->reduce28 ? MLHIP_SEG_KEEP28 : 0);
   const char* hp = (const char*)cx.h_points;
   const char* hs = (const char*)cx.h_scalars;
   char* dsc = (char*)cx.d_scalars + off * 32;

@@ -313,6 +313,63 @@ struct Ops {
     memcpy(out, &a, sizeof(A1));
     return 0;
   }
+  // G2 full additions in the carry-free lane-pair form (ec28_lp.h: xyzz28_lp_add): fold XYZZ points given as affine
+  // inputs scaled by per-point z in Fp2 (so that ZZ != 1)
+  static int add28_lp_chain(const void* pts, const void* zs, int n, void* out) {
+    if constexpr (C::BETA == -1) {
+      typedef PairHost<C> B;
+      typedef Fp2Field<C> F2;
+      const A2* p = (const A2*)pts;
+      const Fp2<C>* z = (const Fp2<C>*)zs;
+      XYZZ28L<typename B::V> acc;
+      bool inf = true;
+      for (int i = 0; i < n; i++) {
+        X2 q;
+        xyzz_from_affine<F2>(q, p[i]);
+        const bool q_inf = xyzz_is_inf<F2>(q);
+        XYZZ28L<typename B::V> b;
+        if (!q_inf) {
+          if (!F2::is_zero(z[i])) {
+            Fp2<C> z2, z3;
+            F2::sqr(z2, z[i]);
+            F2::mul(z3, z2, z[i]);
+            F2::mul(q.x, q.x, z2);
+            F2::mul(q.y, q.y, z3);
+            q.zz = z2;
+            q.zzz = z3;
+          }
+          fp28_from_fp<C>(b.x.v[0], q.x.c0);
+          fp28_from_fp<C>(b.x.v[1], q.x.c1);
+          fp28_from_fp<C>(b.y.v[0], q.y.c0);
+          fp28_from_fp<C>(b.y.v[1], q.y.c1);
+          fp28_from_fp<C>(b.zz.v[0], q.zz.c0);
+          fp28_from_fp<C>(b.zz.v[1], q.zz.c1);
+          fp28_from_fp<C>(b.zzz.v[0], q.zzz.c0);
+          fp28_from_fp<C>(b.zzz.v[1], q.zzz.c1);
+        }
+        xyzz28_lp_add<C, B>(acc, inf, b, q_inf);
+      }
+      X2 a;
+      if (inf) {
+        xyzz_set_inf<F2>(a);
+      } else {
+        fp28_to_fp<C>(a.x.c0, acc.x.v[0]);
+        fp28_to_fp<C>(a.x.c1, acc.x.v[1]);
+        fp28_to_fp<C>(a.y.c0, acc.y.v[0]);
+        fp28_to_fp<C>(a.y.c1, acc.y.v[1]);
+        fp28_to_fp<C>(a.zz.c0, acc.zz.v[0]);
+        fp28_to_fp<C>(a.zz.c1, acc.zz.v[1]);
+        fp28_to_fp<C>(a.zzz.c0, acc.zzz.v[0]);
+        fp28_to_fp<C>(a.zzz.c1, acc.zzz.v[1]);
+      }
+      A2 r;
+      xyzz_to_affine<F2>(r, a);
+      memcpy(out, &r, sizeof(A2));
+      return 0;
+    } else {
+      return -2;
+    }
+  }
   // G2 bucket accumulation in the carry-free lane-pair form (ec28_lp.h) through the host emulation backend
   static int madd28_lp_chain(const void* pts, const uint8_t* neg, int n, void* out) {
     if constexpr (C::BETA == -1) {
@@ -494,6 +551,7 @@ int hm_fp28_op(int curve, int op, const void* a, const void* b, const void* c, c
 int hm_madd28_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_chain(pts, neg, n, out)) }
 int hm_quad_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, quad_chain(pts, zs, n, out)) }
 int hm_quad28_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, quad28_chain(pts, zs, n, out)) }
+int hm_add28_lp_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, add28_lp_chain(pts, zs, n, out)) }
 int hm_madd28_lp_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_lp_chain(pts, neg, n, out)) }
 int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g2dec(w, compressed, subgroup, out)) }
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }

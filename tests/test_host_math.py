@@ -459,6 +459,16 @@ def test_madd28_lane_pair_g2_accumulation(hostmath, name):
         out = ctypes.create_string_buffer(4 * n)
         assert L.hm_madd28_lp_chain(cid, pts, neg, len(seq), out) == 0
         assert out.raw == R.g2_to_mont_bytes(cp, want)
+    # the full addition of the carry-free G2 reduction (xyzz28_lp_add): operands with random Z, doubling, cancellation
+    for seq in cases:
+        pts = b"".join(R.g2_to_mont_bytes(cp, R.g2_neg(cp, q) if s else q) for q, s in seq)
+        zs = b"".join(R.fp_to_mont_bytes(cp, 1 + d.below(cp.p - 1)) + R.fp_to_mont_bytes(cp, d.below(cp.p)) for _ in seq)
+        want = None
+        for q, s in seq:
+            want = R.g2_add(cp, want, R.g2_neg(cp, q) if s else q)
+        out = ctypes.create_string_buffer(4 * n)
+        assert L.hm_add28_lp_chain(cid, pts, zs, len(seq), out) == 0
+        assert out.raw == R.g2_to_mont_bytes(cp, want)
 
 
 @pytest.mark.parametrize("name", list(R.CURVES))
