@@ -638,10 +638,12 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
   p->max_n = max_n;
   p->M = 1u << (window_c - 1);
   // buckets per level-1 reduction chunk: 16 for G1 (the quad-lane kernels are bound by work, and a longer chunk
-  // halves the second level), 8 for G2 and for tiny windows
+  // halves the second level), 8 for G2 on the boundary-form curves and for tiny windows
   // (and for small bucket sets, where the chunk pass is a dependent chain rather than work: 2^12 points, c = 13:
   // reduction 0.25 -> 0.22 ms)
-  p->lgL = (group == MLHIP_GROUP_G1 && p->M >= 256 && (size_t)p->W * p->M >= ((size_t)1 << 17)) ? 4 : 3;
+  // BLS12-381 G2 (carry-free lane-pair reduction): 16 as well -- reduction 1.43 -> 1.31 ms at c = 16
+  const bool chunks16 = group == MLHIP_GROUP_G1 || curve == MLHIP_CURVE_BLS12_381;
+  p->lgL = (chunks16 && p->M >= 256 && (size_t)p->W * p->M >= ((size_t)1 << 17)) ? 4 : 3;
   if (const char* e = getenv("MLHIP_CHUNK_LOG2")) {
     int v = atoi(e);
     if (v >= 1 && v <= 6 && (1u << v) <= p->M) p->lgL = v;
