@@ -8,6 +8,7 @@
 #include "msm_body.h"
 #include "fp2_lanes.h"
 #include "fp2_lanes28.h"
+#include "pairing_quad.h"
 #include "pairing.h"
 
 namespace mlhip {
@@ -187,6 +188,54 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp28(const Affine<F
   }
 }
 
+// ---- one pairing per QUAD of lanes (pairing_quad.h; BLS12-381, carry-free element): pair A of a quad carries the c0 half
+// and pair B the c1 half of every Fp12 value.  WHAT: 0 = Miller loop of one pair, 1 = final exponentiation, 2 = both.
+template <class C, int WHAT>
+__global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_q28(const Affine<FpField<C>>* __restrict__ g1,
+                                                                 const Affine<Fp2Field<C>>* __restrict__ g2, size_t n,
+                                                                 const Fp12<C>* __restrict__ in, Fp12<C>* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = t >> 2;  // the four lanes of a quad share i: quad-uniform exit
+  if (i >= n) return;
+  typedef Fp2L28<C> E2;
+  const int hi = lane_is_hi() ? 1 : 0;          // which Fp2 component this lane holds
+  const int pb = (threadIdx.x & 2u) ? 1 : 0;    // which Fp6 half of an Fp12 this lane's pair holds
+  Fp12Q<C, E2> f, r;
+  if (WHAT == 1) {
+    // Fp12 in memory: c0.{c0,c1,c2}.{c0,c1}, then c1: coefficient j of half pb, component hi
+    const Fp<C>* o = reinterpret_cast<const Fp<C>*>(in + i) + 6 * pb + hi;
+    fp28_from_fp<C>(f.v.c0.v, o[0]);
+    fp28_from_fp<C>(f.v.c1.v, o[2]);
+    fp28_from_fp<C>(f.v.c2.v, o[4]);
+  } else {
+    const Affine<FpField<C>> P = g1[i];
+    const Fp<C>* q = reinterpret_cast<const Fp<C>*>(g2 + i);
+    const Fp<C> qxc = q[hi], qyc = q[2 + hi];
+    uint32_t zq = (fp_is_zero<C>(qxc) & fp_is_zero<C>(qyc)) ? 1u : 0u;
+    zq &= pair_xchg_u32(zq);  // Q at infinity: all four Fp components zero (both pairs hold the same Q)
+    const bool live = !(affine_is_inf<FpField<C>>(P) | (zq != 0));
+    Fp28<C> px, py;
+    E2 qx, qy;
+    fp28_from_fp<C>(px, P.x);
+    fp28_from_fp<C>(py, P.y);
+    fp28_from_fp<C>(qx.v, qxc);
+    fp28_from_fp<C>(qy.v, qyc);
+    miller_loop_q<C, E2, Fp28<C>>(f, px, py, qx, qy, live);
+  }
+  if (WHAT != 0) {
+    final_exp_q<C>(r, f);
+    f = r;
+  }
+  Fp<C>* o = reinterpret_cast<Fp<C>*>(out + i) + 6 * pb + hi;
+  Fp<C> w;
+  fp28_to_fp<C>(w, f.v.c0.v);
+  o[0] = w;
+  fp28_to_fp<C>(w, f.v.c1.v);
+  o[2] = w;
+  fp28_to_fp<C>(w, f.v.c2.v);
+  o[4] = w;
+}
+
 template <class C>
 __global__ void __launch_bounds__(256) k_fp_mul(const Fp<C>* __restrict__ a, const Fp<C>* __restrict__ b, size_t n,
                                                 int repeat, Fp<C>* __restrict__ out) {
@@ -233,6 +282,24 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
     // BLS12-381: lane pairs in the carry-free form (MLHIP_PAIRING_SAT=1 selects the saturated lane-pair kernels below)
     unsigned blocks = (unsigned)((2 * n + 63) / 64);
     if constexpr (C::ID == 1) {
+      // One pairing per QUAD of lanes (pairing_quad.h) while the batch leaves the chip under-filled: up to 2^14 elements
+      // (65 536 lanes = one wave per SIMD) a batch takes the time of ONE pairing's dependent chain, which is 1.5 x
+      // shorter on a quad (1 024 pairings: 5.7 ms instead of 8.5; single Pairing 2.6 / FExp 3.1 ms instead of 3.9 / 4.6);
+      // a full chip is bound by instruction issue, where the pairs' fewer instructions win (65 536: 18.6 vs 23.4 ms).
+      // MLHIP_PAIRING_QUAD=1 / 0 forces / forbids the quads (single pairs only: Pairing2 and products stay on pairs).
+      const char* qe = getenv("MLHIP_PAIRING_QUAD");
+      const bool quads = qe ? qe[0] == '1' : n <= ((size_t)1 << 14);
+      if (quads && (what != 0 || ppp == 1)) {
+        const unsigned qblocks = (unsigned)((4 * n + 63) / 64);
+        if (what == 0)
+          k_pairing_q28<C, 0><<<dim3(qblocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, nullptr, (Fp12<C>*)d_out);
+        else if (what == 1)
+          k_pairing_q28<C, 1><<<dim3(qblocks), dim3(64), 0, st>>>(nullptr, nullptr, n, (const Fp12<C>*)d_in, (Fp12<C>*)d_out);
+        else
+          k_pairing_q28<C, 2><<<dim3(qblocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, nullptr, (Fp12<C>*)d_out);
+        HIPCHK(hipGetLastError());
+        return 0;
+      }
       switch (what) {
         case 0:
           if (ppp == 1)

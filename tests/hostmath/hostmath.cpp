@@ -14,6 +14,7 @@
 #include "../../mathlib_amd/csrc/ec28_lp.h"
 #include "../../mathlib_amd/csrc/modinv.h"
 #include "../../mathlib_amd/csrc/fp2_lanes28.h"
+#include "../../mathlib_amd/csrc/pairing_quad.h"
 
 using namespace mlhip;
 
@@ -527,6 +528,125 @@ struct Lp28 {
   }
 };
 
+// the quad-lane pairing (pairing_quad.h) through its host model Fp2Q28H: pair A / pair B of a quad
+struct Q28 {
+  typedef Bls381 C;
+  typedef Fp2Q28H<C> E;
+  typedef Fp12Q<C, E> F12q;
+  static void to_q(F12q& r, const Fp12<C>& a) {
+    const Fp2<C>* lo = &a.c0.c0;
+    const Fp2<C>* up = &a.c1.c0;
+    E* d = &r.v.c0;
+    for (int j = 0; j < 3; j++) {
+      fp28_from_fp<C>(d[j].c[0], lo[j].c0);
+      fp28_from_fp<C>(d[j].c[1], lo[j].c1);
+      fp28_from_fp<C>(d[j].c[2], up[j].c0);
+      fp28_from_fp<C>(d[j].c[3], up[j].c1);
+      d[j].wt = 1;
+      d[j].vbound = 1;
+    }
+  }
+  static void from_q(Fp12<C>& r, const F12q& a) {
+    Fp2<C>* lo = &r.c0.c0;
+    Fp2<C>* up = &r.c1.c0;
+    const E* s = &a.v.c0;
+    for (int j = 0; j < 3; j++) {
+      fp28_to_fp<C>(lo[j].c0, s[j].c[0]);
+      fp28_to_fp<C>(lo[j].c1, s[j].c[1]);
+      fp28_to_fp<C>(up[j].c0, s[j].c[2]);
+      fp28_to_fp<C>(up[j].c1, s[j].c[3]);
+    }
+  }
+  static void rep(E& r, const Fp2<C>& a) {  // an Fp2 value replicated on both pairs
+    fp28_from_fp<C>(r.c[0], a.c0);
+    fp28_from_fp<C>(r.c[1], a.c1);
+    r.c[2] = r.c[0];
+    r.c[3] = r.c[1];
+    r.wt = 1;
+    r.vbound = 1;
+  }
+  static int max_w(const F12q& a) {
+    const E* s = &a.v.c0;
+    int w = 0;
+    for (int j = 0; j < 3; j++) w = s[j].wt > w ? s[j].wt : w;
+    return w;
+  }
+  static int fp12_op(int op, const void* a, const void* b, void* out) {
+    Fp12<C> x, y, r;
+    memcpy(&x, a, sizeof(x));
+    if (b && op != 12 && op != 13) memcpy(&y, b, sizeof(y));
+    F12q hx, hy, hr;
+    to_q(hx, x);
+    if (b && op != 12 && op != 13) to_q(hy, y);
+    switch (op) {
+      case 0: fp12q_mul<C>(hr, hx, hy); break;
+      case 1: fp12q_sqr<C>(hr, hx); break;
+      case 2: fp12q_inv<C>(hr, hx); break;
+      case 3: fp12q_frob<C, 1>(hr, hx); break;
+      case 4: fp12q_frob<C, 2>(hr, hx); break;
+      case 5: fp12q_frob<C, 3>(hr, hx); break;
+      case 7: fp12q_conj<C>(hr, hx); break;
+      case 8: fp12q_expt<C>(hr, hx); break;
+      case 9: final_exp_q<C>(hr, hx); break;
+      case 10: hr = hx; fp12q_mul<C>(hr, hr, hy); break;  // in place
+      case 11: hr = hx; fp12q_sqr<C>(hr, hr); break;
+      case 12: {  // compressed cyclotomic squarings on the quad, decompressed (replicated) with their own inversion
+        CycloCompQ<C, E> k;
+        cyclo_compress_q<C>(k, hx);
+        const int reps = b ? ((const uint8_t*)b)[0] : 1;
+        for (int i = 0; i < (reps < 1 ? 1 : reps); i++) cyclo_sqr_compressed_q<C>(k);
+        CycloComp<C, E> kc;
+        cyclo_replicate_q<C>(kc, k);
+        E num, den, inv, a1;
+        cyclo_a1_fraction<C>(num, den, kc);
+        fp2_inv<C>(inv, den);
+        fp2_mul<C>(a1, num, inv);
+        Fp12<C, E> v;
+        cyclo_decompress<C>(v, kc, a1);
+        fp12q_from_replicated<C>(hr, v);
+        break;
+      }
+      case 13: {  // f *= line (c0, c1, c4): b holds the three Fp2 coefficients
+        const Fp2<C>* l = (const Fp2<C>*)b;
+        E c0, c1, c4;
+        rep(c0, l[0]);
+        rep(c1, l[1]);
+        rep(c4, l[2]);
+        hr = hx;
+        fp12q_mul_by_014<C>(hr, c0, c1, c4);
+        break;
+      }
+      default: return -1;
+    }
+    from_q(r, hr);
+    memcpy(out, &r, sizeof(r));
+    return max_w(hr);
+  }
+  static int pairing(const void* g1, const void* g2, int with_fexp, void* out) {
+    typedef Affine<FpField<C>> A1;
+    typedef Affine<Fp2Field<C>> A2;
+    const A1* P = (const A1*)g1;
+    const A2* Q = (const A2*)g2;
+    const bool live = !(affine_is_inf<FpField<C>>(P[0]) | affine_is_inf<Fp2Field<C>>(Q[0]));
+    Fp28<C> px, py;
+    E qx, qy;
+    fp28_from_fp<C>(px, P[0].x);
+    fp28_from_fp<C>(py, P[0].y);
+    rep(qx, Q[0].x);
+    rep(qy, Q[0].y);
+    F12q f, r;
+    miller_loop_q<C, E, Fp28<C>>(f, px, py, qx, qy, live);
+    if (with_fexp) {
+      final_exp_q<C>(r, f);
+      f = r;
+    }
+    Fp12<C> o;
+    from_q(o, f);
+    memcpy(out, &o, sizeof(o));
+    return max_w(f);
+  }
+};
+
 #define DISPATCH(curve, call)                 \
   switch (curve) {                            \
     case 0: return Ops<Bn254>::call;          \
@@ -557,6 +677,8 @@ int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }
 int hm_lp28_fp12_op(int op, const void* a, const void* b, void* out) { return Lp28::fp12_op(op, a, b, out); }
 int hm_lp28_pairing(const void* g1s, const void* g2s, int n_pairs, int with_fexp, void* out) { return Lp28::pairing(g1s, g2s, n_pairs, with_fexp, out); }
+int hm_q28_fp12_op(int op, const void* a, const void* b, void* out) { return Q28::fp12_op(op, a, b, out); }
+int hm_q28_pairing(const void* g1, const void* g2, int with_fexp, void* out) { return Q28::pairing(g1, g2, with_fexp, out); }
 int hm_fp28_reduce(int curve, const int32_t* in, int32_t* out) {
   if (curve != 1) return -2;
   Fp28<Bls381> a, r;

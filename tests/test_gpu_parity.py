@@ -593,6 +593,52 @@ def test_pairing_saturated_lane_pair_kernels_agree(lib, mlhip, monkeypatch):
     assert res["0"] == res["1"] == cref.final_exp(cid, cref.miller_loop(cid, p1, p2, 2, n // 2, 8), n // 2, 8)
 
 
+def test_pairing_quad_lane_kernels_agree(lib, mlhip, monkeypatch):
+    """MLHIP_PAIRING_QUAD=1: one BLS12-381 pairing per quad of lanes (pairing_quad.h, k_pairing_q28) -- Miller loop
+    (compared after the final exponentiation, the raw value is not canonical), final exponentiation on the lane-pair
+    kernels' raw Miller values, and the fused pairing, against the oracle: goldens and a ragged batch with infinities."""
+    from oracle import cref
+
+    g = load_golden("BLS12-381")
+    cid = g["curve_id"]
+    _, g1b, g2b, gtb = mlhip.sizes(cid)
+    n = 83  # ragged: the last wave holds 3 quads
+    p1 = bytearray(cref.gen_points(cid, 1, 818, 27, n))
+    p2 = bytearray(cref.gen_points(cid, 2, 919, 29, n))
+    p1[5 * g1b : 6 * g1b] = bytes(g1b)
+    p2[9 * g2b : 10 * g2b] = bytes(g2b)
+    p1, p2 = bytes(p1), bytes(p2)
+    want = cref.pairing_batch(cid, p1, p2, n, 8)
+    monkeypatch.setenv("MLHIP_PAIRING_QUAD", "0")
+    raw_pairs = ctypes.create_string_buffer(gtb * n)  # raw Miller values from the lane-pair kernels
+    mlhip.check(lib.mlhip_miller_loop(cid, p1, p2, 1, n, raw_pairs))
+    # batches up to 2^14 run on quads by default; "1" forces them, "0" keeps this small batch on the lane-pair kernels
+    for quad in ("1", "0", None):
+        if quad is None:
+            monkeypatch.delenv("MLHIP_PAIRING_QUAD")
+        else:
+            monkeypatch.setenv("MLHIP_PAIRING_QUAD", quad)
+        out = ctypes.create_string_buffer(gtb * n)
+        mlhip.check(lib.mlhip_pairing_batch(cid, p1, p2, n, out))
+        assert out.raw == want, quad
+        fe = ctypes.create_string_buffer(gtb * n)
+        mlhip.check(lib.mlhip_final_exp(cid, raw_pairs, n, fe))
+        assert fe.raw == want, quad
+        ml = ctypes.create_string_buffer(gtb * n)
+        mlhip.check(lib.mlhip_miller_loop(cid, p1, p2, 1, n, ml))
+        assert cref.final_exp(cid, ml.raw, n, 8) == want, quad
+        cases = g["pairing"]
+        q1 = b"".join(_h(c["g1"]) for c in cases)
+        q2 = b"".join(_h(c["g2"]) for c in cases)
+        out = ctypes.create_string_buffer(gtb * len(cases))
+        mlhip.check(lib.mlhip_pairing_batch(cid, q1, q2, len(cases), out))
+        assert out.raw == b"".join(_h(c["fexp"]) for c in cases), quad
+        # Pairing2 (two pairs per product) stays on the lane-pair kernels whatever the switch says
+        ml2 = ctypes.create_string_buffer(gtb * (n // 2))
+        mlhip.check(lib.mlhip_miller_loop(cid, p1, p2, 2, n // 2, ml2))
+        assert cref.final_exp(cid, ml2.raw, n // 2, 8) == cref.final_exp(cid, cref.miller_loop(cid, p1, p2, 2, n // 2, 8), n // 2, 8)
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_msm_differential_sweep(lib, mlhip, curve):
     """Seeded sweep over (n, window, scalar width, duplicates / negated duplicates / infinities) against the C

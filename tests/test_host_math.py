@@ -672,3 +672,57 @@ def test_fp28_reduce_range(hostmath):
         got = sum(int(out[i]) << (28 * i) for i in range(14))
         assert (got - v) % p == 0 and abs(got) < 0.6 * p, (trial, v / p, got / p)
         assert all(0 <= int(out[i]) < (1 << 28) for i in range(13))
+
+
+def test_q28_tower_ops_and_weight_budget(hostmath):
+    """pairing_quad.h: every Fp12-level operation of the quad-lane pairing through its host model (Fp2Q28H: the four
+    lanes of a quad, pair A = the c0 half and pair B = the c1 half of an Fp12, with the weight / value-bound checks of
+    the lane-pair model and a check that no branch depends on a value that differs between the pairs)."""
+    cp = R.CURVES["BLS12-381"]
+    T = R.tower(cp)
+    L = hostmath
+    d = R.Drbg("hm/q28/ops")
+    rf = lambda: tuple((d.below(cp.p), d.below(cp.p)) for _ in range(6))  # noqa: E731
+    gb = lambda f: R.gt_to_mont_bytes(cp, f)  # noqa: E731
+    out = ctypes.create_string_buffer(576)
+    for _ in range(2):
+        f, g = rf(), rf()
+        c = T.f12_mul(T.f12_conj(f), T.f12_inv(f))
+        c = T.f12_mul(T.f12_frob(c, 2), c)  # cyclotomic subgroup element
+        cases = [(0, f, T.f12_mul(f, g)), (1, f, T.f12_sqr(f)), (10, f, T.f12_mul(f, g)), (11, f, T.f12_sqr(f)), (2, f, T.f12_inv(f)),
+                 (3, f, T.f12_frob(f, 1)), (4, f, T.f12_frob(f, 2)), (5, f, T.f12_frob(f, 3)), (7, f, T.f12_conj(f)),
+                 (8, c, T.f12_pow(c, cp.x)), (9, f, R.final_exp(cp, f))]
+        for op, a, exp in cases:
+            assert L.hm_q28_fp12_op(op, gb(a), gb(g), out) == 1, op
+            assert R.gt_from_mont_bytes(cp, out.raw) == exp, op
+    for n in (1, 2, 17, 63):
+        assert L.hm_q28_fp12_op(12, gb(c), bytes([n]) + bytes(575), out) == 1
+        exp = c
+        for _ in range(n):
+            exp = T.f12_sqr(exp)
+        assert R.gt_from_mont_bytes(cp, out.raw) == exp, n
+    one = tuple([(1, 0)] + [(0, 0)] * 5)
+    assert L.hm_q28_fp12_op(8, gb(one), None, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
+    assert L.hm_q28_fp12_op(9, gb(one), None, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
+
+
+def test_q28_pairing_matches_oracle(hostmath):
+    """Whole pairings through the quad-lane host model: Miller loop alone (compared after the oracle's final
+    exponentiation), fused pairing, the golden generator pairing, infinity on either side."""
+    cp = R.CURVES["BLS12-381"]
+    L = hostmath
+    d = R.Drbg("hm/q28/pairing")
+    out = ctypes.create_string_buffer(576)
+    P, Q = R.random_g1(cp, d), R.random_g2(cp, d)
+    g1, g2 = R.g1_to_mont_bytes(cp, P), R.g2_to_mont_bytes(cp, Q)
+    assert L.hm_q28_pairing(g1, g2, 1, out) == 1
+    assert R.gt_from_mont_bytes(cp, out.raw) == R.pairing(cp, P, Q)
+    assert L.hm_q28_pairing(g1, g2, 0, out) == 1
+    assert R.final_exp(cp, R.gt_from_mont_bytes(cp, out.raw)) == R.pairing(cp, P, Q)
+    g = load_golden("BLS12-381")
+    c0 = g["pairing"][0]
+    assert L.hm_q28_pairing(bytes.fromhex(c0["g1"]), bytes.fromhex(c0["g2"]), 1, out) == 1
+    assert out.raw.hex() == c0["fexp"]
+    one = tuple([(1, 0)] + [(0, 0)] * 5)
+    assert L.hm_q28_pairing(bytes(96), g2, 1, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
+    assert L.hm_q28_pairing(g1, bytes(192), 1, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
