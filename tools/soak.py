@@ -117,6 +117,11 @@ while time.time() - t0 < budget:
         p1, p2 = bytes(p1), bytes(p2)
         exp = cref.pairing_batch(cid, p1, p2, n, 16)
         out = ctypes.create_string_buffer(gtb * n)
+        quad = rnd.choice([None, "0", "1"])  # BLS12-381: one pairing per quad of lanes (default at these sizes) or per lane pair
+        if quad is None:
+            os.environ.pop("MLHIP_PAIRING_QUAD", None)
+        else:
+            os.environ["MLHIP_PAIRING_QUAD"] = quad
         _lib.check(lib.mlhip_pairing_batch(cid, p1, p2, n, out))
         if out.raw != exp:
             print("MISMATCH pairing", name, n, "seed", seed, flush=True)
