@@ -189,10 +189,11 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp28(const Affine<F
 }
 
 // ---- one pairing per QUAD of lanes (pairing_quad.h; BLS12-381, carry-free element): pair A of a quad carries the c0 half
-// and pair B the c1 half of every Fp12 value.  WHAT: 0 = Miller loop of one pair, 1 = final exponentiation, 2 = both.
-template <class C, int WHAT>
+// and pair B the c1 half of every Fp12 value.  WHAT: 0 = Miller loop of ppp <= MAXP pairs per product, 1 = final
+// exponentiation, 2 = Miller loop of one pair + final exponentiation.
+template <class C, int WHAT, int MAXP>
 __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_q28(const Affine<FpField<C>>* __restrict__ g1,
-                                                                 const Affine<Fp2Field<C>>* __restrict__ g2, size_t n,
+                                                                 const Affine<Fp2Field<C>>* __restrict__ g2, int ppp, size_t n,
                                                                  const Fp12<C>* __restrict__ in, Fp12<C>* __restrict__ out) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = t >> 2;  // the four lanes of a quad share i: quad-uniform exit
@@ -208,19 +209,22 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_q28(const Affine<Fp
     fp28_from_fp<C>(f.v.c1.v, o[2]);
     fp28_from_fp<C>(f.v.c2.v, o[4]);
   } else {
-    const Affine<FpField<C>> P = g1[i];
-    const Fp<C>* q = reinterpret_cast<const Fp<C>*>(g2 + i);
-    const Fp<C> qxc = q[hi], qyc = q[2 + hi];
-    uint32_t zq = (fp_is_zero<C>(qxc) & fp_is_zero<C>(qyc)) ? 1u : 0u;
-    zq &= pair_xchg_u32(zq);  // Q at infinity: all four Fp components zero (both pairs hold the same Q)
-    const bool live = !(affine_is_inf<FpField<C>>(P) | (zq != 0));
-    Fp28<C> px, py;
-    E2 qx, qy;
-    fp28_from_fp<C>(px, P.x);
-    fp28_from_fp<C>(py, P.y);
-    fp28_from_fp<C>(qx.v, qxc);
-    fp28_from_fp<C>(qy.v, qyc);
-    miller_loop_q<C, E2, Fp28<C>>(f, px, py, qx, qy, live);
+    Fp28<C> px[MAXP], py[MAXP];
+    E2 qx[MAXP], qy[MAXP];
+    bool live[MAXP];
+    for (int k = 0; k < ppp && k < MAXP; k++) {
+      const Affine<FpField<C>> P = g1[i * ppp + k];
+      const Fp<C>* q = reinterpret_cast<const Fp<C>*>(g2 + i * ppp + k);
+      const Fp<C> qxc = q[hi], qyc = q[2 + hi];
+      uint32_t zq = (fp_is_zero<C>(qxc) & fp_is_zero<C>(qyc)) ? 1u : 0u;
+      zq &= pair_xchg_u32(zq);  // Q at infinity: all four Fp components zero (both pairs hold the same Q)
+      live[k] = !(affine_is_inf<FpField<C>>(P) | (zq != 0));
+      fp28_from_fp<C>(px[k], P.x);
+      fp28_from_fp<C>(py[k], P.y);
+      fp28_from_fp<C>(qx[k].v, qxc);
+      fp28_from_fp<C>(qy[k].v, qyc);
+    }
+    miller_loop_q<C, MAXP, E2, Fp28<C>>(f, px, py, qx, qy, live, ppp);
   }
   if (WHAT != 0) {
     final_exp_q<C>(r, f);
@@ -286,17 +290,19 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
       // (65 536 lanes = one wave per SIMD) a batch takes the time of ONE pairing's dependent chain, which is 1.5 x
       // shorter on a quad (1 024 pairings: 5.7 ms instead of 8.5; single Pairing 2.6 / FExp 3.1 ms instead of 3.9 / 4.6);
       // a full chip is bound by instruction issue, where the pairs' fewer instructions win (65 536: 18.6 vs 23.4 ms).
-      // MLHIP_PAIRING_QUAD=1 / 0 forces / forbids the quads (single pairs only: Pairing2 and products stay on pairs).
+      // MLHIP_PAIRING_QUAD=1 / 0 forces / forbids the quads (products of up to 4 pairs; longer ones stay on lane pairs).
       const char* qe = getenv("MLHIP_PAIRING_QUAD");
       const bool quads = qe ? qe[0] == '1' : n <= ((size_t)1 << 14);
-      if (quads && (what != 0 || ppp == 1)) {
+      if (quads && (what != 0 || ppp <= 4)) {
         const unsigned qblocks = (unsigned)((4 * n + 63) / 64);
-        if (what == 0)
-          k_pairing_q28<C, 0><<<dim3(qblocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, nullptr, (Fp12<C>*)d_out);
+        if (what == 0 && ppp == 1)
+          k_pairing_q28<C, 0, 1><<<dim3(qblocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr, (Fp12<C>*)d_out);
+        else if (what == 0)
+          k_pairing_q28<C, 0, 4><<<dim3(qblocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, nullptr, (Fp12<C>*)d_out);
         else if (what == 1)
-          k_pairing_q28<C, 1><<<dim3(qblocks), dim3(64), 0, st>>>(nullptr, nullptr, n, (const Fp12<C>*)d_in, (Fp12<C>*)d_out);
+          k_pairing_q28<C, 1, 1><<<dim3(qblocks), dim3(64), 0, st>>>(nullptr, nullptr, 1, n, (const Fp12<C>*)d_in, (Fp12<C>*)d_out);
         else
-          k_pairing_q28<C, 2><<<dim3(qblocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, nullptr, (Fp12<C>*)d_out);
+          k_pairing_q28<C, 2, 1><<<dim3(qblocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr, (Fp12<C>*)d_out);
         HIPCHK(hipGetLastError());
         return 0;
       }

@@ -11,10 +11,11 @@
 //     compressed cyclotomic squaring: (b0 | d0), (b1 | d1) -- three Fp2 squarings         instead of six
 // with the halves exchanged by quad_perm [2,3,0,1] moves (14 per Fp2 value) and merged by per-pair selects.  The point
 // T of the Miller loop and the line coefficients are replicated on both pairs (g2_double_step / g2_add_step run as
-// they are).  What this buys: an Fp12 fits the register file together with the temporaries of the product that updates
-// it, so the whole-Fp12 round trips through scratch of the lane-pair kernel (31 GB per 65 536 pairings) go away, and the
-// dependent chain of one pairing is 1.5-1.8 x shorter.  What it costs: 4 instead of 3 Fp6 products per f g, 16 instead
-// of 13 product slots per line, the doubling step computed twice.
+// they are).  What this buys: the dependent chain of one pairing is 1.5 x shorter (measured: a batch that leaves the chip
+// under-filled takes 5.7 ms instead of 8.5), and an Fp12 is 42 words per lane.  What it costs: 4 instead of 3 Fp6 products
+// per f g, 16 instead of 13 product slots per line, the doubling step computed twice -- 27 % more instructions, so a full
+// chip (issue bound) stays on lane pairs; and as long as the Fp12 operations are out-of-line functions taking references
+// their operands still cross scratch (DESIGN.md section 4 lists what is left to do).
 //
 // Every function is written over the element type E with four helpers (quad_swap, quad_sel_b, quad_on_a, quad_on_b):
 // Fp2L28 on the device (DPP), Fp2Q28H on the host -- the host model of one quad, with the weight / value-bound checks of
@@ -309,27 +310,37 @@ MLHIP_HD void mul_by_line_q(Fp12Q<C, E>& f, const Line<C, E>& l, const EP& px, c
   fp12q_mul_by_014<C>(f, c, b, a);
 }
 
-// the Miller loop of one pair (P, Q); qx, qy, T and the lines are replicated on both pairs of the quad
-template <class C, class E, class EP>
-MLHIP_HD void miller_loop_q(Fp12Q<C, E>& f, const EP& px, const EP& py, const E& qx, const E& qy, bool live) {
+// f = prod_k f_{loop,Q_k}(P_k) over n_pairs pairs sharing the squarings (the reference's Pairing / Pairing2,
+// driver/gurvy/bls12381/bls12-381.go:448-464); qx, qy, the points T_k and the lines are replicated on both pairs of the
+// quad.  Pairs flagged not live (one side at infinity) are skipped, as gnark does.
+template <class C, int MAXP, class E, class EP>
+MLHIP_HD void miller_loop_q(Fp12Q<C, E>& f, const EP* px, const EP* py, const E* qx, const E* qy, const bool* live,
+                            int n_pairs) {
   static_assert(!C::IS_BN, "BLS12 loop");
+  G2Proj<C, E> T[MAXP];
+  int any = 0;
+  for (int k = 0; k < n_pairs && k < MAXP; k++) {
+    T[k].x = qx[k];
+    T[k].y = qy[k];
+    fp2_one<C>(T[k].z);
+    any |= live[k];
+  }
   fp12q_one<C>(f);
-  if (!live) return;
-  G2Proj<C, E> T;
-  T.x = qx;
-  T.y = qy;
-  fp2_one<C>(T.z);
+  if (!any) return;
   Line<C, E> l;
   bool first = true;
   for (int i = C::ATE_BITS - 2; i >= 0; i--) {
     if (!first) fp12q_sqr<C>(f, f);
     first = false;
     const bool bit = (i >= 64) ? ((C::ATE_HI >> (i - 64)) & 1) : ((C::ATE_LO >> i) & 1);
-    g2_double_step<C>(T, l);
-    mul_by_line_q<C>(f, l, px, py);
-    if (bit) {
-      g2_add_step<C>(T, qx, qy, l);
-      mul_by_line_q<C>(f, l, px, py);
+    for (int k = 0; k < n_pairs && k < MAXP; k++) {
+      if (!live[k]) continue;
+      g2_double_step<C>(T[k], l);
+      mul_by_line_q<C>(f, l, px[k], py[k]);
+      if (bit) {
+        g2_add_step<C>(T[k], qx[k], qy[k], l);
+        mul_by_line_q<C>(f, l, px[k], py[k]);
+      }
     }
   }
   if (C::X_NEG) fp12q_conj<C>(f, f);

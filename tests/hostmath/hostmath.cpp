@@ -622,20 +622,23 @@ struct Q28 {
     memcpy(out, &r, sizeof(r));
     return max_w(hr);
   }
-  static int pairing(const void* g1, const void* g2, int with_fexp, void* out) {
+  static int pairing(const void* g1, const void* g2, int n_pairs, int with_fexp, void* out) {
     typedef Affine<FpField<C>> A1;
     typedef Affine<Fp2Field<C>> A2;
     const A1* P = (const A1*)g1;
     const A2* Q = (const A2*)g2;
-    const bool live = !(affine_is_inf<FpField<C>>(P[0]) | affine_is_inf<Fp2Field<C>>(Q[0]));
-    Fp28<C> px, py;
-    E qx, qy;
-    fp28_from_fp<C>(px, P[0].x);
-    fp28_from_fp<C>(py, P[0].y);
-    rep(qx, Q[0].x);
-    rep(qy, Q[0].y);
+    Fp28<C> px[4], py[4];
+    E qx[4], qy[4];
+    bool live[4];
+    for (int k = 0; k < n_pairs && k < 4; k++) {
+      live[k] = !(affine_is_inf<FpField<C>>(P[k]) | affine_is_inf<Fp2Field<C>>(Q[k]));
+      fp28_from_fp<C>(px[k], P[k].x);
+      fp28_from_fp<C>(py[k], P[k].y);
+      rep(qx[k], Q[k].x);
+      rep(qy[k], Q[k].y);
+    }
     F12q f, r;
-    miller_loop_q<C, E, Fp28<C>>(f, px, py, qx, qy, live);
+    miller_loop_q<C, 4, E, Fp28<C>>(f, px, py, qx, qy, live, n_pairs);
     if (with_fexp) {
       final_exp_q<C>(r, f);
       f = r;
@@ -678,7 +681,7 @@ int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPAT
 int hm_lp28_fp12_op(int op, const void* a, const void* b, void* out) { return Lp28::fp12_op(op, a, b, out); }
 int hm_lp28_pairing(const void* g1s, const void* g2s, int n_pairs, int with_fexp, void* out) { return Lp28::pairing(g1s, g2s, n_pairs, with_fexp, out); }
 int hm_q28_fp12_op(int op, const void* a, const void* b, void* out) { return Q28::fp12_op(op, a, b, out); }
-int hm_q28_pairing(const void* g1, const void* g2, int with_fexp, void* out) { return Q28::pairing(g1, g2, with_fexp, out); }
+int hm_q28_pairing(const void* g1, const void* g2, int n_pairs, int with_fexp, void* out) { return Q28::pairing(g1, g2, n_pairs, with_fexp, out); }
 int hm_fp28_reduce(int curve, const int32_t* in, int32_t* out) {
   if (curve != 1) return -2;
   Fp28<Bls381> a, r;

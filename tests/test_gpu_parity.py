@@ -633,7 +633,7 @@ def test_pairing_quad_lane_kernels_agree(lib, mlhip, monkeypatch):
         out = ctypes.create_string_buffer(gtb * len(cases))
         mlhip.check(lib.mlhip_pairing_batch(cid, q1, q2, len(cases), out))
         assert out.raw == b"".join(_h(c["fexp"]) for c in cases), quad
-        # Pairing2 (two pairs per product) stays on the lane-pair kernels whatever the switch says
+        # Pairing2 (two pairs per product sharing the squarings) runs on quads too (products of up to 4 pairs)
         ml2 = ctypes.create_string_buffer(gtb * (n // 2))
         mlhip.check(lib.mlhip_miller_loop(cid, p1, p2, 2, n // 2, ml2))
         assert cref.final_exp(cid, ml2.raw, n // 2, 8) == cref.final_exp(cid, cref.miller_loop(cid, p1, p2, 2, n // 2, 8), n // 2, 8)

@@ -708,21 +708,27 @@ def test_q28_tower_ops_and_weight_budget(hostmath):
 
 def test_q28_pairing_matches_oracle(hostmath):
     """Whole pairings through the quad-lane host model: Miller loop alone (compared after the oracle's final
-    exponentiation), fused pairing, the golden generator pairing, infinity on either side."""
+    exponentiation), fused pairing, two pairs sharing the squarings (Pairing2), the golden generator pairing, infinity
+    on either side."""
     cp = R.CURVES["BLS12-381"]
     L = hostmath
     d = R.Drbg("hm/q28/pairing")
     out = ctypes.create_string_buffer(576)
     P, Q = R.random_g1(cp, d), R.random_g2(cp, d)
+    P2, Q2 = R.random_g1(cp, d), R.random_g2(cp, d)
     g1, g2 = R.g1_to_mont_bytes(cp, P), R.g2_to_mont_bytes(cp, Q)
-    assert L.hm_q28_pairing(g1, g2, 1, out) == 1
+    assert L.hm_q28_pairing(g1, g2, 1, 1, out) == 1
     assert R.gt_from_mont_bytes(cp, out.raw) == R.pairing(cp, P, Q)
-    assert L.hm_q28_pairing(g1, g2, 0, out) == 1
+    assert L.hm_q28_pairing(g1, g2, 1, 0, out) == 1
     assert R.final_exp(cp, R.gt_from_mont_bytes(cp, out.raw)) == R.pairing(cp, P, Q)
+    assert L.hm_q28_pairing(g1 + R.g1_to_mont_bytes(cp, P2), g2 + R.g2_to_mont_bytes(cp, Q2), 2, 1, out) == 1
+    assert R.gt_from_mont_bytes(cp, out.raw) == R.final_exp(cp, R.miller_loop(cp, [(P, Q), (P2, Q2)]))
+    assert L.hm_q28_pairing(g1 + bytes(96), g2 + R.g2_to_mont_bytes(cp, Q2), 2, 1, out) == 1  # second pair not live
+    assert R.gt_from_mont_bytes(cp, out.raw) == R.pairing(cp, P, Q)
     g = load_golden("BLS12-381")
     c0 = g["pairing"][0]
-    assert L.hm_q28_pairing(bytes.fromhex(c0["g1"]), bytes.fromhex(c0["g2"]), 1, out) == 1
+    assert L.hm_q28_pairing(bytes.fromhex(c0["g1"]), bytes.fromhex(c0["g2"]), 1, 1, out) == 1
     assert out.raw.hex() == c0["fexp"]
     one = tuple([(1, 0)] + [(0, 0)] * 5)
-    assert L.hm_q28_pairing(bytes(96), g2, 1, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
-    assert L.hm_q28_pairing(g1, bytes(192), 1, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
+    assert L.hm_q28_pairing(bytes(96), g2, 1, 1, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
+    assert L.hm_q28_pairing(g1, bytes(192), 1, 1, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
