@@ -188,6 +188,27 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp28(const Affine<F
   }
 }
 
+// Fp12 in memory (c0.{c0,c1,c2}.{c0,c1}, then c1) <-> the quad form: this lane moves coefficient j of half `pair B ? c1 : c0`,
+// component `hi ? imaginary : real`
+template <class C>
+__device__ __forceinline__ void q28_load_gt(Fp12Q<C, Fp2L28<C>>& f, const Fp12<C>* in, size_t i) {
+  const Fp<C>* o = reinterpret_cast<const Fp<C>*>(in + i) + ((threadIdx.x & 2u) ? 6 : 0) + (lane_is_hi() ? 1 : 0);
+  fp28_from_fp<C>(f.v.c0.v, o[0]);
+  fp28_from_fp<C>(f.v.c1.v, o[2]);
+  fp28_from_fp<C>(f.v.c2.v, o[4]);
+}
+template <class C>
+__device__ __forceinline__ void q28_store_gt(Fp12<C>* out, size_t i, const Fp12Q<C, Fp2L28<C>>& f) {
+  Fp<C>* o = reinterpret_cast<Fp<C>*>(out + i) + ((threadIdx.x & 2u) ? 6 : 0) + (lane_is_hi() ? 1 : 0);
+  Fp<C> w;
+  fp28_to_fp<C>(w, f.v.c0.v);
+  o[0] = w;
+  fp28_to_fp<C>(w, f.v.c1.v);
+  o[2] = w;
+  fp28_to_fp<C>(w, f.v.c2.v);
+  o[4] = w;
+}
+
 // ---- one pairing per QUAD of lanes (pairing_quad.h; BLS12-381, carry-free element): pair A of a quad carries the c0 half
 // and pair B the c1 half of every Fp12 value.  WHAT: 0 = Miller loop of ppp <= MAXP pairs per product, 1 = final
 // exponentiation, 2 = Miller loop of one pair + final exponentiation.
@@ -199,15 +220,10 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_q28(const Affine<Fp
   const size_t i = t >> 2;  // the four lanes of a quad share i: quad-uniform exit
   if (i >= n) return;
   typedef Fp2L28<C> E2;
-  const int hi = lane_is_hi() ? 1 : 0;          // which Fp2 component this lane holds
-  const int pb = (threadIdx.x & 2u) ? 1 : 0;    // which Fp6 half of an Fp12 this lane's pair holds
+  const int hi = lane_is_hi() ? 1 : 0;  // which Fp2 component this lane holds
   Fp12Q<C, E2> f, r;
   if (WHAT == 1) {
-    // Fp12 in memory: c0.{c0,c1,c2}.{c0,c1}, then c1: coefficient j of half pb, component hi
-    const Fp<C>* o = reinterpret_cast<const Fp<C>*>(in + i) + 6 * pb + hi;
-    fp28_from_fp<C>(f.v.c0.v, o[0]);
-    fp28_from_fp<C>(f.v.c1.v, o[2]);
-    fp28_from_fp<C>(f.v.c2.v, o[4]);
+    q28_load_gt<C>(f, in, i);
   } else {
     Fp28<C> px[MAXP], py[MAXP];
     E2 qx[MAXP], qy[MAXP];
@@ -230,14 +246,7 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_q28(const Affine<Fp
     final_exp_q<C>(r, f);
     f = r;
   }
-  Fp<C>* o = reinterpret_cast<Fp<C>*>(out + i) + 6 * pb + hi;
-  Fp<C> w;
-  fp28_to_fp<C>(w, f.v.c0.v);
-  o[0] = w;
-  fp28_to_fp<C>(w, f.v.c1.v);
-  o[2] = w;
-  fp28_to_fp<C>(w, f.v.c2.v);
-  o[4] = w;
+  q28_store_gt<C>(out, i, f);
 }
 
 template <class C>
@@ -432,6 +441,44 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_gt_exp_lp(const Fp12<C>* __
 
 // the same in the carry-free form (BLS12-381): 4-bit windows, the table of powers in scratch as 28-bit-limb values, the
 // accumulator too (an 84-word slot per lane would cost the eighth wave of a CU its LDS)
+// Gt.Exp with one exponentiation per quad of lanes (pairing_quad.h): the 4-bit windowed chain of k_gt_exp_lp28 with one
+// Fp6 product per squaring instead of two and two per multiplication instead of three -- for batches that leave the chip
+// under-filled (the chain's depth is what they wait for)
+template <class C>
+__global__ void __launch_bounds__(64) MLHIP_LP_OCC k_gt_exp_q28(const Fp12<C>* __restrict__ in,
+                                                                const uint32_t* __restrict__ scalars, int mont, size_t n,
+                                                                Fp12<C>* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = t >> 2;  // quad-uniform exit
+  if (i >= n) return;
+  typedef Fp2L28<C> E2;
+  uint32_t s[8];
+  fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  Fp12Q<C, E2> tab[15], acc;
+  q28_load_gt<C>(tab[0], in, i);
+#pragma unroll 1
+  for (int k = 1; k < 15; k++) fp12q_mul<C>(tab[k], tab[k - 1], tab[0]);
+  fp12q_one<C>(acc);
+  bool started = false;
+#pragma unroll 1
+  for (int w = 63; w >= 0; w--) {  // the scalar is the same on the four lanes of a quad: every branch is quad-uniform
+    if (started) {
+#pragma unroll 1
+      for (int d = 0; d < 4; d++) fp12q_sqr<C>(acc, acc);
+    }
+    const uint32_t nib = (s[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (nib) {
+      if (started)
+        fp12q_mul<C>(acc, acc, tab[nib - 1]);
+      else {
+        acc = tab[nib - 1];
+        started = true;
+      }
+    }
+  }
+  q28_store_gt<C>(out, i, acc);
+}
+
 template <class C>
 __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_gt_exp_lp28(const Fp12<C>* __restrict__ in,
                                                                  const uint32_t* __restrict__ scalars, int mont, size_t n,
@@ -474,9 +521,15 @@ int gt_exp_device(const void* d_in, const void* d_scalars, int mont, size_t n, v
     k_gt_exp<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars, mont, n,
                                                                    (Fp12<C>*)d_out);
   else if (lp28_enabled<C>()) {
-    if constexpr (C::ID == 1)
-      k_gt_exp_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in,
-                                                                              (const uint32_t*)d_scalars, mont, n, (Fp12<C>*)d_out);
+    if constexpr (C::ID == 1) {
+      const char* qe = getenv("MLHIP_PAIRING_QUAD");  // as for the pairings: quads up to 2^14 elements
+      if (qe ? qe[0] == '1' : n <= ((size_t)1 << 14))
+        k_gt_exp_q28<C><<<dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,
+                                                                               mont, n, (Fp12<C>*)d_out);
+      else
+        k_gt_exp_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in,
+                                                                                (const uint32_t*)d_scalars, mont, n, (Fp12<C>*)d_out);
+    }
   } else
     k_gt_exp_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,
                                                                           mont, n, (Fp12<C>*)d_out);

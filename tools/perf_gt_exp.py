@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
 gen = torch.Generator(device=dev)
 gen.manual_seed(2)
-n = 65536
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 for name in ("BLS12-381", "BN254", "BLS12-377"):
     g = load_golden(name)
     cid = g["curve_id"]
