@@ -46,12 +46,12 @@ import (
 var WindowC = 0
 
 // The GPU is a throughput device.  Measured on one MI355X through this ABI (tools/perf_latency.py): a
-// MultiScalarMul of 2 points takes 0.35 ms, of 2^20 points 4.5 ms; but ONE Miller loop takes 4.0 ms and ONE final
-// exponentiation 8.5 ms, because a single pairing occupies a single lane pair (65 536 of them take 18.7 ms).
+// MultiScalarMul of 2 points takes 0.35 ms, of 2^20 points 4.3 ms; but ONE Miller loop takes 2.6-2.9 ms and ONE final
+// exponentiation 5.7-5.9 ms, because a single pairing occupies a single quad of lanes (65 536 pairings take 18.7 ms).
 // gnark on the CPU does a single pairing in about a millisecond.  Hence:
 //
 // MinDeviceMSM: MultiScalarMul with fewer pairs stays on the embedded gurvy driver.  A host-slice MSM costs the device
-// a flat 0.35-0.7 ms up to 2^10 pairs and about 1.1 ms from 2^12 to 2^16 (profiles/r01_perf_small_msm.txt).  The CPU
+// a flat 0.35-0.7 ms up to 2^10 pairs and 0.7-0.95 ms from 2^12 to 2^16 (profiles/r02_perf_small_msm.txt).  The CPU
 // side cannot be measured with gnark here (no Go toolchain); the stated stand-in, one thread of the C restatement
 // (oracle/cref, tools/perf_min_device_msm.py, profiles/r02_min_device_msm.txt), needs 0.74 ms for 2 pairs, 4.3 ms for 32
 // and 51 ms for 2^10 -- the device wins from the first pair against it.  gnark with ADX assembly and GLV is roughly an
@@ -59,8 +59,9 @@ var WindowC = 0
 // near 8-32 pairs; 32 keeps the tiny proofs-of-knowledge MSMs (perf_test.go:198-224, 3-7 pairs) on the CPU.
 var MinDeviceMSM = 32
 
-// MinDevicePairingBatch: PairingBatch with fewer pairs stays on the embedded gurvy driver.  Any batch up to 32 768
-// pairs costs one wave time on the device (8.6 ms on an MI355X, profiles/r02_perf_hostapi_pairing.txt); a CPU
+// MinDevicePairingBatch: PairingBatch with fewer pairs stays on the embedded gurvy driver.  Any batch up to 16 384
+// pairs costs one wave time on the device (5.7 ms on an MI355X, one pairing per quad of lanes:
+// profiles/r02_perf_pairing_quads.txt); a CPU
 // core needs about a millisecond per pairing, so a few hundred pairs are where the device starts to win.
 var MinDevicePairingBatch = 256
 
