@@ -190,12 +190,14 @@ int launch_sort(mlhip_msm_plan* p, const void* d_scalars, int mont, size_t n, hi
     const uint32_t big_bin = (uint32_t)std::min<size_t>(std::max<size_t>(32768, 8 * ((size_t)p->W * n / NB)), 0x7fffffffu);
     k_fine_sort<<<dim3(NB), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->c, p->sort_low,
                                                p->sort_idx_bits, big_bin, p->d_counts, p->d_offsets, p->d_sorted);
-    k_bigbin_prefix<<<dim3(1), dim3(1024), 0, st>>>(p->d_coarse_count, NB, big_bin, p->d_binprefix);
-    k_bigbin_hist<<<dim3(1024), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->d_binprefix, NB,
-                                                   p->sort_low, p->sort_idx_bits, p->d_counts);
-    k_bigbin_place<<<dim3(1024), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->d_binprefix, NB,
-                                                    p->sort_low, p->sort_idx_bits, p->d_counts, p->d_cursor, p->d_offsets,
-                                                    p->d_sorted);
+    if ((size_t)p->W * n > big_bin) {  // a bin holds at most all W n entries: small MSMs skip three near-empty launches
+      k_bigbin_prefix<<<dim3(1), dim3(1024), 0, st>>>(p->d_coarse_count, NB, big_bin, p->d_binprefix);
+      k_bigbin_hist<<<dim3(1024), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->d_binprefix, NB,
+                                                     p->sort_low, p->sort_idx_bits, p->d_counts);
+      k_bigbin_place<<<dim3(1024), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->d_binprefix, NB,
+                                                      p->sort_low, p->sort_idx_bits, p->d_counts, p->d_cursor, p->d_offsets,
+                                                      p->d_sorted);
+    }
   } else {
     // legacy path (very large n or MLHIP_LEGACY_SORT=1): digits array + global-atomic histogram / scatter
     {
@@ -405,7 +407,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
           p->d_bigcount, (X*)p->d_buckets);
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[3], st));
-    {
+    if (n > big_threshold) {  // a bucket holds at most all n entries: small MSMs skip three near-empty launches
       constexpr int BB = sizeof(X) <= 192 ? 256 : 128;  // 48 KB of LDS per block
       launch_big_slices<F, BB>(p, (const A*)d_points, st);
       bool folded = false;
