@@ -34,6 +34,7 @@
 
 namespace mlhip {
 
+constexpr size_t QUAD_ACC_MAX_BUCKETS = 32768;  // up to here a G1 MSM accumulates one bucket per quad of lanes (k_accumulate_q28)
 constexpr uint32_t BIG_BUCKET_MIN = 256;  // a bucket goes to the sliced long-bucket path above max(this, 8 x the mean length)
 constexpr int CHUNK_L = 8;            // buckets per level-1 reduction thread
 

@@ -392,7 +392,12 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
             p->d_bigcount, (X*)p->d_buckets);
     } else if (p->d_points28) {
       HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
-      if (p->reduce28)  // one segment that is first and last, leaving the raw accumulators for k_chunks_q28
+      if (p->reduce28 && nbuckets <= QUAD_ACC_MAX_BUCKETS && !getenv("MLHIP_NO_QUAD_ACC"))
+        // too few buckets to fill the chip with one lane each: one bucket per quad of lanes (shorter dependent chains)
+        k_accumulate_q28<C><<<dim3((unsigned)((4 * nbuckets + 255) / 256)), dim3(256), 0, st>>>(
+            (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, big_threshold, p->d_biglist,
+            p->d_bigcount, (XYZZ28<C>*)p->d_state28);
+      else if (p->reduce28)  // one segment that is first and last, leaving the raw accumulators for k_chunks_q28
         k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
             (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
             p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28,

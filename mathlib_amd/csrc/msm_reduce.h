@@ -129,6 +129,49 @@ __device__ __forceinline__ void quad28_store(XYZZ28<C>* arr, size_t idx, const F
   reinterpret_cast<Fp28<C>*>(arr + idx)[threadIdx.x & 3u] = v;
 }
 
+// Bucket accumulation with one bucket per QUAD of lanes, for MSMs too small to fill the chip with one lane per bucket:
+// what such an MSM waits for is the chain of dependent additions of its fullest bucket, and on a quad an addition is four
+// rounds of one product per lane (quad28_xyzz_add; the point enters as (x, +-y, 1, 1)) instead of ten products in a row.
+// Leaves the carry-free bucket state the reduction reads (as k_accumulate28_seg with MLHIP_SEG_KEEP28).
+template <class C>
+__global__ void __launch_bounds__(256) k_accumulate_q28(const Affine28<C>* __restrict__ points,
+                                                        const uint32_t* __restrict__ sorted,
+                                                        const uint32_t* __restrict__ offsets,
+                                                        const uint32_t* __restrict__ counts, size_t n_buckets,
+                                                        uint32_t big_threshold, uint32_t* __restrict__ big_list,
+                                                        uint32_t* __restrict__ big_count, XYZZ28<C>* __restrict__ state) {
+  typedef QuadDevice28<C> B;
+  const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (g >= n_buckets) return;  // quad-uniform
+  const unsigned lane = threadIdx.x & 3u;
+  const uint32_t cnt = counts[g];
+  if (cnt > big_threshold) {  // k_big_slices / k_accumulate_big_seg write this bucket's state
+    if (lane == 0) {
+      const uint32_t pos = atomicAdd(big_count, 1u);
+      big_list[pos] = (uint32_t)g;
+    }
+    return;
+  }
+  Fp28<C> acc, one;
+  fp28_zero<C>(acc);
+  fp28_from_const<C>(one, C::ONE28);
+  const size_t begin = offsets[g], end = begin + cnt;
+#pragma unroll 1
+  for (size_t k = begin; k < end; k++) {
+    const uint32_t e = sorted[k];
+    const Fp28<C>* q = reinterpret_cast<const Fp28<C>*>(points + (e & 0x7fffffffu));  // x | y
+    Fp28<C> c = q[lane & 1u], n, b;
+    // the point at infinity is (0, 0): skip it (quad-uniform: lanes 0 and 1 hold x and y)
+    const unsigned z = B::quad_or((fp28_all_zero<C>(c) ? 1u : 0u) << lane);
+    if ((z & 3u) == 3u) continue;
+    fp28_neg<C>(n, c);
+    fp28_select<C>(c, lane == 1 && (e >> 31) != 0, n, c);
+    fp28_select<C>(b, lane >= 2, one, c);
+    quad28_xyzz_add<C, B>(acc, b);
+  }
+  quad28_store<C>(state, g, acc);
+}
+
 template <class C>
 __global__ void __launch_bounds__(256) k_chunks_q28(const XYZZ28<C>* __restrict__ buckets, size_t n_chunks, int l_eff,
                                                     XYZZ28<C>* __restrict__ A, XYZZ28<C>* __restrict__ W0) {
