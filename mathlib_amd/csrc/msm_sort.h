@@ -116,7 +116,7 @@ static inline int sort_tile_for(size_t n) {
   // keep at least ~4 blocks per CU (256 CUs) in flight
   if (n >= ((size_t)1 << 23)) return 8192;
   if (n >= ((size_t)1 << 22)) return 4096;
-  if (n >= ((size_t)1 << 21)) return 2048;
+  if (n >= ((size_t)1 << 20)) return 2048;  // 2^20: digits + sort 0.45 -> 0.42 ms; 2^19 is best at 1024, 2^21 is flat
   return 1024;
 }
 
