@@ -221,3 +221,48 @@ def test_msm_other_config_shapes(mlhip, curve_name, group, log_n):
     ss = s.cpu().numpy().view(np.uint64).reshape(n, 4)
     assert cref.msm(cid, group, pts.cpu().numpy(), ss, n, False, 16, threads) == full
     plan.close()
+
+
+def test_shared_scalars_config4_shard(mlhip, monkeypatch):
+    """BASELINE configs[3] as bench.py runs it: the G1 and the G2 MSM of one scalar vector through
+    mlhip_msm_launch_shared at the 8-GPU shard size (2^21 pairs), one pass and cut into four tiles -- against the two
+    independent plan runs (which test_msm_other_config_shapes checks against the C oracle on the whole input) and, for
+    the G1 half, against the C oracle directly."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from conftest import load_golden
+    from oracle import cref
+
+    g = load_golden("BLS12-381")
+    cid = g["curve_id"]
+    lib = mlhip.load()
+    _, g1b, g2b, _ = mlhip.sizes(cid)
+    n = 1 << 21
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2104)
+    rnd = lambda m: torch.randint(-(1 << 63), (1 << 63) - 1, (m, 4), dtype=torch.int64, generator=gen, device=dev).view(torch.uint8).reshape(m, 32).contiguous()  # noqa: E731
+    st = torch.cuda.current_stream().cuda_stream
+    pts = {}
+    for group, sz, key in ((1, g1b, "g1_gen"), (2, g2b, "g2_gen")):
+        base = torch.frombuffer(bytearray(bytes.fromhex(g[key])), dtype=torch.uint8).to(dev)
+        pts[group] = torch.empty(n * sz, dtype=torch.uint8, device=dev)
+        mlhip.check(lib.mlhip_scalar_mul_device(cid, group, base.data_ptr(), 0, rnd(n).data_ptr(), 0, n, pts[group].data_ptr(), st))
+    s = rnd(n)
+    torch.cuda.synchronize()
+    a, b = mlhip.MsmPlan(cid, 1, n, 16), mlhip.MsmPlan(cid, 2, n, 16)
+    want1 = a.run(pts[1].data_ptr(), s.data_ptr(), n, False, st)
+    want2 = b.run(pts[2].data_ptr(), s.data_ptr(), n, False, st)
+    for tile in (None, "19"):
+        if tile:
+            monkeypatch.setenv("MLHIP_TILE_LOG2", tile)
+        a.launch_shared(b, pts[1].data_ptr(), pts[2].data_ptr(), s.data_ptr(), n, False, st)
+        assert (a.finish(), b.finish()) == (want1, want2), tile
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    ss = s.cpu().numpy().view(np.uint64).reshape(n, 4)
+    assert cref.msm(cid, 1, pts[1].cpu().numpy(), ss, n, False, 16, threads) == want1
+    a.close()
+    b.close()
