@@ -319,6 +319,59 @@ MLHIP_HD void mul_by_line_q(Fp12Q<C, E>& f, const Line<C, E>& l, const EP& px, c
   fp12q_mul_by_014<C>(f, c, b, a);
 }
 
+// T <- 2T with the line through T, T: the formulas of g2_double_step (pairing.h) with the nine Fp2 products spread over the
+// two pairs of the quad -- three squaring rounds and two product rounds instead of six and three in a row:
+//     (Y^2 | Z^2)    ((Y + Z)^2 | X^2)    X Y on both    (E^2 | G^2)    (A (B - F) | B H)
+// T, the line and every linear combination are replicated on both pairs (quad_on_a / quad_on_b pick a round's results).
+template <class C, class E2>
+MLHIP_HD void g2_double_step_q(G2Proj<C, E2>& T, Line<C, E2>& l) {
+  static_assert(C::ID == 1, "BLS12-381 (b' = 4 xi)");
+  E2 A, B, Cc, E, F, G, H, I, J, EE, GG, s, t, u, r1, r2;
+  fp2_add<C>(s, T.y, T.z);
+  fp2_norm<C>(s);
+  quad_sel_b<C>(t, T.z, T.y);
+  fp2_sqr<C>(r1, t);  // Y^2 | Z^2
+  quad_sel_b<C>(t, T.x, s);
+  fp2_sqr<C>(r2, t);  // (Y + Z)^2 | X^2
+  fp2_mul<C>(A, T.x, T.y);
+  fp2_halve<C>(A, A);
+  quad_on_a<C>(B, r1);
+  quad_on_b<C>(Cc, r1);
+  quad_on_a<C>(H, r2);
+  quad_on_b<C>(J, r2);
+  fp2_mul_xi<C>(E, Cc);
+  fp2_mul_small<C>(E, E, 12);
+  fp2_reduce<C>(E);  // 3 b' Z^2: squared below
+  fp2_dbl<C>(F, E);
+  fp2_add<C>(F, F, E);  // 3E
+  fp2_add<C>(G, B, F);
+  fp2_halve<C>(G, G);
+  fp2_norm<C>(G);
+  fp2_add<C>(t, B, Cc);
+  fp2_sub<C>(H, H, t);  // 2YZ   (3)
+  fp2_sub<C>(I, E, B);  // 2
+  quad_sel_b<C>(t, G, E);
+  fp2_sqr<C>(r1, t);  // E^2 | G^2
+  fp2_sub<C>(t, B, F);
+  fp2_norm<C>(t);
+  quad_sel_b<C>(u, B, A);  // A | B
+  fp2_norm<C>(H);
+  quad_sel_b<C>(t, H, t);  // B - F | H
+  fp2_mul<C>(r2, u, t);    // X3 = A (B - F) | Z3 = B H
+  quad_on_a<C>(EE, r1);
+  quad_on_b<C>(GG, r1);
+  quad_on_a<C>(T.x, r2);
+  quad_on_b<C>(T.z, r2);
+  fp2_dbl<C>(t, EE);
+  fp2_add<C>(t, t, EE);
+  fp2_sub<C>(T.y, GG, t);  // G^2 - 3 E^2   (4)
+  fp2_norm<C>(T.y);
+  fp2_neg<C>(l.r0, H);
+  fp2_dbl<C>(l.r1, J);
+  fp2_add<C>(l.r1, l.r1, J);
+  l.r2 = I;
+}
+
 // f = prod_k f_{loop,Q_k}(P_k) over n_pairs pairs sharing the squarings (the reference's Pairing / Pairing2,
 // driver/gurvy/bls12381/bls12-381.go:448-464); qx, qy, the points T_k and the lines are replicated on both pairs of the
 // quad.  Pairs flagged not live (one side at infinity) are skipped, as gnark does.
@@ -344,7 +397,7 @@ MLHIP_HD void miller_loop_q(Fp12Q<C, E>& f, const EP* px, const EP* py, const E*
     const bool bit = (i >= 64) ? ((C::ATE_HI >> (i - 64)) & 1) : ((C::ATE_LO >> i) & 1);
     for (int k = 0; k < n_pairs && k < MAXP; k++) {
       if (!live[k]) continue;
-      g2_double_step<C>(T[k], l);
+      g2_double_step_q<C>(T[k], l);
       mul_by_line_q<C>(f, l, px[k], py[k]);
       if (bit) {
         g2_add_step<C>(T[k], qx[k], qy[k], l);
