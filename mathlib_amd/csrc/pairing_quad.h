@@ -6,16 +6,17 @@
 // 2, 3).  An Fp12 value f = c0 + c1 w is stored as ONE Fp6-shaped object: pair A holds c0, pair B holds c1 (42 words per
 // lane instead of 84).  The Fp12 formulas then read
 //     f^2   : one Fp6 product        (A: (a0 + a1)(a0 + v a1),  B: a0 a1)                 instead of two in a row
-//     f g   : two Fp6 products       (a * b and a * swap(b))                              instead of three
+//     f g   : one Fp6 product + three rounds (Karatsuba: m0 | m1, then m2 split over the pairs)  instead of three products
 //     f * l : fp6_mul_by_01 + fp6_mul_by_1 (8 Fp2 products deep)                          instead of 13
 //     compressed cyclotomic squaring: (b0 | d0), (b1 | d1) -- three Fp2 squarings         instead of six
 // with the halves exchanged by quad_perm [2,3,0,1] moves (14 per Fp2 value) and merged by per-pair selects.  The point
-// T of the Miller loop and the line coefficients are replicated on both pairs (g2_double_step / g2_add_step run as
-// they are).  What this buys: the dependent chain of one pairing is 1.5 x shorter (measured: a batch that leaves the chip
-// under-filled takes 5.7 ms instead of 8.5), and an Fp12 is 42 words per lane.  What it costs: 4 instead of 3 Fp6 products
-// per f g, 16 instead of 13 product slots per line, the doubling step computed twice -- 27 % more instructions, so a full
-// chip (issue bound) stays on lane pairs; and as long as the Fp12 operations are out-of-line functions taking references
-// their operands still cross scratch (DESIGN.md section 4 lists what is left to do).
+// T of the Miller loop and the line coefficients are replicated on both pairs; the doubling step spreads its nine Fp2
+// products over the pairs (g2_double_step_q), the five addition steps run as they are (g2_add_step).  What this buys: the
+// dependent chain of one pairing is 1.6 x shorter (measured: a batch that leaves the chip under-filled takes 5.2 ms
+// instead of 8.5), and an Fp12 is 42 words per lane.  What it costs: 16 instead of 13 product slots per line, exchanges and
+// per-pair selects around every round -- more instructions in total (65 536 pairings: 20.9 ms against the lane pairs'
+// 18.6), so a full chip (issue bound) stays on lane pairs; and the Fp12 operations of the final exponentiation are still
+// out-of-line functions whose operands cross scratch (DESIGN.md section 4 lists what is left to do).
 //
 // Every function is written over the element type E with four helpers (quad_swap, quad_sel_b, quad_on_a, quad_on_b):
 // Fp2L28 on the device (DPP), Fp2Q28H on the host -- the host model of one quad, with the weight / value-bound checks of
@@ -202,19 +203,64 @@ MLHIP_HD void fp12q_conj(Fp12Q<C, E>& r, const Fp12Q<C, E>& a) {
   fp6q_sel_b<C>(r.v, n, a.v);
 }
 
-// r = a b: (a0 b0 + v a1 b1) + (a0 b1 + a1 b0) w -- two Fp6 products, each computing two of the four at once
+// r = a b, Karatsuba over the pairs: m0 = a0 b0 | m1 = a1 b1 is ONE Fp6 product (six rounds), and the six Fp2 products of
+// m2 = (a0 + a1)(b0 + b1) take three more rounds -- pair A computes s_j r_j, pair B the three products of sums:
+//     c0 = m0 + v m1 (pair A)        c1 = m2 - m0 - m1 (pair B)
+// nine rounds instead of the twelve of a * b and a * swap(b).
 template <class C, class E>
 MLHIP_HD_NOINLINE void fp12q_mul(Fp12Q<C, E>& r, const Fp12Q<C, E>& a, const Fp12Q<C, E>& b) {
-  Fp6<C, E> t1, t2, bs, s, u;
-  fp6_mul_i<C>(t1, a.v, b.v);  // A: a0 b0 | B: a1 b1
-  fp6q_swap<C>(bs, b.v);
-  fp6_mul_i<C>(t2, a.v, bs);  // A: a0 b1 | B: a1 b0
-  fp6q_swap<C>(s, t1);
-  fp6_mul_v<C>(u, s);
-  fp6_add<C>(u, t1, u);  // A: a0 b0 + v a1 b1   (3, 2, 2)
-  fp6q_swap<C>(s, t2);
-  fp6_add<C>(s, t2, s);  // both pairs: a0 b1 + a1 b0   (2)
-  fp6q_sel_b<C>(r.v, s, u);
+  Fp6<C, E> t, ts, sa, sb, m2, u;
+  fp6_mul_i<C>(t, a.v, b.v);  // A: m0 | B: m1
+  fp6q_swap<C>(sa, a.v);
+  fp6_add<C>(sa, a.v, sa);  // a0 + a1 on both pairs   (2)
+  fp6_norm<C>(sa);
+  fp6q_swap<C>(sb, b.v);
+  fp6_add<C>(sb, b.v, sb);
+  fp6_norm<C>(sb);
+  {
+    // the Karatsuba products of sa * sb: pair A takes x_j y_j, pair B (x_i + x_k)(y_i + y_k)
+    E xs, ys, X, Y, p0, p1, p2, t0, t1, t2, u0, u1, u2, w;
+    fp2_add<C>(xs, sa.c1, sa.c2);
+    fp2_add<C>(ys, sb.c1, sb.c2);
+    quad_sel_b<C>(X, xs, sa.c0);
+    quad_sel_b<C>(Y, ys, sb.c0);
+    fp2_mul<C>(p0, X, Y);  // x0 y0 | (x1 + x2)(y1 + y2)     (2 x 2 on pair B)
+    fp2_add<C>(xs, sa.c0, sa.c1);
+    fp2_add<C>(ys, sb.c0, sb.c1);
+    quad_sel_b<C>(X, xs, sa.c1);
+    quad_sel_b<C>(Y, ys, sb.c1);
+    fp2_mul<C>(p1, X, Y);  // x1 y1 | (x0 + x1)(y0 + y1)
+    fp2_add<C>(xs, sa.c0, sa.c2);
+    fp2_add<C>(ys, sb.c0, sb.c2);
+    quad_sel_b<C>(X, xs, sa.c2);
+    quad_sel_b<C>(Y, ys, sb.c2);
+    fp2_mul<C>(p2, X, Y);  // x2 y2 | (x0 + x2)(y0 + y2)
+    quad_on_a<C>(t0, p0);
+    quad_on_b<C>(u0, p0);
+    quad_on_a<C>(t1, p1);
+    quad_on_b<C>(u1, p1);
+    quad_on_a<C>(t2, p2);
+    quad_on_b<C>(u2, p2);
+    // m2 (on both pairs), as fp6_mul_i assembles it
+    fp2_sub<C>(w, u0, t1);
+    fp2_sub<C>(w, w, t2);
+    fp2_mul_xi<C>(w, w);
+    fp2_add<C>(m2.c0, w, t0);  // 7
+    fp2_sub<C>(w, u1, t0);
+    fp2_sub<C>(w, w, t1);
+    fp2_mul_xi<C>(xs, t2);
+    fp2_add<C>(m2.c1, w, xs);  // 5
+    fp2_sub<C>(w, u2, t0);
+    fp2_sub<C>(w, w, t2);
+    fp2_add<C>(m2.c2, w, t1);  // 4
+    fp6_norm<C>(m2);
+  }
+  fp6q_swap<C>(ts, t);  // A: m1 | B: m0
+  fp6_mul_v<C>(u, ts);
+  fp6_add<C>(u, t, u);  // A: m0 + v m1   (3, 2, 2)
+  fp6_sub<C>(m2, m2, t);
+  fp6_sub<C>(m2, m2, ts);  // m2 - m0 - m1   (3)
+  fp6q_sel_b<C>(r.v, m2, u);
   fp6_reduce<C>(r.v);
 }
 
