@@ -46,8 +46,8 @@ import (
 var WindowC = 0
 
 // The GPU is a throughput device.  Measured on one MI355X through this ABI (tools/perf_latency.py): a
-// MultiScalarMul of 2 points takes 0.35 ms, of 2^20 points 4.3 ms; but ONE Miller loop takes 2.6-2.9 ms and ONE final
-// exponentiation 5.7-5.9 ms, because a single pairing occupies a single quad of lanes (65 536 pairings take 18.7 ms).
+// MultiScalarMul of 2 points takes 0.35 ms, of 2^20 points 4.3 ms; but ONE Miller loop takes 2.4 ms and ONE final
+// exponentiation 5.4 ms, because a single pairing occupies a single quad of lanes (65 536 pairings take 18.7 ms).
 // gnark on the CPU does a single pairing in about a millisecond.  Hence:
 //
 // MinDeviceMSM: MultiScalarMul with fewer pairs stays on the embedded gurvy driver.  A host-slice MSM costs the device
@@ -60,7 +60,7 @@ var WindowC = 0
 var MinDeviceMSM = 32
 
 // MinDevicePairingBatch: PairingBatch with fewer pairs stays on the embedded gurvy driver.  Any batch up to 16 384
-// pairs costs one wave time on the device (5.7 ms on an MI355X, one pairing per quad of lanes:
+// pairs costs one wave time on the device (5.2 ms on an MI355X, one pairing per quad of lanes:
 // profiles/r02_perf_pairing_quads.txt); a CPU
 // core needs about a millisecond per pairing, so a few hundred pairs are where the device starts to win.
 var MinDevicePairingBatch = 256
