@@ -94,6 +94,22 @@ def seeded_scalars(n_total: int, lo: int, hi: int, seed: int, dev) -> torch.Tens
     return torch.cat(out).contiguous() if out else torch.empty((0, 32), dtype=torch.uint8, device=dev)
 
 
+def self_launch(n_ranks: int) -> int:
+    """python -m torch.distributed.run --standalone --nproc-per-node N bench.py <the same arguments>, as a child"""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port (several benches may share a node)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,8 +138,10 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (never an exec, and before
+        # anything in this process has touched the GPU), relay rank 0's JSON line and leave with the child's exit code
+        sys.exit(self_launch(args.gpus))
     # MLHIP_BENCH_REHEARSAL=1: several ranks share GPU 0 and exchange over gloo -- only for rehearsing the
     # N > 1 code path on a one-GPU box (RCCL needs one device per rank); never a measurement.
     rehearsal = os.environ.get("MLHIP_BENCH_REHEARSAL") == "1"
@@ -240,11 +258,8 @@ def main() -> None:
             "traffic": None, "avg_kernel_ms": kernel_ms,
             "note": "864 algorithmic bytes per pairing; the kernel is integer-issue bound (DESIGN.md section 4)",
         }
-        pm = _pmc("k_pairing_lp28<Bls381, 2")
-        if pm:
-            roofline["traffic"] = pm[0]
-            roofline["traffic_note"] = pm[1]
-        unit, metric = "pairings/s", "pairings/sec (BLS12-381, Miller loop + final exponentiation, batch of 65 536 per GPU)"
+        roofline["traffic"], roofline["traffic_note"] = _pmc(3, "k_pairing_lp28<Bls381, 2")
+        unit, metric = "pairings/s", "pairings/sec (BLS12-381, Miller loop + final exponentiation, batch of 65 536 per GPU, inputs resident in HBM)"
         res_check = None
     else:
         # =========================================================== MSM configs
@@ -356,9 +371,9 @@ def main() -> None:
             "algorithmic_bytes_per_launch": bytes_unit * n // tiles, "launches_per_msm": tiles,
             "phase_ms": {("g1_" if g == G1 else "g2_") + k_: v for (g, k_), v in sorted(phase_avg.items()) if k_ != "tiles"},
         }
-        pm = _pmc(acc_kernel.split("<")[0] + "<" + cname) if args.config == 2 else None
-        if pm:
-            roofline["traffic"], roofline["traffic_note"] = pm
+        roofline["traffic"], roofline["traffic_note"] = _pmc(args.config, acc_kernel.split("<")[0] + "<" + cname)
+        if reduced:
+            roofline["traffic"], roofline["traffic_note"] = None, "reduced size: the PMC passes are of the full config"
         if dom == G1 and not acc32 and fpb == 48:
             # the path is integer-ALU bound, not HBM bound: W = 16 mixed additions per scalar, each 8 x 196 + 2 x 105
             # product and 9 x 210 reduction v_mad_i64_i32 + 9 x 14 v_mul_lo_u32 in the carry-free form => fraction of
@@ -367,6 +382,16 @@ def main() -> None:
             roofline["int_alu"] = {
                 "form": "carry-free 28-bit limbs (fp28.h)",
                 "fp_mul_per_s": (n * 16 * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
+                "v_mad_per_mixed_add": v_mad,
+                "v_mad_frac_of_measured_peak": ((n * 16 * v_mad) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
+            }
+        if dom == G2 and CURVE == 1 and not acc32:
+            # G2 on lane pairs, carry-free form (ec28_lp.h: xyzz28_lp_madd): per lane 8 dual products (2 x 196 product +
+            # 210 reduction v_mad_i64_i32 + 14 v_mul_lo_u32 each) and 2 single products (196 + 210 + 14), two lanes per addition
+            v_mad = 2 * (8 * (2 * 196 + 210 + 14) + 2 * (196 + 210 + 14))
+            roofline["int_alu"] = {
+                "form": "carry-free 28-bit limbs on lane pairs (ec28_lp.h)",
+                "fp2_mul_per_s": (n * 16 * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
                 "v_mad_per_mixed_add": v_mad,
                 "v_mad_frac_of_measured_peak": ((n * 16 * v_mad) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
             }
@@ -380,9 +405,10 @@ def main() -> None:
         if len(groups) > 1:
             metric = "(point, scalar) pairs/sec through the G1 MSM and the G2 MSM of a step (BLS12-381 2^24 pairs, shared scalars): each pair is one G1 and one G2 scalar-mul"
         else:
-            metric = "G1 scalar-muls/sec (%s 2^%d-point MSM%s)" % (cfg["curve_name"], log_n, " per GPU" if cfg["scaling"] == "weak" else ", sharded over the ranks")
+            metric = "G1 scalar-muls/sec (%s 2^%d-point MSM%s, inputs resident in HBM: SURVEY 8d protocol a)" % (
+                cfg["curve_name"], log_n, " per GPU" if cfg["scaling"] == "weak" else ", sharded over the ranks")
         if args.config == 2:
-            metric += ", pairings/sec reported in extra"
+            metric += "; protocol b (scalars from host memory) in extra.headline_protocol_b, pairings/sec in extra"
         res_check = res
 
         # ---- extras, after the timed region (never the headline) -------------------------------------------------
@@ -571,21 +597,28 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def _pmc(kernel_prefix: str):
+def _pmc(config: int, kernel_prefix: str):
     """HBM-side traffic of a kernel from the committed PMC passes (the counters cannot be read from inside this process):
-    (bytes per launch, note) or None.  Newest round first."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    (bytes per launch or None, note).  The file names the sources it was taken on (mathlib_amd.build.source_hash):
+    when the kernels have changed since, the figure is withheld rather than quoted for code it was not measured on."""
+    from mathlib_amd.build import source_hash
+
+    for name in ("r03_pmc_traffic.json",):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pm = json.load(f)
-            kk = next(v for k_, v in pm["kernels"].items() if k_.startswith(kernel_prefix) and "Fp2" not in k_)
-            return ((kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024.0,
-                    "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB from profiles/%s (separate --pmc passes), uncorrected: "
-                    "the x2 gfx950 correction applies to wide coalesced streaming reads, this kernel gathers 16-byte pieces of "
-                    "random rows / spills through scratch (uncalibrated pattern); Infinity-Cache hits are counted" % name)
+            kk = next(v for k_, v in pm["configs"][str(config)].items() if k_.startswith(kernel_prefix) and "Fp2" not in k_)
         except Exception:
             continue
-    return None
+        if pm.get("source_hash") != source_hash():
+            return (None, "profiles/%s was taken on other kernel sources (hash %s, commit %s; this tree: %s): traffic withheld"
+                    % (name, pm.get("source_hash"), pm.get("commit"), source_hash()))
+        return ((kk["FETCH_SIZE"] + kk["WRITE_SIZE"]) * 1024.0,
+                "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB from profiles/%s (separate --pmc passes of `bench.py --config %d "
+                "--kernels-only`, commit %s, source hash %s = this tree), uncorrected: the x2 gfx950 correction applies to wide "
+                "coalesced streaming reads, this kernel gathers 16-byte pieces of random rows / spills through scratch "
+                "(uncalibrated pattern); Infinity-Cache hits are counted" % (name, config, pm.get("commit"), pm.get("source_hash")))
+    return (None, "no PMC pass committed for this config")
 
 
 if __name__ == "__main__":

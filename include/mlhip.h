@@ -73,10 +73,16 @@ int mlhip_set_device(int device);
  * per-device partial sums (already in host memory, where each shard's host tail leaves them) are added on the host.
  * No device-side collective is involved: the caller wants the result in host memory.  (The process-per-GPU form,
  * mathlib_amd/dist.py, exchanges the partials with one RCCL all-gather because there every rank wants the total.)
- * Threads pinned with mlhip_set_device are never spread.  A device may be listed more than once. */
+ * Threads pinned with mlhip_set_device are never spread.  A device may be listed more than once.  Device indices are
+ * 0 .. 63 and below the device count; anything else is MLHIP_EINVAL (mlhip_init, mlhip_set_device, the explicit
+ * lists below), and a MLHIP_DEVICES value that does not parse makes every compute call and mlhip_get_devices fail
+ * with MLHIP_EINVAL instead of silently running on device 0.
+ * STATUS: spreading is opt-in (nothing is spread unless the caller lists two or more devices) and has so far run only
+ * on lists that repeat device 0 of a one-GPU box (tests/test_multi_device.py); see DESIGN.md section 5. */
 int mlhip_init(const int* devices, int n_devices);
-int mlhip_get_devices(int* devices, int cap); /* returns the length of the list */
-int mlhip_shutdown(void);                     /* frees every cached plan / arena and forgets the device list */
+int mlhip_get_devices(int* devices, int cap); /* returns the length of the list, or MLHIP_EINVAL (malformed MLHIP_DEVICES) */
+/* frees every cached plan / arena and forgets the device list; the next call reads MLHIP_DEVICES again */
+int mlhip_shutdown(void);
 /* The same MSM with an explicit device list, whatever its size (group: MLHIP_GROUP_G1 / _G2). */
 int mlhip_msm_multi(int curve, int group, const int* devices, int n_devices, const void* points, const void* scalars,
                     int scalars_mont, size_t n, int window_c, void* out_affine);
@@ -150,7 +156,8 @@ int mlhip_msm_launch_shared(mlhip_msm_plan* g1_plan, mlhip_msm_plan* g2_plan, co
 /* Phase timings of the last run with profiling on (HIP events on the plan's stream), milliseconds:
  * [0] digits [1] sort (histogram scan + scatter) [2] bucket accumulation [3] bucket reduction
  * [4] device total [5] host tail [6] the number of tiles the accumulation ran in (device-resident inputs from 2^22 / 2^23
- * points on are accumulated tile by tile; [1] and [2] are then sums over the tiles' launches).  Returns the number of
+ * points on are accumulated tile by tile; [1] and [2] are then sums over the tiles' launches).  A streamed host-buffer
+ * MSM (mlhip_msm_g1 and friends on a pooled plan) records no phase events: [0..5] are then 0.  Returns the number of
  * values written (at most `cap`). */
 int mlhip_msm_plan_set_profiling(mlhip_msm_plan* plan, int on);
 int mlhip_msm_plan_timings(mlhip_msm_plan* plan, float* ms, int cap);

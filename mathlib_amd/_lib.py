@@ -177,6 +177,8 @@ def init_devices(devices=None) -> None:
 def get_devices():
     buf = (c_int * 64)()
     k = load().mlhip_get_devices(buf, 64)
+    if k < 0:  # MLHIP_DEVICES did not parse
+        raise MlhipError(k, load().mlhip_last_error().decode())
     return [buf[i] for i in range(min(k, 64))]
 
 

@@ -47,6 +47,21 @@ def _deps_mtime() -> float:
     return m
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.h, *.hip, *.inc and include/*.h, by name): profiles taken on a GPU box carry
+    it, so that bench.py can tell whether a committed PMC pass was made with the code it is running."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in sorted(os.listdir(root)):
+            if f.endswith((".h", ".hpp", ".hip", ".inc")):
+                h.update(f.encode())
+                with open(os.path.join(root, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _compile(unit: str, newest: float, verbose: bool) -> str:
     src = os.path.join(CSRC, unit)
     obj = os.path.join(OBJ, unit.replace(".hip", ".o"))
@@ -78,4 +93,7 @@ def build(verbose: bool = True, jobs: int | None = None) -> str:
 
 
 if __name__ == "__main__":
-    print(build(verbose="-q" not in sys.argv))
+    if "--source-hash" in sys.argv:
+        print(source_hash())
+    else:
+        print(build(verbose="-q" not in sys.argv))

@@ -26,6 +26,8 @@ thread_local int g_device = 0;       // device of the call in progress on this t
 std::mutex g_devs_mu;
 std::vector<int> g_devs;
 bool g_devs_set = false;
+bool g_devs_bad = false;  // MLHIP_DEVICES did not parse: every compute call fails until mlhip_init / mlhip_shutdown
+constexpr int MLHIP_MAX_DEVICES = 64;  // device indices 0 .. 63 (the per-device tables below are indexed by them)
 size_t g_multi_min_msm = (size_t)1 << 21, g_multi_min_pairing = (size_t)1 << 17;
 
 bool parse_device_list(const char* e, std::vector<int>& out) {
@@ -34,14 +36,14 @@ bool parse_device_list(const char* e, std::vector<int>& out) {
   if (!strcmp(e, "all")) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
-    for (int i = 0; i < n && i < 64; i++) out.push_back(i);
+    for (int i = 0; i < n && i < MLHIP_MAX_DEVICES; i++) out.push_back(i);
     return true;
   }
   const char* q = e;
   while (*q) {
     char* end = nullptr;
     long v = strtol(q, &end, 10);
-    if (end == q || v < 0 || v > 1023 || out.size() >= 64) return false;
+    if (end == q || v < 0 || v >= MLHIP_MAX_DEVICES || out.size() >= 64) return false;
     out.push_back((int)v);
     q = end;
     if (*q == ',') q++;
@@ -54,7 +56,8 @@ std::vector<int> device_list() {
   std::lock_guard<std::mutex> lk(g_devs_mu);
   if (!g_devs_set) {
     g_devs_set = true;
-    if (!parse_device_list(getenv("MLHIP_DEVICES"), g_devs)) g_devs.clear();
+    g_devs_bad = !parse_device_list(getenv("MLHIP_DEVICES"), g_devs);
+    if (g_devs_bad) g_devs.clear();
     if (const char* e = getenv("MLHIP_MULTI_MIN")) g_multi_min_msm = strtoull(e, nullptr, 10);
     if (const char* e = getenv("MLHIP_MULTI_MIN_PAIRINGS")) g_multi_min_pairing = strtoull(e, nullptr, 10);
   }
@@ -68,11 +71,11 @@ int ensure_device() {
     return mlhip_rt::fail(MLHIP_ENODEVICE,
                           std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
   int d = g_device_sel;
-  if (d < 0) {
-    const std::vector<int> l = device_list();
-    d = l.empty() ? 0 : l[0];
-  }
-  if (d < 0 || d >= n) return mlhip_rt::fail(MLHIP_EINVAL, "device index out of range");
+  const std::vector<int> l = device_list();
+  if (g_devs_bad)
+    return mlhip_rt::fail(MLHIP_EINVAL, "MLHIP_DEVICES is malformed (want \"all\" or a comma-separated list of device indices 0 .. 63)");
+  if (d < 0) d = l.empty() ? 0 : l[0];
+  if (d < 0 || d >= n || d >= MLHIP_MAX_DEVICES) return mlhip_rt::fail(MLHIP_EINVAL, "device index out of range");
   g_device = d;
   HIPCHK(hipSetDevice(d));
   return 0;
@@ -189,7 +192,7 @@ struct Lease {
   size_t cap = 0;
 };
 std::mutex g_leases_mu;
-std::vector<Lease> g_leases[64];  // idle leases per device
+std::vector<Lease> g_leases[MLHIP_MAX_DEVICES];  // idle leases per device
 
 struct HostCall {
   int device;
@@ -199,7 +202,7 @@ struct HostCall {
   HostCall() : device(g_device) {
     {
       std::lock_guard<std::mutex> lk(g_leases_mu);
-      std::vector<Lease>& idle = g_leases[device & 63];
+      std::vector<Lease>& idle = g_leases[device];
       if (!idle.empty()) {
         l = idle.back();
         idle.pop_back();
@@ -214,7 +217,7 @@ struct HostCall {
     if (!l.st) return;
     (void)hipStreamSynchronize(l.st);  // nothing of this call is left in flight when the caller gets its buffers back
     std::lock_guard<std::mutex> lk(g_leases_mu);
-    g_leases[device & 63].push_back(l);
+    g_leases[device].push_back(l);
   }
   // call once, before the first dev() / up(): the total number of device bytes this call needs
   void reserve(size_t bytes) {
@@ -547,7 +550,7 @@ int mlhip_device_count(int* count) {
 }
 
 int mlhip_set_device(int device) {
-  if (device < -1) return mlhip_rt::fail(MLHIP_EINVAL, "negative device index");
+  if (device < -1 || device >= MLHIP_MAX_DEVICES) return mlhip_rt::fail(MLHIP_EINVAL, "device index: -1 (unpin) or 0 .. 63");
   g_device_sel = device;
   return 0;
 }
@@ -559,19 +562,24 @@ int mlhip_init(const int* devices, int n_devices) {
   if (n_devices == 0) {
     parse_device_list("all", l);
   } else {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) count = 0;  // no device here: the first compute call reports it
     for (int i = 0; i < n_devices; i++) {
-      if (devices[i] < 0) return mlhip_rt::fail(MLHIP_EINVAL, "negative device index in the device list");
+      if (devices[i] < 0 || devices[i] >= MLHIP_MAX_DEVICES || (count > 0 && devices[i] >= count))
+        return mlhip_rt::fail(MLHIP_EINVAL, "device list: index out of range (0 .. min(63, device count - 1))");
       l.push_back(devices[i]);
     }
   }
   (void)device_list();  // the environment's thresholds are read once, before the list is replaced
   std::lock_guard<std::mutex> lk(g_devs_mu);
   g_devs = l;
+  g_devs_bad = false;
   return 0;
 }
 
 int mlhip_get_devices(int* devices, int cap) {
   const std::vector<int> l = device_list();
+  if (g_devs_bad) return mlhip_rt::fail(MLHIP_EINVAL, "MLHIP_DEVICES is malformed");
   for (size_t i = 0; i < l.size() && (int)i < cap; i++)
     if (devices) devices[i] = l[i];
   return (int)l.size();
@@ -581,6 +589,7 @@ int mlhip_shutdown(void) {
   mlhip_release_cache();
   std::lock_guard<std::mutex> lk(g_devs_mu);
   g_devs.clear();
+  g_devs_set = g_devs_bad = false;  // the next call reads MLHIP_DEVICES again
   return 0;
 }
 
@@ -599,7 +608,7 @@ int mlhip_msm_multi(int curve, int group, const int* devices, int n_devices, con
   if (!points || !scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
   std::vector<int> devs(devices, devices + n_devices);
   for (int d : devs)
-    if (d < 0) return mlhip_rt::fail(MLHIP_EINVAL, "negative device index in the device list");
+    if (d < 0 || d >= MLHIP_MAX_DEVICES) return mlhip_rt::fail(MLHIP_EINVAL, "device list: index out of range (0 .. 63)");
   if (devs.size() > n) devs.resize(n);
   return msm_multi(devs, curve, group, points, scalars, scalars_mont, n, window_c, out_affine, ptsz);
 }
@@ -777,13 +786,14 @@ int mlhip_msm_g1g2(int curve, const void* points_g1, const void* points_g2, cons
     return 0;
   }
   if (!points_g1 || !points_g2 || !scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
-  if (window_c == 0) window_c = pick_window(n, sz.fr_bits);
   if (!spread_devices(n, false).empty()) {
-    // spread over the device list: every device sorts its own shard anyway -- two sharded MSMs
+    // spread over the device list: every device sorts its own shard anyway -- two sharded MSMs; the caller's window_c
+    // travels as given (0 = each shard picks the width of its own size)
     int rc = msm_host_buffers(curve, MLHIP_GROUP_G1, points_g1, scalars, scalars_mont, n, window_c, out_g1);
     if (rc) return rc;
     return msm_host_buffers(curve, MLHIP_GROUP_G2, points_g2, scalars, scalars_mont, n, window_c, out_g2);
   }
+  if (window_c == 0) window_c = pick_window(n, sz.fr_bits);
   int rc = ensure_device();
   if (rc) return rc;
   PoolEntry* e1 = pool_acquire(curve, MLHIP_GROUP_G1, window_c, n, sz.g1, rc);
@@ -946,7 +956,7 @@ int mlhip_bases_create_multi(int curve, int group, const int* devices, int n_dev
   if (n_devices < 1 || n_devices > 64 || !devices) return mlhip_rt::fail(MLHIP_EINVAL, "device list: 1 .. 64 entries");
   std::vector<int> devs(devices, devices + n_devices);
   for (int d : devs)
-    if (d < 0) return mlhip_rt::fail(MLHIP_EINVAL, "negative device index in the device list");
+    if (d < 0 || d >= MLHIP_MAX_DEVICES) return mlhip_rt::fail(MLHIP_EINVAL, "device list: index out of range (0 .. 63)");
   if (devs.size() > n) devs.resize(n);
   return bases_create_on(devs, curve, group, points, n, window_c, group == MLHIP_GROUP_G1 ? sz.g1 : sz.g2, out);
 }

@@ -710,6 +710,8 @@ int plan_finish(mlhip_msm_plan* p, void* out_affine, void* out_xyzz) {
       for (int i = 0; i < 4; i++) HIPCHK(hipEventElapsedTime(&p->ms[i], p->ev[i], p->ev[i + 1]));
       HIPCHK(hipEventElapsedTime(&p->ms[4], p->ev[0], p->ev[4]));
       p->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } else if (p->profiling) {
+      for (int i = 0; i < 6; i++) p->ms[i] = 0;  // a streamed host-buffer MSM records no phase events: nothing stale is left
     }
   }
   A r;

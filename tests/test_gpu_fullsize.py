@@ -266,3 +266,68 @@ def test_shared_scalars_config4_shard(mlhip, monkeypatch):
     assert cref.msm(cid, 1, pts[1].cpu().numpy(), ss, n, False, 16, threads) == want1
     a.close()
     b.close()
+
+
+def test_config4_whole_n1(mlhip):
+    """BASELINE configs[3] exactly as `bench.py --config 4` runs it at N = 1: BLS12-381 2^24 pairs, G1 and G2 MSM of ONE
+    scalar vector through mlhip_msm_launch_shared (16 tiles of 2^20 pairs, each sorted once for both groups).
+    (1) == mlhip_g1_sum / mlhip_g2_sum of the 8 contiguous 2^21-pair shard results (independent plan runs: the size
+        and path test_msm_other_config_shapes pins to the C oracle, and what 8 ranks would each compute);
+    (2) linearity, independent of any MSM path: P_i = [k_i]G1, Q_i = [k'_i]G2  =>  results are [sum k_i s_i]G1 and
+        [sum k'_i s_i]G2, the integer dot products taken exactly on 16-bit limbs (2^24 products < 2^32 sum below 2^56)."""
+    import torch
+
+    from conftest import load_golden
+    from mathlib_amd.driver import Curve
+
+    g = load_golden("BLS12-381")
+    cid = g["curve_id"]
+    lib = mlhip.load()
+    _, g1b, g2b, _ = mlhip.sizes(cid)
+    log_n, shards = 24, 8
+    n = 1 << log_n
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2404)
+    rnd = lambda m: torch.randint(-(1 << 63), (1 << 63) - 1, (m, 4), dtype=torch.int64, generator=gen, device=dev).view(torch.uint8).reshape(m, 32).contiguous()  # noqa: E731
+    st = torch.cuda.current_stream().cuda_stream
+    s = rnd(n)
+
+    def limbs16(x):  # n x 32 bytes -> n x 16 int64 limbs of 16 bits, little endian
+        return x.view(torch.int16).reshape(-1, 16).to(torch.int64) & 0xFFFF
+
+    def dot(k):  # exact integer sum_i k_i * s_i
+        kl, sl = limbs16(k), limbs16(s)
+        tot = 0
+        for a in range(16):
+            col = (kl[:, a : a + 1] * sl).sum(0).cpu().tolist()
+            tot += sum(int(v) << (16 * (a + b)) for b, v in enumerate(col))
+        return tot
+
+    pts, want = {}, {}
+    r = int(g["r"], 16) if isinstance(g.get("r"), str) else 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    cv = Curve(cid)
+    for group, sz, key in ((1, g1b, "g1_gen"), (2, g2b, "g2_gen")):
+        base = torch.frombuffer(bytearray(bytes.fromhex(g[key])), dtype=torch.uint8).to(dev)
+        pts[group] = torch.empty(n * sz, dtype=torch.uint8, device=dev)
+        k = rnd(n)
+        mlhip.check(lib.mlhip_scalar_mul_device(cid, group, base.data_ptr(), 0, k.data_ptr(), 0, n, pts[group].data_ptr(), st))
+        torch.cuda.synchronize()
+        z = cv.NewZrFromInt(dot(k) % r)
+        want[group] = (cv.GenG1() if group == 1 else cv.GenG2()).Mul(z).raw
+        del k
+    a, b = mlhip.MsmPlan(cid, 1, n, 16), mlhip.MsmPlan(cid, 2, n, 16)
+    a.launch_shared(b, pts[1].data_ptr(), pts[2].data_ptr(), s.data_ptr(), n, False, st)
+    whole = {1: a.finish(), 2: b.finish()}
+    a.close()
+    b.close()
+    lib.mlhip_release_cache()
+    per = n // shards
+    for group, sz in ((1, g1b), (2, g2b)):
+        plan = mlhip.MsmPlan(cid, group, per, 16)
+        parts = b"".join(plan.run(pts[group].data_ptr() + i * per * sz, s.data_ptr() + i * per * 32, per, False, st) for i in range(shards))
+        plan.close()
+        out = ctypes.create_string_buffer(sz)
+        mlhip.check((lib.mlhip_g1_sum if group == 1 else lib.mlhip_g2_sum)(cid, parts, shards, out))
+        assert out.raw == whole[group], group
+        assert whole[group] == want[group], group

@@ -21,15 +21,18 @@ def _devs(*d):
 def test_device_list_host_logic(mlhip):
     """no GPU needed: argument checking, the list round trip, thread pinning"""
     lib = mlhip.load()
+    d1 = 0 if mlhip.device_count() == 1 else 1  # with devices present, indices at or above their count are rejected
     try:
-        arr, k = _devs(0, 0, 1)
+        arr, k = _devs(0, 0, d1)
         assert lib.mlhip_init(arr, k) == 0
-        assert mlhip.get_devices() == [0, 0, 1]
+        assert mlhip.get_devices() == [0, 0, d1]
         bad, k = _devs(0, -2)
-        assert lib.mlhip_init(bad, k) == -1 and b"negative" in lib.mlhip_last_error()
+        assert lib.mlhip_init(bad, k) == -1 and b"out of range" in lib.mlhip_last_error()
+        big, k = _devs(0, 64)  # indices are 0 .. 63: the per-device tables are indexed by them, nothing is masked
+        assert lib.mlhip_init(big, k) == -1 and b"out of range" in lib.mlhip_last_error()
         assert lib.mlhip_init(None, 3) == -1
         assert lib.mlhip_init(arr, 65) == -1
-        assert mlhip.get_devices() == [0, 0, 1]  # a rejected list changes nothing
+        assert mlhip.get_devices() == [0, 0, d1]  # a rejected list changes nothing
         out = ctypes.create_string_buffer(96)
         assert lib.mlhip_msm_multi(1, 1, None, 2, b"x", b"y", 0, 1, 0, out) == -1
         assert lib.mlhip_msm_multi(1, 3, arr, 2, b"x", b"y", 0, 1, 0, out) == -1
@@ -37,7 +40,9 @@ def test_device_list_host_logic(mlhip):
         # n = 0: the identity, no device touched (MultiExp on empty slices, bls12-381.go:777)
         out = ctypes.create_string_buffer(b"\xff" * 96, 96)
         assert lib.mlhip_msm_multi(1, 1, arr, 2, None, None, 0, 0, 0, out) == 0 and out.raw == bytes(96)
-        assert lib.mlhip_set_device(-1) == 0 and lib.mlhip_set_device(-2) == -1
+        assert lib.mlhip_set_device(-1) == 0 and lib.mlhip_set_device(-2) == -1 and lib.mlhip_set_device(64) == -1
+        big, k2 = _devs(0, 1023)
+        assert lib.mlhip_msm_multi(1, 1, big, k2, b"x", b"y", 0, 2, 0, out) == -1 and b"out of range" in lib.mlhip_last_error()
     finally:
         lib.mlhip_shutdown()
     assert mlhip.get_devices() == []
@@ -49,10 +54,35 @@ def test_device_list_from_the_environment():
         "from mathlib_amd import _lib\n"
         "print(_lib.get_devices())\n" % ROOT
     )
-    for env, want in (("0,2,1", "[0, 2, 1]"), ("", "[]"), ("0,x", "[]"), ("3", "[3]")):
+    for env, want in (("0,2,1", "[0, 2, 1]"), ("", "[]"), ("3", "[3]")):
         e = dict(os.environ, MLHIP_DEVICES=env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout
         assert out.strip().splitlines()[-1] == want, (env, out)
+
+
+def test_malformed_environment_list_is_an_error_not_device_0():
+    """MLHIP_DEVICES that does not parse: mlhip_get_devices and every compute call fail with MLHIP_EINVAL (they used to
+    run on device 0 without a word); mlhip_shutdown makes the library read the variable again."""
+    code = (
+        "import sys, os, ctypes; sys.path.insert(0, %r)\n"
+        "from mathlib_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = (ctypes.c_int * 4)()\n"
+        "print(lib.mlhip_get_devices(buf, 4), lib.mlhip_last_error().decode())\n"
+        "out = ctypes.create_string_buffer(96)\n"
+        "rc = lib.mlhip_msm_g1(1, bytes(96), bytes(32), 0, 1, 0, out)\n"
+        "print(rc, lib.mlhip_last_error().decode())\n"
+        "os.environ['MLHIP_DEVICES'] = '1,0'\n"
+        "lib.mlhip_shutdown()\n"
+        "print(_lib.get_devices())\n" % ROOT
+    )
+    for env in ("0,x", "0,64", "-1", "0;1"):
+        e = dict(os.environ, MLHIP_DEVICES=env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.strip().splitlines()
+        assert out[-3].startswith("-1 ") and "malformed" in out[-3], (env, out)
+        # without a GPU the missing device is reported first; with one, the malformed list
+        assert out[-2].startswith("-1 ") and "malformed" in out[-2] or out[-2].startswith("-2 "), (env, out)
+        assert out[-1] == "[1, 0]", (env, out)
 
 
 def test_multi_without_a_gpu_fails_loudly(mlhip):

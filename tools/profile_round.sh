@@ -1,20 +1,33 @@
 #!/bin/bash
 # The round's judged profile artifacts, produced on the GPU box from the repo root:
-#   1. python bench.py (default flags the driver uses)                      -> $out/bench_default.json
-#   2. rocprofv3 --kernel-trace --stats of `bench.py --kernels-only`        -> $out/stats/  (+ the bench line under rocprof)
-#   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same -> $out/pmc_fetch, $out/pmc_write
-#   4. the same three for `bench.py --config 3 --kernels-only` (the pairing batch)
-# Usage: bash tools/profile_round.sh gpurun_out/r02_profile
+#   1. python bench.py (default flags the driver uses)                        -> $out/bench_default.json
+#   2. per BASELINE config N in 2 3 4 5 (`bench.py --config N --kernels-only`, rocprofv3 directly in front of python3):
+#      rocprofv3 --kernel-trace --stats                                       -> $out/stats_cN/  (+ the bench line under rocprof)
+#      rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)        -> $out/pmc_fetch_cN, $out/pmc_write_cN
+#   3. the full bench lines of configs 3, 4, 5                                -> $out/bench_cN.json
+# Usage: bash tools/profile_round.sh gpurun_out/r03_profile ["2 3 4 5"]
+# Afterwards, here: python tools/pmc_traffic.py profiles/rNN_pmc_traffic.json $(cat $out/source_hash.txt) $(git rev-parse --short HEAD) \
+#                     2:$out/pmc_fetch_c2/..counter_collection.csv 2:$out/pmc_write_c2/.. 3:.. (tools/collect_profiles.py does it)
 set -e
-out=${1:-gpurun_out/r02_profile}
+out=${1:-gpurun_out/r03_profile}
+configs=${2:-2 3 4 5}
 mkdir -p "$out"
 export TMPDIR=/tmp
+python3 -m mathlib_amd.build --source-hash > "$out/source_hash.txt"
 python3 bench.py --steps 20 --warmup 5 > "$out/bench_default.json" 2> "$out/bench_default.err"
-rocprofv3 --kernel-trace --stats -d "$out/stats" -o b --output-format csv -- python3 bench.py --kernels-only --steps 10 --warmup 3 > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o f --output-format csv -- python3 bench.py --kernels-only --steps 3 --warmup 1 > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o w --output-format csv -- python3 bench.py --kernels-only --steps 3 --warmup 1 > "$out/pmc_write.json" 2> "$out/pmc_write.err"
-rocprofv3 --kernel-trace --stats -d "$out/stats_c3" -o b --output-format csv -- python3 bench.py --config 3 --kernels-only --steps 5 --warmup 2 > "$out/bench_c3_under_rocprof.json" 2> "$out/stats_c3.err"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch_c3" -o f --output-format csv -- python3 bench.py --config 3 --kernels-only --steps 3 --warmup 1 > "$out/pmc_fetch_c3.json" 2> "$out/pmc_fetch_c3.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write_c3" -o w --output-format csv -- python3 bench.py --config 3 --kernels-only --steps 3 --warmup 1 > "$out/pmc_write_c3.json" 2> "$out/pmc_write_c3.err"
-python3 bench.py --config 3 --steps 5 --warmup 2 > "$out/bench_c3.json" 2> "$out/bench_c3.err"
-find "$out" -name "*stats*.csv" | head
+echo "bench default done"
+for c in $configs; do
+  steps=10; warm=3
+  if [ "$c" = 4 ]; then steps=3; warm=1; fi
+  rocprofv3 --kernel-trace --stats -d "$out/stats_c$c" -o b --output-format csv -- python3 bench.py --config $c --kernels-only --steps $steps --warmup $warm > "$out/bench_c${c}_under_rocprof.json" 2> "$out/stats_c$c.err"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch_c$c" -o f --output-format csv -- python3 bench.py --config $c --kernels-only --steps 3 --warmup 1 > "$out/pmc_fetch_c$c.json" 2> "$out/pmc_fetch_c$c.err"
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write_c$c" -o w --output-format csv -- python3 bench.py --config $c --kernels-only --steps 3 --warmup 1 > "$out/pmc_write_c$c.json" 2> "$out/pmc_write_c$c.err"
+  echo "config $c profiled"
+  if [ "$c" != 2 ]; then
+    python3 bench.py --config $c --steps 5 --warmup 2 > "$out/bench_c$c.json" 2> "$out/bench_c$c.err"
+    echo "config $c bench line done"
+  fi
+done
+# the traces themselves are large: keep the stats and the counter tables only
+find "$out" -name "*kernel_trace.csv" -size +20M -delete
+find "$out" -name "*stats*.csv"
