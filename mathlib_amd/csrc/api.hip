@@ -1,8 +1,11 @@
 // api.hip -- the extern "C" surface of libmlhip.so (include/mlhip.h): argument checking, device
 // selection, host-buffer staging and dispatch to the per-curve translation units.  No kernels here.
 // There is no CPU fallback: every compute entry point needs a HIP device (MLHIP_ENODEVICE otherwise).
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -532,6 +535,95 @@ namespace mlhip_rt {
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
+}
+
+// ---- host worker threads (the per-window half of an MSM's host tail) ----------------------------------------------------
+// One small pool per process, started on first use and never joined (a Go process loads the library for its lifetime;
+// the workers sleep on a condition variable between calls, after a short spin so that back-to-back MSMs do not pay a
+// futex wake-up each).  One call at a time owns the pool; a second caller arriving meanwhile does its own jobs.
+namespace {
+struct HostJob {
+  void (*fn)(void*, int);
+  void* ctx;
+  int njobs;
+  std::atomic<int> next{0}, remaining{0};
+};
+struct HostPool {
+  std::mutex owner;  // held by the call that is using the workers
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<unsigned long> gen{0};
+  std::shared_ptr<HostJob> job;  // guarded by mu
+  int workers = 0;
+};
+HostPool* g_host_pool = nullptr;
+std::once_flag g_host_pool_once;
+
+void host_job_run(HostJob& j) {
+  for (;;) {
+    const int k = j.next.fetch_add(1, std::memory_order_relaxed);
+    if (k >= j.njobs) return;
+    j.fn(j.ctx, k);
+    j.remaining.fetch_sub(1, std::memory_order_release);
+  }
+}
+
+void host_worker(HostPool* pool) {
+  unsigned long seen = 0;
+  for (;;) {
+    // spin for a few tens of microseconds (a job is often followed by another one at once), then sleep
+    bool fresh = false;
+    for (int i = 0; i < 2000 && !fresh; i++) {
+      fresh = pool->gen.load(std::memory_order_acquire) != seen;
+      if (!fresh) __builtin_ia32_pause();
+    }
+    std::shared_ptr<HostJob> j;
+    {
+      std::unique_lock<std::mutex> lk(pool->mu);
+      pool->cv.wait(lk, [&] { return pool->gen.load(std::memory_order_relaxed) != seen; });
+      seen = pool->gen.load(std::memory_order_relaxed);
+      j = pool->job;
+    }
+    if (j) host_job_run(*j);
+  }
+}
+
+void host_pool_start() {
+  int total = 0;
+  if (const char* e = getenv("MLHIP_HOST_THREADS")) total = atoi(e);
+  if (total <= 0) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    total = hw >= 8 ? 8 : (hw > 0 ? (int)hw : 1);
+  }
+  if (total > 64) total = 64;
+  HostPool* pool = new HostPool;  // never freed: the workers outlive every static destructor
+  pool->workers = total - 1;
+  for (int i = 0; i < pool->workers; i++) std::thread(host_worker, pool).detach();
+  g_host_pool = pool;
+}
+}  // namespace
+
+void host_parallel(int njobs, void (*fn)(void*, int), void* ctx) {
+  std::call_once(g_host_pool_once, host_pool_start);
+  HostPool* pool = g_host_pool;
+  std::unique_lock<std::mutex> own(pool->owner, std::try_to_lock);
+  if (njobs < 2 || pool->workers == 0 || !own.owns_lock()) {
+    for (int k = 0; k < njobs; k++) fn(ctx, k);
+    return;
+  }
+  auto j = std::make_shared<HostJob>();
+  j->fn = fn;
+  j->ctx = ctx;
+  j->njobs = njobs;
+  j->remaining.store(njobs, std::memory_order_relaxed);
+  {
+    std::lock_guard<std::mutex> lk(pool->mu);
+    pool->job = j;
+    pool->gen.fetch_add(1, std::memory_order_release);
+  }
+  pool->cv.notify_all();
+  host_job_run(*j);
+  while (j->remaining.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
 }
 }  // namespace mlhip_rt
 

@@ -9,6 +9,11 @@
 
 namespace mlhip_rt {
 int fail(int code, const std::string& msg);
+// fn(ctx, j) for j = 0 .. njobs - 1 on the library's host worker threads and the calling thread; returns when all are
+// done.  The workers are started on first use (MLHIP_HOST_THREADS = threads per call incl. the caller, default
+// min(8, cores); 1 = none); a call that finds them busy with another caller's jobs, or njobs < 2, runs everything itself.
+// Used by the host tail of an MSM (msm_plan.h: host_tail): the per-window sums are independent of each other.
+void host_parallel(int njobs, void (*fn)(void*, int), void* ctx);
 }
 
 #define HIPCHK(x)                                                                                             \

@@ -119,34 +119,50 @@ int plan_alloc(mlhip_msm_plan* p) {
   return 0;
 }
 
-// Horner over bit positions: total = sum_w 2^(cw) [ out[w][0..3] summed + L * sum_k 2^k out[w][4+k] ]
+// total = sum_w 2^off(w) V_w,  V_w = out[w][0..3] summed + 2^lgL sum_k 2^k out[w][4+k]
+// (window w starts at bit off(w): msm_win_layout, widths differ by at most one bit).  The V_w are independent chains of
+// nb + lgL doublings and nb + 4 additions each -- two thirds of the tail's field products -- and run on the library's host
+// workers (mlhip_rt::host_parallel); what stays sequential is the Horner pass over the windows, one doubling per scalar
+// bit.  2^20 points, c = 16: 0.20 -> 0.10 ms.  MLHIP_HOST_THREADS=1 keeps everything on the calling thread.
+template <class F>
+struct HostTailJob {
+  const mlhip_msm_plan* p;
+  const XYZZ<F>* o;
+  XYZZ<F>* V;
+};
+template <class F>
+void host_tail_window(void* ctx, int w) {
+  const HostTailJob<F>& job = *static_cast<const HostTailJob<F>*>(ctx);
+  const mlhip_msm_plan* p = job.p;
+  const XYZZ<F>* o = job.o + (size_t)w * p->nsel;
+  XYZZ<F> acc, d;
+  xyzz_set_inf<F>(acc);
+  for (int k = p->nb - 1; k >= 0; k--) {
+    xyzz_dbl<F>(d, acc);
+    acc = d;
+    xyzz_add<F>(acc, o[4 + k]);
+  }
+  for (int k = 0; k < p->lgL; k++) {
+    xyzz_dbl<F>(d, acc);
+    acc = d;
+  }
+  for (int h = 0; h < 4; h++) xyzz_add<F>(acc, o[h]);
+  job.V[w] = acc;
+}
 template <class F>
 void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
-  const XYZZ<F>* o = reinterpret_cast<const XYZZ<F>*>(p->h_out);
-  // window w starts at bit off(w) (msm_win_layout: widths differ by at most one bit); its masked sums carry the weights
-  // 2^(lgL + k) relative to that, which may reach into the next window's positions -- slots accumulate
   const WinLayout wl = msm_win_layout(F::Curve::FR_BITS, p->c);
-  const int npos = msm_win_off(wl.base, wl.rem, p->W - 1) + p->c + 1;
-  std::vector<XYZZ<F>> slot(npos);
-  for (int i = 0; i < npos; i++) xyzz_set_inf<F>(slot[i]);
-  for (int w = 0; w < p->W; w++) {
-    const int off = msm_win_off(wl.base, wl.rem, w);
-    XYZZ<F> s = o[w * p->nsel + 0];
-    for (int h = 1; h < 4; h++) xyzz_add<F>(s, o[w * p->nsel + h]);
-    xyzz_add<F>(slot[off], s);
-    for (int k = 0; k < p->nb; k++) xyzz_add<F>(slot[off + p->lgL + k], o[w * p->nsel + 4 + k]);
-  }
+  std::vector<XYZZ<F>> V(p->W);
+  HostTailJob<F> job{p, reinterpret_cast<const XYZZ<F>*>(p->h_out), V.data()};
+  mlhip_rt::host_parallel(p->W, host_tail_window<F>, &job);
   xyzz_set_inf<F>(total);
-  bool started = false;
-  for (int i = npos - 1; i >= 0; i--) {
-    if (started) {
+  for (int w = p->W - 1; w >= 0; w--) {
+    xyzz_add<F>(total, V[w]);
+    const int down = w > 0 ? msm_win_off(wl.base, wl.rem, w) - msm_win_off(wl.base, wl.rem, w - 1) : 0;
+    for (int k = 0; k < down; k++) {
       XYZZ<F> d;
       xyzz_dbl<F>(d, total);
       total = d;
-    }
-    if (!xyzz_is_inf<F>(slot[i])) {
-      xyzz_add<F>(total, slot[i]);
-      started = true;
     }
   }
 }
