@@ -541,12 +541,19 @@ int fail(int code, const std::string& msg) {
 // One small pool per process, started on first use and never joined (a Go process loads the library for its lifetime;
 // the workers sleep on a condition variable between calls, after a short spin so that back-to-back MSMs do not pay a
 // futex wake-up each).  One call at a time owns the pool; a second caller arriving meanwhile does its own jobs.
+// A call never waits for a worker longer than the job would take the caller itself: jobs are pure functions of a blob
+// the call COPIES into the (reference-counted) job record, so the caller can run a job a worker has claimed but not
+// finished a second time and take whichever result is there first -- a worker that the scheduler parked behind a
+// spinning thread for a timeslice (seen: 6 ms, once in 200 MSMs) costs nothing, and a worker that wakes up late only
+// ever touches the record, never the caller's memory.
 namespace {
 struct HostJob {
-  void (*fn)(void*, int);
-  void* ctx;
-  int njobs;
-  std::atomic<int> next{0}, remaining{0};
+  void (*fn)(const void*, int, void*);
+  int njobs = 0;
+  size_t out_stride = 0;
+  std::vector<unsigned char> in, out_worker, out_caller;
+  std::atomic<int> next{0};
+  std::atomic<int> state[64];  // 0 not started, 1 claimed by a worker, 2 worker's result valid, 3 caller's result valid
 };
 struct HostPool {
   std::mutex owner;  // held by the call that is using the workers
@@ -558,15 +565,6 @@ struct HostPool {
 };
 HostPool* g_host_pool = nullptr;
 std::once_flag g_host_pool_once;
-
-void host_job_run(HostJob& j) {
-  for (;;) {
-    const int k = j.next.fetch_add(1, std::memory_order_relaxed);
-    if (k >= j.njobs) return;
-    j.fn(j.ctx, k);
-    j.remaining.fetch_sub(1, std::memory_order_release);
-  }
-}
 
 void host_worker(HostPool* pool) {
   unsigned long seen = 0;
@@ -584,7 +582,16 @@ void host_worker(HostPool* pool) {
       seen = pool->gen.load(std::memory_order_relaxed);
       j = pool->job;
     }
-    if (j) host_job_run(*j);
+    if (!j) continue;
+    for (;;) {
+      const int k = j->next.fetch_add(1, std::memory_order_relaxed);
+      if (k >= j->njobs) break;
+      int expect = 0;
+      if (!j->state[k].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) continue;
+      j->fn(j->in.data(), k, j->out_worker.data() + (size_t)k * j->out_stride);
+      expect = 1;
+      (void)j->state[k].compare_exchange_strong(expect, 2, std::memory_order_acq_rel);  // lost: the caller redid it
+    }
   }
 }
 
@@ -603,27 +610,55 @@ void host_pool_start() {
 }
 }  // namespace
 
-void host_parallel(int njobs, void (*fn)(void*, int), void* ctx) {
+void host_parallel(int njobs, void (*fn)(const void*, int, void*), const void* in, size_t in_bytes, void* out, size_t out_stride) {
   std::call_once(g_host_pool_once, host_pool_start);
   HostPool* pool = g_host_pool;
   std::unique_lock<std::mutex> own(pool->owner, std::try_to_lock);
-  if (njobs < 2 || pool->workers == 0 || !own.owns_lock()) {
-    for (int k = 0; k < njobs; k++) fn(ctx, k);
+  if (njobs < 2 || njobs > 64 || pool->workers == 0 || !own.owns_lock()) {
+    for (int k = 0; k < njobs; k++) fn(in, k, (unsigned char*)out + (size_t)k * out_stride);
     return;
   }
   auto j = std::make_shared<HostJob>();
   j->fn = fn;
-  j->ctx = ctx;
   j->njobs = njobs;
-  j->remaining.store(njobs, std::memory_order_relaxed);
+  j->out_stride = out_stride;
+  j->in.assign((const unsigned char*)in, (const unsigned char*)in + in_bytes);
+  j->out_worker.resize((size_t)njobs * out_stride);
+  j->out_caller.resize((size_t)njobs * out_stride);
+  for (int k = 0; k < njobs; k++) j->state[k].store(0, std::memory_order_relaxed);
   {
     std::lock_guard<std::mutex> lk(pool->mu);
     pool->job = j;
     pool->gen.fetch_add(1, std::memory_order_release);
   }
   pool->cv.notify_all();
-  host_job_run(*j);
-  while (j->remaining.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+  // the caller takes jobs from the top end, the workers from the bottom
+  for (int k = njobs - 1; k >= 0; k--) {
+    int st = j->state[k].load(std::memory_order_acquire);
+    if (st == 0) {
+      int expect = 0;
+      if (j->state[k].compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) {
+        // claimed and (below) computed by the caller; nobody else looks at out_caller before the call returns
+        fn(j->in.data(), k, j->out_caller.data() + (size_t)k * out_stride);
+        continue;
+      }
+      st = expect;
+    }
+    if (st == 1) {
+      // a worker is on it: give it about the time of one job, then do the job here as well
+      for (int spin = 0; spin < 400 && j->state[k].load(std::memory_order_acquire) == 1; spin++) __builtin_ia32_pause();
+      if (j->state[k].load(std::memory_order_acquire) == 1) {
+        fn(j->in.data(), k, j->out_caller.data() + (size_t)k * out_stride);
+        int expect = 1;
+        (void)j->state[k].compare_exchange_strong(expect, 3, std::memory_order_acq_rel);  // lost: the worker's is there
+      }
+    }
+  }
+  for (int k = 0; k < njobs; k++) {
+    const int st = j->state[k].load(std::memory_order_acquire);
+    const unsigned char* src = (st == 2 ? j->out_worker.data() : j->out_caller.data()) + (size_t)k * out_stride;
+    memcpy((unsigned char*)out + (size_t)k * out_stride, src, out_stride);
+  }
 }
 }  // namespace mlhip_rt
 

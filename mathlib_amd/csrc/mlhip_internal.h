@@ -9,11 +9,13 @@
 
 namespace mlhip_rt {
 int fail(int code, const std::string& msg);
-// fn(ctx, j) for j = 0 .. njobs - 1 on the library's host worker threads and the calling thread; returns when all are
-// done.  The workers are started on first use (MLHIP_HOST_THREADS = threads per call incl. the caller, default
-// min(8, cores); 1 = none); a call that finds them busy with another caller's jobs, or njobs < 2, runs everything itself.
+// out[j] = fn(in, j) for j = 0 .. njobs - 1 on the library's host worker threads and the calling thread; returns when
+// all are there.  fn must be a pure function of the `in_bytes` bytes at `in` (the call copies them: a worker never touches
+// the caller's memory) writing `out_stride` bytes.  The workers are started on first use (MLHIP_HOST_THREADS = threads per
+// call incl. the caller, default min(8, cores); 1 = none); a call that finds them busy with another caller's jobs, or
+// njobs < 2, computes everything itself, and a job a worker is slow with is computed by the caller as well (api.hip).
 // Used by the host tail of an MSM (msm_plan.h: host_tail): the per-window sums are independent of each other.
-void host_parallel(int njobs, void (*fn)(void*, int), void* ctx);
+void host_parallel(int njobs, void (*fn)(const void*, int, void*), const void* in, size_t in_bytes, void* out, size_t out_stride);
 }
 
 #define HIPCHK(x)                                                                                             \

@@ -124,37 +124,38 @@ int plan_alloc(mlhip_msm_plan* p) {
 // nb + lgL doublings and nb + 4 additions each -- two thirds of the tail's field products -- and run on the library's host
 // workers (mlhip_rt::host_parallel); what stays sequential is the Horner pass over the windows, one doubling per scalar
 // bit.  2^20 points, c = 16: 0.20 -> 0.10 ms.  MLHIP_HOST_THREADS=1 keeps everything on the calling thread.
-template <class F>
-struct HostTailJob {
-  const mlhip_msm_plan* p;
-  const XYZZ<F>* o;
-  XYZZ<F>* V;
+// (host_parallel copies its input blob: {nb, lgL, nsel} then the W x nsel partial sums as the device left them)
+struct HostTailHeader {
+  int nb, lgL, nsel, pad;
 };
 template <class F>
-void host_tail_window(void* ctx, int w) {
-  const HostTailJob<F>& job = *static_cast<const HostTailJob<F>*>(ctx);
-  const mlhip_msm_plan* p = job.p;
-  const XYZZ<F>* o = job.o + (size_t)w * p->nsel;
+void host_tail_window(const void* in, int w, void* out) {
+  const HostTailHeader& h = *static_cast<const HostTailHeader*>(in);
+  const XYZZ<F>* o = reinterpret_cast<const XYZZ<F>*>(static_cast<const unsigned char*>(in) + sizeof(HostTailHeader)) + (size_t)w * h.nsel;
   XYZZ<F> acc, d;
   xyzz_set_inf<F>(acc);
-  for (int k = p->nb - 1; k >= 0; k--) {
+  for (int k = h.nb - 1; k >= 0; k--) {
     xyzz_dbl<F>(d, acc);
     acc = d;
     xyzz_add<F>(acc, o[4 + k]);
   }
-  for (int k = 0; k < p->lgL; k++) {
+  for (int k = 0; k < h.lgL; k++) {
     xyzz_dbl<F>(d, acc);
     acc = d;
   }
-  for (int h = 0; h < 4; h++) xyzz_add<F>(acc, o[h]);
-  job.V[w] = acc;
+  for (int q = 0; q < 4; q++) xyzz_add<F>(acc, o[q]);
+  memcpy(out, &acc, sizeof(acc));
 }
 template <class F>
 void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
   const WinLayout wl = msm_win_layout(F::Curve::FR_BITS, p->c);
+  const size_t sums = (size_t)p->W * p->nsel * sizeof(XYZZ<F>);
+  std::vector<unsigned char> blob(sizeof(HostTailHeader) + sums);
+  const HostTailHeader h{p->nb, p->lgL, p->nsel, 0};
+  memcpy(blob.data(), &h, sizeof(h));
+  memcpy(blob.data() + sizeof(h), p->h_out, sums);
   std::vector<XYZZ<F>> V(p->W);
-  HostTailJob<F> job{p, reinterpret_cast<const XYZZ<F>*>(p->h_out), V.data()};
-  mlhip_rt::host_parallel(p->W, host_tail_window<F>, &job);
+  mlhip_rt::host_parallel(p->W, host_tail_window<F>, blob.data(), blob.size(), V.data(), sizeof(XYZZ<F>));
   xyzz_set_inf<F>(total);
   for (int w = p->W - 1; w >= 0; w--) {
     xyzz_add<F>(total, V[w]);
@@ -192,16 +193,40 @@ int launch_sort(mlhip_msm_plan* p, const void* d_scalars, int mont, size_t n, hi
   const size_t nbuckets = (size_t)p->W * p->M;
   if (p->sort_low > 0) {
     // two-level LDS counting sort (no per-key global atomics)
-    const int tile = sort_tile_for(n);
-    const unsigned blocks = (unsigned)((n + tile - 1) / tile);
+    int tile = sort_tile_for(n);
     const uint32_t NB = p->sort_nb;
+    // entries staged in LDS and written bin by bin (k_coarse_scatter_staged) when a block's tile * W entries fit beside
+    // the three bin tables -- the tile shrinks to make them fit; MLHIP_SCATTER_STAGED=0: one store per entry (round 1)
+    const char* staged_env = getenv("MLHIP_SCATTER_STAGED");  // read per launch so that a test can switch paths
+    const bool staged_on = !(staged_env && staged_env[0] == '0');
+    constexpr size_t kLdsMax = 160 * 1024 - 256;
+    auto staged_lds = [&](int t) { return (3 * (size_t)NB + (size_t)t * p->W) * 4; };
+    bool staged = false;
+    if (staged_on) {
+      int t = tile;
+      while (t > 1024 && staged_lds(t) > kLdsMax) t /= 2;
+      if (staged_lds(t) <= kLdsMax) {
+        tile = t;
+        staged = true;
+      }
+    }
+    const unsigned blocks = (unsigned)((n + tile - 1) / tile);
     k_coarse_hist<C><<<dim3(blocks), dim3(256), NB * 4, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low, NB,
                                                             p->d_coarse_count, p->d_blockhist, tile);
     if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
     launch_scan(p->d_coarse_count, p->d_coarse_off, p->d_tilesums, NB, st);
-    k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low,
-                                                               p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
-                                                               p->d_digits, p->d_blockhist, tile);
+    if (staged) {
+      int group = 1;  // lanes per bin in the write-out: the mean run length, rounded down to a power of two
+      while (group < 64 && (size_t)group * 2 * NB <= (size_t)tile * p->W) group *= 2;
+      HIPCHK(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+      k_coarse_scatter_staged<C><<<dim3(blocks), dim3(1024), staged_lds(tile), st>>>(
+          (const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low, p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
+          p->d_digits, p->d_blockhist, tile, group);
+    } else {
+      k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low,
+                                                                 p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
+                                                                 p->d_digits, p->d_blockhist, tile);
+    }
     // bins more than 8x the mean (and at least 32768 entries) are sorted by many workgroups
     const uint32_t big_bin = (uint32_t)std::min<size_t>(std::max<size_t>(32768, 8 * ((size_t)p->W * n / NB)), 0x7fffffffu);
     k_fine_sort<<<dim3(NB), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->c, p->sort_low,

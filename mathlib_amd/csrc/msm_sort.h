@@ -88,6 +88,7 @@ static __global__ void __launch_bounds__(1024) k_scan_add(uint32_t* __restrict__
 static inline void launch_scan(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, size_t total, hipStream_t st) {
   const size_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;
   k_scan_tile<<<dim3((unsigned)n_tiles), dim3(1024), 0, st>>>(in, out, tile_sums, total);
+  if (n_tiles <= 1) return;  // one tile is the whole scan (the coarse bins of the two-level sort: 2048 counts)
   k_scan_sums<<<dim3(1), dim3(1024), 0, st>>>(tile_sums, n_tiles);
   k_scan_add<<<dim3((unsigned)n_tiles), dim3(1024), 0, st>>>(out, tile_sums, total);
 }
@@ -189,6 +190,85 @@ __global__ void __launch_bounds__(256) k_coarse_scatter(const uint32_t* __restri
         tmp[pos] = ((bkt & low_mask) << (idx_bits + 1)) | (neg << idx_bits) | (uint32_t)i;
       }
     }
+  }
+}
+
+// The same placement with the block's entries STAGED in LDS and written out bin by bin (round 3).  k_coarse_scatter stores
+// every entry with its own 4-byte store to a random coarse bin: 64 different lines per wave instruction, 355 MB of
+// memory-side writes for 64 MB of entries (profiles/r02_pmc_traffic.json), and the kernel takes four times as long as
+// k_coarse_hist, which does the same digit and LDS-atomic work without the stores.  Here a block of 1024 threads ranks its
+// tile * W entries into an LDS image ordered by bin (local offsets = an exclusive scan of the block's histogram), then
+// groups of G = tile * W / NB lanes copy one bin's run each to its reserved slice: every store instruction writes whole
+// runs of 32 - 64 contiguous bytes.  LDS: 3 NB + tile * W words (c = 16: 88 KB at tile 1024, 152 KB at 2048), one block per CU.
+template <class C>
+__global__ void __launch_bounds__(1024) k_coarse_scatter_staged(const uint32_t* __restrict__ scalars, size_t n, int mont, int c,
+                                                                int W, int low, int idx_bits, uint32_t NB,
+                                                                const uint32_t* __restrict__ coarse_off,
+                                                                uint32_t* __restrict__ coarse_cursor, uint32_t* __restrict__ tmp,
+                                                                const uint16_t* __restrict__ blockhist, int tile, int group) {
+  extern __shared__ uint32_t lds_u32[];
+  uint32_t* cnt = lds_u32;            // this block's count per bin, then the running rank
+  uint32_t* loc = lds_u32 + NB;       // start of the bin's run in the staged image
+  uint32_t* base = lds_u32 + 2 * NB;  // global position of this block's slice of the bin
+  uint32_t* stage = lds_u32 + 3 * NB;
+  __shared__ uint32_t wave_sum[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t cb_shift = (uint32_t)(c - 1 - low);
+  const WinLayout wl = msm_win_layout(C::FR_BITS, c);
+  // exclusive scan of the block's histogram: thread t owns bins [t per, (t + 1) per)
+  const uint32_t per = (NB + 1023u) / 1024u;
+  uint32_t mine = 0;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t b = tid * per + k;
+    if (b < NB) mine += blockhist[(size_t)blockIdx.x * NB + b];
+  }
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+    if (lane >= (uint32_t)d) incl += up;
+  }
+  if (lane == 63) wave_sum[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < wave; w++) before += wave_sum[w];
+  uint32_t run = before + incl - mine;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t b = tid * per + k;
+    if (b < NB) {
+      const uint32_t h = blockhist[(size_t)blockIdx.x * NB + b];
+      loc[b] = run;
+      run += h;
+      base[b] = h ? coarse_off[b] + atomicAdd(&coarse_cursor[b], h) : 0u;
+      cnt[b] = 0;
+    }
+  }
+  __syncthreads();
+  // rank into the staged image
+  const uint32_t low_mask = (1u << low) - 1u;
+  for (int k = 0; k < tile / 1024; k++) {
+    const size_t i = (size_t)blockIdx.x * tile + (size_t)k * 1024 + tid;
+    if (i < n) {
+      uint32_t s[8];
+      fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+      uint32_t carry = 0, neg = 0;
+      for (int w = 0; w < W; w++) {
+        const uint32_t mag = msm_window_digit(s, msm_win_off(wl.base, wl.rem, w), msm_win_bits(wl.base, wl.rem, w), carry, neg);
+        if (mag) {
+          const uint32_t bkt = mag - 1;
+          const uint32_t bin = ((uint32_t)w << cb_shift) + (bkt >> low);
+          const uint32_t r = atomicAdd(&cnt[bin], 1u);
+          stage[loc[bin] + r] = ((bkt & low_mask) << (idx_bits + 1)) | (neg << idx_bits) | (uint32_t)i;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // write out: `group` adjacent lanes per bin (a power of two <= 64)
+  const uint32_t g = tid / (uint32_t)group, r0 = tid % (uint32_t)group, ngroups = 1024u / (uint32_t)group;
+  for (uint32_t b = g; b < NB; b += ngroups) {
+    const uint32_t h = cnt[b], l0 = loc[b], b0 = base[b];
+    for (uint32_t k = r0; k < h; k += (uint32_t)group) tmp[b0 + k] = stage[l0 + k];
   }
 }
 

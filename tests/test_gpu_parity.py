@@ -478,7 +478,8 @@ def test_g2_wire_codec_vs_oracle(lib, mlhip, curve):
 @pytest.mark.parametrize("curve", CURVES)
 @pytest.mark.parametrize("switch", ["MLHIP_LEGACY_SORT", "MLHIP_ACC32", "MLHIP_REDUCE_ONE_LANE", "MLHIP_REDUCE32", "MLHIP_NO_QUAD_ACC",
                                     "MLHIP_NO_PLAN_CACHE", "MLHIP_ACC_BLOCK=256", "MLHIP_RED_BLOCK=64", "MLHIP_CHUNK_LOG2=3",
-                                    "MLHIP_STREAM_SEGMENTS=2", "MLHIP_STREAM_SEGMENTS=5", "MLHIP_REDUCE32+MLHIP_STREAM_SEGMENTS=3"])
+                                    "MLHIP_STREAM_SEGMENTS=2", "MLHIP_STREAM_SEGMENTS=5", "MLHIP_REDUCE32+MLHIP_STREAM_SEGMENTS=3",
+                                    "MLHIP_SCATTER_STAGED=0", "MLHIP_HOST_THREADS=1"])
 def test_msm_alternate_paths(lib, mlhip, curve, switch, monkeypatch):
     g = load_golden(curve)
     cid = g["curve_id"]
