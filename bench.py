@@ -64,8 +64,9 @@ CONFIGS = {
             workload="BLS12-381 batch of 65 536 optimal-ate pairings + FExp per GPU (BASELINE configs[2]); inputs resident in HBM"),
     4: dict(curve=_lib.CURVE_BLS12_381, curve_name="BLS12-381", log_n=24, groups=(G1, G2), scaling="strong",
             workload="BLS12-381 2^24-point G1 + G2 MSM (shared scalars) sharded over the ranks, Pippenger c=16 (BASELINE configs[3]); inputs resident in HBM"),
-    5: dict(curve=_lib.CURVE_BLS12_377, curve_name="BLS12-377", log_n=22, groups=(G1,), scaling="strong",
-            workload="BLS12-377 2^22-point G1 MSM sharded over the ranks, Pippenger c=16 (BASELINE configs[4]); inputs resident in HBM"),
+    5: dict(curve=_lib.CURVE_BLS12_377, curve_name="BLS12-377", log_n=22, groups=(G1,), scaling="strong", window_c=0,
+            workload="BLS12-377 2^22-point G1 MSM sharded over the ranks (BASELINE configs[4], which names no window: the library "
+                     "picks it per shard -- c=17, 15 windows, from 2^22 pairs on, c=16 below); inputs resident in HBM"),
 }
 # algorithmic bytes per scalar-mul: affine point + 32-byte scalar
 MSM_BYTES = {(0, G1): 96, (1, G1): 128, (2, G1): 128, (0, G2): 160, (1, G2): 224, (2, G2): 224}
@@ -259,13 +260,26 @@ def main() -> None:
             "note": "864 algorithmic bytes per pairing; the kernel is integer-issue bound (DESIGN.md section 4)",
         }
         roofline["traffic"], roofline["traffic_note"] = _pmc(3, "k_pairing_lp28<Bls381, 2")
+        # the honest bound is integer issue: 64-bit integer VALU instructions per pairing (v_mad_i64_i32 and the 64-bit
+        # column shifts; the kernel is straight-line, the count does not depend on the data) from the PMC pass
+        # profiles/r03_pmc_issue.txt: SQ_INSTS_VALU_INT64 5.9215e9 wave-instructions per 65 536 pairings, 69 % of its VALU
+        # instructions -- against the same measured issue peak as the MSM kernels
+        int64_per_pairing = 5.9215e9 * 64 / 65536
+        roofline["int_alu"] = {
+            "form": "carry-free 28-bit limbs on lane pairs (fp2_lanes28.h)",
+            "int64_valu_per_pairing": int64_per_pairing, "share_of_valu_instructions": 5.9215 / 8.5321,
+            "frac_of_measured_peak": (int64_per_pairing * npair / (kernel_ms * 1e-3)) / INT_MAC_PEAK if kernel_ms else 0.0,
+            "source": "profiles/r03_pmc_issue.txt (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 ...)",
+        }
         unit, metric = "pairings/s", "pairings/sec (BLS12-381, Miller loop + final exponentiation, batch of 65 536 per GPU, inputs resident in HBM)"
         res_check = None
     else:
         # =========================================================== MSM configs
         # one plan + stream per (slot, group); slot 1 only for the two-deep runs
         nslots = 2
-        plans = {(s, g): _lib.MsmPlan(CURVE, g, n, WINDOW_C) for s in range(nslots) for g in groups}
+        window_c = cfg.get("window_c", WINDOW_C)  # 0: the library's pick for this shard's size
+        plans = {(s, g): _lib.MsmPlan(CURVE, g, n, window_c) for s in range(nslots) for g in groups}
+        window_c, n_windows = plans[(0, groups[0])].window()
         streams = {(s, g): torch.cuda.Stream(device=dev) for s in range(nslots) for g in groups}
         for pl in plans.values():
             pl.set_profiling(True)
@@ -375,15 +389,15 @@ def main() -> None:
         if reduced:
             roofline["traffic"], roofline["traffic_note"] = None, "reduced size: the PMC passes are of the full config"
         if dom == G1 and not acc32 and fpb == 48:
-            # the path is integer-ALU bound, not HBM bound: W = 16 mixed additions per scalar, each 8 x 196 + 2 x 105
+            # the path is integer-ALU bound, not HBM bound: W mixed additions per scalar (16 at c = 16), each 8 x 196 + 2 x 105
             # product and 9 x 210 reduction v_mad_i64_i32 + 9 x 14 v_mul_lo_u32 in the carry-free form => fraction of
             # the measured v_mad issue peak (profiles/r01_ubench_int.txt); the kernel is power limited (~1.9 GHz)
             v_mad = 8 * 196 + 2 * 105 + 9 * 210 + 9 * 14
             roofline["int_alu"] = {
                 "form": "carry-free 28-bit limbs (fp28.h)",
-                "fp_mul_per_s": (n * 16 * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
-                "v_mad_per_mixed_add": v_mad,
-                "v_mad_frac_of_measured_peak": ((n * 16 * v_mad) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
+                "fp_mul_per_s": (n * n_windows * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
+                "v_mad_per_mixed_add": v_mad, "mixed_adds_per_scalar": n_windows,
+                "v_mad_frac_of_measured_peak": ((n * n_windows * v_mad) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
             }
         if dom == G2 and CURVE == 1 and not acc32:
             # G2 on lane pairs, carry-free form (ec28_lp.h: xyzz28_lp_madd): per lane 8 dual products (2 x 196 product +
@@ -391,9 +405,9 @@ def main() -> None:
             v_mad = 2 * (8 * (2 * 196 + 210 + 14) + 2 * (196 + 210 + 14))
             roofline["int_alu"] = {
                 "form": "carry-free 28-bit limbs on lane pairs (ec28_lp.h)",
-                "fp2_mul_per_s": (n * 16 * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
-                "v_mad_per_mixed_add": v_mad,
-                "v_mad_frac_of_measured_peak": ((n * 16 * v_mad) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
+                "fp2_mul_per_s": (n * n_windows * 10) / (acc_ms * 1e-3) if acc_ms > 0 else 0.0,
+                "v_mad_per_mixed_add": v_mad, "mixed_adds_per_scalar": n_windows,
+                "v_mad_frac_of_measured_peak": ((n * n_windows * v_mad) / (acc_ms * 1e-3)) / INT_MAC_PEAK if acc_ms > 0 else 0.0,
             }
         if len(groups) > 1:
             g1_ms = phase_avg.get((G1, "accumulate"), 0.0)
@@ -453,7 +467,7 @@ def main() -> None:
                 hs = scalars.cpu().numpy().tobytes()
                 out_h = ctypes.create_string_buffer(g1b)
                 handle = ctypes.c_void_p()
-                _lib.check(lib.mlhip_bases_create(CURVE, G1, hp, n, WINDOW_C, ctypes.byref(handle)))
+                _lib.check(lib.mlhip_bases_create(CURVE, G1, hp, n, cfg.get("window_c", WINDOW_C), ctypes.byref(handle)))
                 tb, tc = [], []
                 for _ in range(6):
                     t1 = time.perf_counter()
@@ -463,7 +477,7 @@ def main() -> None:
                 _lib.check(lib.mlhip_bases_destroy(handle))
                 for _ in range(6):
                     t1 = time.perf_counter()
-                    _lib.check(lib.mlhip_msm_g1(CURVE, hp, hs, 0, n, WINDOW_C, out_h))
+                    _lib.check(lib.mlhip_msm_g1(CURVE, hp, hs, 0, n, cfg.get("window_c", WINDOW_C), out_h))
                     tc.append((time.perf_counter() - t1) * 1e3)
                 same_c = world > 1 or out_h.raw == res[G1]
                 extra["pcie_inclusive"] = {
@@ -536,7 +550,7 @@ def main() -> None:
                 if ns == n:
                     ok = ok and ref == res_check[g]
                 else:  # the GPU on the same sample
-                    pl = _lib.MsmPlan(CURVE, g, ns, WINDOW_C)
+                    pl = _lib.MsmPlan(CURVE, g, ns, cfg.get("window_c", WINDOW_C))
                     ok = ok and ref == pl.run(points[g].data_ptr(), scalars.data_ptr(), ns, False, stream)
                     pl.close()
             cpu_baseline = {
@@ -581,7 +595,7 @@ def main() -> None:
                 "curve": cfg["curve_name"],
                 "pairs_total": n_total,
                 "pairs_per_gpu": n,
-                "window_c": WINDOW_C,
+                "window_c": window_c if args.config != 3 else None,
                 "parallelism": par,
                 "protocol": "SURVEY 8d (a): inputs resident in HBM; kernels + D2H of the window sums + host tail" + ("" if args.config == 3 else "; %d step(s) in flight" % (2 if args.pipelined else 1))
                 + ("; G1 and G2 share their scalars: one sort per tile for both (mlhip_msm_launch_shared)" if args.config == 4 and not args.separate_sorts else ""),

@@ -157,8 +157,9 @@ int mlhip_msm_launch_shared(mlhip_msm_plan* g1_plan, mlhip_msm_plan* g2_plan, co
  * [0] digits [1] sort (histogram scan + scatter) [2] bucket accumulation [3] bucket reduction
  * [4] device total [5] host tail [6] the number of tiles the accumulation ran in (device-resident inputs from 2^22 / 2^23
  * points on are accumulated tile by tile; [1] and [2] are then sums over the tiles' launches).  A streamed host-buffer
- * MSM (mlhip_msm_g1 and friends on a pooled plan) records no phase events: [0..5] are then 0.  Returns the number of
- * values written (at most `cap`). */
+ * MSM (mlhip_msm_g1 and friends on a pooled plan) records no phase events: [0..5] are then 0.  [7] and [8] are not times:
+ * the window width c the plan runs with (the library's pick when it was created with window_c = 0) and its number of
+ * windows W.  Returns the number of values written (at most `cap`, at most 9). */
 int mlhip_msm_plan_set_profiling(mlhip_msm_plan* plan, int on);
 int mlhip_msm_plan_timings(mlhip_msm_plan* plan, float* ms, int cap);
 

@@ -203,10 +203,16 @@ class MsmPlan:
         check(load().mlhip_msm_plan_set_profiling(self._h, 1 if on else 0))
 
     def timings(self):
-        buf = (c_float * 7)()
-        k = load().mlhip_msm_plan_timings(self._h, buf, 7)
+        buf = (c_float * 9)()
+        k = load().mlhip_msm_plan_timings(self._h, buf, 9)
         names = ["digits", "sort", "accumulate", "reduce", "device_total", "host_tail", "tiles"]
-        return {names[i]: float(buf[i]) for i in range(k)}
+        return {names[i]: float(buf[i]) for i in range(min(k, 7))}
+
+    def window(self):
+        """(c, W): the window width the plan runs with (the library's pick for window_c = 0) and its number of windows"""
+        buf = (c_float * 9)()
+        load().mlhip_msm_plan_timings(self._h, buf, 9)
+        return int(buf[7]), int(buf[8])
 
     def run(self, d_points: int, d_scalars: int, n: int, scalars_mont: bool, stream: int = 0, want_xyzz: bool = False):
         out = ctypes.create_string_buffer(self.point_bytes)

@@ -977,9 +977,11 @@ int mlhip_msm_plan_set_profiling(mlhip_msm_plan* p, int on) {
 
 int mlhip_msm_plan_timings(mlhip_msm_plan* p, float* ms, int cap) {
   if (!p || !ms) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
-  int k = cap < 7 ? cap : 7;
+  int k = cap < 9 ? cap : 9;
   for (int i = 0; i < k && i < 6; i++) ms[i] = p->ms[i];
-  if (k == 7) ms[6] = p->tiles_timed > 0 ? (float)p->tiles_timed : 1.0f;
+  if (k >= 7) ms[6] = p->tiles_timed > 0 ? (float)p->tiles_timed : 1.0f;
+  if (k >= 8) ms[7] = (float)p->c;
+  if (k >= 9) ms[8] = (float)p->W;
   return k;
 }
 
