@@ -145,6 +145,18 @@ MLHIP_HD void mul_by_line(Fp12<C, E2>& f, const Line<C, E2>& l, const EP& px, co
   else
     fp12_mul_by_034<C>(f, a, b, c);
 }
+// f = f^2 * line in one out-of-line call (tower.h: fp12_sqr_mul_by_014 / _034): f crosses memory once, not twice
+template <class C, class E2, class EP>
+MLHIP_HD void sqr_mul_by_line(Fp12<C, E2>& f, const Line<C, E2>& l, const EP& px, const EP& py) {
+  E2 a, b, c = l.r2;
+  fp2_mul_fp<C>(a, l.r0, py);
+  fp2_mul_fp<C>(b, l.r1, px);
+  fp2_norm<C>(c);
+  if (C::MTWIST)
+    fp12_sqr_mul_by_014<C>(f, c, b, a);
+  else
+    fp12_sqr_mul_by_034<C>(f, a, b, c);
+}
 
 // f = prod_k f_{loop,Q_k}(P_k) over n_pairs pairs (shared squaring chain: the reference's Pairing2,
 // driver/gurvy/bls12381/bls12-381.go:457-464).  Pairs flagged not live (one side at infinity) are skipped, as
@@ -165,13 +177,19 @@ MLHIP_HD void miller_loop_core(Fp12<C, E2>& f, const EP* px, const EP* py, const
   Line<C, E2> l;
   bool first = true;
   for (int i = C::ATE_BITS - 2; i >= 0; i--) {
-    if (!first) fp12_sqr<C>(f, f);
+    // the iteration's squaring rides with the first live pair's line (the doubling step needs T only, so the line is
+    // ready before f is touched): f^2 * line is one call -- same operations, same results
+    bool square = !first;
     first = false;
     bool bit = (i >= 64) ? ((C::ATE_HI >> (i - 64)) & 1) : ((C::ATE_LO >> i) & 1);
     for (int k = 0; k < n_pairs && k < MAXP; k++) {
       if (!live[k]) continue;
       g2_double_step<C>(T[k], l);
-      mul_by_line<C>(f, l, px[k], py[k]);
+      if (square)
+        sqr_mul_by_line<C>(f, l, px[k], py[k]);
+      else
+        mul_by_line<C>(f, l, px[k], py[k]);
+      square = false;
       if (bit) {
         g2_add_step<C>(T[k], qx[k], qy[k], l);
         mul_by_line<C>(f, l, px[k], py[k]);

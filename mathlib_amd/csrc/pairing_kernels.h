@@ -148,6 +148,94 @@ __device__ __forceinline__ void lp28_load_gt(Fp12<C, Fp2L28<C>>& f, const Fp12<C
   for (int k = 0; k < 6; k++) fp28_from_fp<C>(c[k].v, o[2 * k]);
 }
 
+// ---- the Miller loop of ONE pair with the point T and P's coordinates in LDS (round 3) ------------------------------------
+// In miller_loop_core T, P and the line are locals of the kernel that must survive two out-of-line Fp12 calls per
+// iteration: the register allocator spills them (about 110 words per lane stored and reloaded through scratch every
+// iteration, beside the 84-word f the callees exchange), and with two waves per SIMD those round trips are exposed
+// (profiles/r03_pmc_waits.txt: the lane-pair Miller loop runs at 80 % of the rate its instruction mix allows, the
+// inlined quad loop at 97 %).  Here T (three Fp2 = 42 words per lane) and px, py (28 words) live in a 71-word LDS slot per
+// lane (odd stride: conflict-free; 18 KB per wave, eight waves fill the CU), are read where a step starts and written
+// where it ends -- nothing but f's address is live across the calls.  Same formulas, same order: bit-identical results.
+template <class C>
+struct MillerLds {
+  static constexpr int STRIDE = 5 * C::N28 + 1;
+  int32_t* slot;
+  __device__ __forceinline__ void put(int k, const Fp28<C>& v) const {
+#pragma unroll
+    for (int i = 0; i < C::N28; i++) slot[k * C::N28 + i] = v.l[i];
+  }
+  __device__ __forceinline__ void get(Fp28<C>& v, int k) const {
+#pragma unroll
+    for (int i = 0; i < C::N28; i++) v.l[i] = slot[k * C::N28 + i];
+  }
+};
+template <class C>
+__device__ __forceinline__ void miller_loop_lp28_lds(Fp12<C, Fp2L28<C>>& f, const Fp28<C>& px, const Fp28<C>& py,
+                                                     const Fp2L28<C>& qx, const Fp2L28<C>& qy, bool live,
+                                                     const MillerLds<C>& lds) {
+  static_assert(!C::IS_BN && C::MTWIST, "BLS12 loop with the M-twist line (BLS12-381)");
+  typedef Fp2L28<C> E2;
+  fp12_one<C>(f);
+  if (!live) return;
+  {
+    E2 one;
+    fp2_one<C>(one);
+    lds.put(0, qx.v);
+    lds.put(1, qy.v);
+    lds.put(2, one.v);
+    lds.put(3, px);
+    lds.put(4, py);
+  }
+  bool first = true;
+#pragma unroll 1
+  for (int i = C::ATE_BITS - 2; i >= 0; i--) {
+    const bool bit = (i >= 64) ? ((C::ATE_HI >> (i - 64)) & 1) : ((C::ATE_LO >> i) & 1);
+    {
+      // the doubling step needs T only: the line is ready before f is touched, and f^2 * line is one call
+      // (fp12_sqr_mul_by_014: f crosses memory once per iteration)
+      G2Proj<C, E2> T;
+      Line<C, E2> l;
+      lds.get(T.x.v, 0);
+      lds.get(T.y.v, 1);
+      lds.get(T.z.v, 2);
+      g2_double_step<C>(T, l);
+      lds.put(0, T.x.v);
+      lds.put(1, T.y.v);
+      lds.put(2, T.z.v);
+      Fp28<C> x, y;
+      lds.get(x, 3);
+      lds.get(y, 4);
+      // (inlining the two bodies into the loop instead -- f a local the compiler spills piecewise -- is slower: 19.1 ms
+      // against 17.8 for the fused batch, profiles/r03_pairing_ab.txt)
+      E2 a, b, c = l.r2;
+      fp2_mul_fp<C>(a, l.r0, y);
+      fp2_mul_fp<C>(b, l.r1, x);
+      fp2_norm<C>(c);
+      if (first)
+        fp12_mul_by_014<C>(f, c, b, a);
+      else
+        fp12_sqr_mul_by_014<C>(f, c, b, a);
+      first = false;
+    }
+    if (bit) {
+      G2Proj<C, E2> T;
+      Line<C, E2> l;
+      lds.get(T.x.v, 0);
+      lds.get(T.y.v, 1);
+      lds.get(T.z.v, 2);
+      g2_add_step<C>(T, qx, qy, l);
+      lds.put(0, T.x.v);
+      lds.put(1, T.y.v);
+      lds.put(2, T.z.v);
+      Fp28<C> x, y;
+      lds.get(x, 3);
+      lds.get(y, 4);
+      mul_by_line<C>(f, l, x, y);
+    }
+  }
+  if (C::X_NEG) fp12_conj<C>(f, f);
+}
+
 template <class C, int WHAT, int MAXP>
 __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp28(const Affine<FpField<C>>* __restrict__ g1,
                                                                   const Affine<Fp2Field<C>>* __restrict__ g2, int ppp,
@@ -178,7 +266,13 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp28(const Affine<F
       fp28_from_fp<C>(qx[k].v, qxc);
       fp28_from_fp<C>(qy[k].v, qyc);
     }
-    miller_loop_core<C, MAXP, E2, Fp28<C>>(f, px, py, qx, qy, live, ppp);
+    if constexpr (MAXP == 1 && !C::IS_BN) {
+      __shared__ int32_t t_slots[64 * MillerLds<C>::STRIDE];
+      const MillerLds<C> lds{t_slots + threadIdx.x * MillerLds<C>::STRIDE};
+      miller_loop_lp28_lds<C>(f, px[0], py[0], qx[0], qy[0], live[0], lds);
+    } else {
+      miller_loop_core<C, MAXP, E2, Fp28<C>>(f, px, py, qx, qy, live, ppp);
+    }
   }
   if (WHAT == 0) {
     lp28_store_gt<C>(out, i, f);
@@ -301,9 +395,9 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
       // a full chip is bound by instruction issue, where the pairs' fewer instructions win (65 536: 18.6 vs 23.4 ms).
       // MLHIP_PAIRING_QUAD=1 / 0 forces / forbids the quads (products of up to 4 pairs; longer ones stay on lane pairs).
       const char* qe = getenv("MLHIP_PAIRING_QUAD");
-      // (the Miller loop alone is ahead on quads at any size since its doubling step runs on both pairs: 65 536 loops 9.1
-      // ms against 9.3)
-      const bool quads = qe ? qe[0] == '1' : (n <= ((size_t)1 << 14) || (what == 0 && ppp == 1));
+      // (round 2 also ran the Miller loop of single pairs on quads at every size -- 65 536 loops 9.0 ms against the pairs'
+      // 9.2; since round 3 the pairs' loop keeps T and P in LDS and squares and multiplies by the line in one call: 8.6 ms)
+      const bool quads = qe ? qe[0] == '1' : n <= ((size_t)1 << 14);
       if (quads && (what != 0 || ppp <= 4)) {
         const unsigned qblocks = (unsigned)((4 * n + 63) / 64);
         if (what == 0 && ppp == 1)

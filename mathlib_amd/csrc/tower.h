@@ -441,8 +441,9 @@ MLHIP_HD_NOINLINE void fp12_mul(Fp12<C, E2>& r, const Fp12<C, E2>& a, const Fp12
   fp6_reduce<C>(r.c0);  // 3, 2, 2
 }
 
+// (inlined bodies + the shared out-of-line copies; fp12_sqr_mul_by_014 below chains the two bodies in one function)
 template <class C, class E2>
-MLHIP_HD_NOINLINE void fp12_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
+MLHIP_HD void fp12_sqr_i(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   // complex squaring: c0 = (a0+a1)(a0+v a1) - ab - v ab ; c1 = 2ab
   Fp6<C, E2> ab, s0, s1, t;
   fp6_mul_i<C>(ab, a.c0, a.c1);
@@ -458,6 +459,10 @@ MLHIP_HD_NOINLINE void fp12_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   fp6_reduce<C>(r.c0);  // 4, 3, 3
   fp6_dbl<C>(r.c1, ab);
   fp6_reduce<C>(r.c1);  // 2
+}
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
+  fp12_sqr_i<C>(r, a);
 }
 
 template <class C, class E2>
@@ -574,7 +579,7 @@ MLHIP_HD_NOINLINE void fp12_cyclo_sqr(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
 
 // f *= (c0 + c1 v + c4 v w)   -- line of an M-twist curve (BLS12-381)
 template <class C, class E2>
-MLHIP_HD_NOINLINE void fp12_mul_by_014(Fp12<C, E2>& f, const E2& c0, const E2& c1, const E2& c4) {
+MLHIP_HD void fp12_mul_by_014_i(Fp12<C, E2>& f, const E2& c0, const E2& c1, const E2& c4) {
   Fp6<C, E2> t0, t1, s, x;
   E2 d;
   fp6_mul_by_01<C>(t0, f.c0, c0, c1);  // raw: 3, 3, 2
@@ -591,10 +596,24 @@ MLHIP_HD_NOINLINE void fp12_mul_by_014(Fp12<C, E2>& f, const E2& c0, const E2& c
   fp6_add<C>(f.c0, t0, t1);
   fp6_reduce<C>(f.c0);  // 5, 5, 3
 }
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_mul_by_014(Fp12<C, E2>& f, const E2& c0, const E2& c1, const E2& c4) {
+  fp12_mul_by_014_i<C>(f, c0, c1, c4);
+}
+// f = f^2 (c0 + c1 v + c4 v w): one Miller-loop iteration's squaring and line product in ONE out-of-line function -- f
+// crosses memory once per iteration instead of twice (the square stays in registers / the function's own frame between
+// the two bodies).  Same operations in the same order as fp12_sqr followed by fp12_mul_by_014.
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_sqr_mul_by_014(Fp12<C, E2>& f, const E2& c0, const E2& c1, const E2& c4) {
+  Fp12<C, E2> g;
+  fp12_sqr_i<C>(g, f);
+  fp12_mul_by_014_i<C>(g, c0, c1, c4);
+  f = g;
+}
 
 // f *= (c0 + c3 w + c4 v w)   -- line of a D-twist curve (BN254, BLS12-377)
 template <class C, class E2>
-MLHIP_HD_NOINLINE void fp12_mul_by_034(Fp12<C, E2>& f, const E2& c0, const E2& c3, const E2& c4) {
+MLHIP_HD void fp12_mul_by_034_i(Fp12<C, E2>& f, const E2& c0, const E2& c3, const E2& c4) {
   Fp6<C, E2> t0, t1, s, x;
   E2 d;
   fp6_mul_by_0<C>(t0, f.c0, c0);       // 1, 1, 1
@@ -610,6 +629,18 @@ MLHIP_HD_NOINLINE void fp12_mul_by_034(Fp12<C, E2>& f, const E2& c0, const E2& c
   fp6_mul_v<C>(t1, t1);
   fp6_add<C>(f.c0, t0, t1);
   fp6_reduce<C>(f.c0);  // 5, 4, 4
+}
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_mul_by_034(Fp12<C, E2>& f, const E2& c0, const E2& c3, const E2& c4) {
+  fp12_mul_by_034_i<C>(f, c0, c3, c4);
+}
+// f = f^2 (c0 + c3 w + c4 v w): see fp12_sqr_mul_by_014
+template <class C, class E2>
+MLHIP_HD_NOINLINE void fp12_sqr_mul_by_034(Fp12<C, E2>& f, const E2& c0, const E2& c3, const E2& c4) {
+  Fp12<C, E2> g;
+  fp12_sqr_i<C>(g, f);
+  fp12_mul_by_034_i<C>(g, c0, c3, c4);
+  f = g;
 }
 
 }  // namespace mlhip
