@@ -820,6 +820,12 @@ int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
     for (hipEvent_t e : tile)
       if (e) (void)hipEventDestroy(e);
   if (p->aux) (void)hipStreamDestroy(p->aux);
+  for (int i = 0; i < 2; i++) {
+    if (p->sort_helper[i]) (void)mlhip_msm_plan_destroy(p->sort_helper[i]);
+    if (p->ev_sorted[i]) (void)hipEventDestroy(p->ev_sorted[i]);
+    if (p->ev_lists_free[i]) (void)hipEventDestroy(p->ev_lists_free[i]);
+  }
+  if (p->sort_stream) (void)hipStreamDestroy(p->sort_stream);
   delete p;
   return 0;
 }
@@ -844,6 +850,7 @@ int mlhip_msm_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scal
     // the plan reusable, as tu_plan_stream does.
     (void)hipStreamSynchronize(st);
     if (p->aux) (void)hipStreamSynchronize(p->aux);
+    if (p->sort_stream) (void)hipStreamSynchronize(p->sort_stream);
     (void)hipGetLastError();
     p->pending = false;
     p->upload_src = nullptr;
@@ -869,6 +876,7 @@ static int tu_plan_shared(mlhip_msm_plan* g1, mlhip_msm_plan* g2, void* d1, void
   if (rc) {  // as mlhip_msm_launch: drain what was queued (copies from the caller's buffers too) and leave both plans reusable
     (void)hipStreamSynchronize(st);
     if (g1->aux) (void)hipStreamSynchronize(g1->aux);
+    if (g1->sort_stream) (void)hipStreamSynchronize(g1->sort_stream);
     if (g2->aux) (void)hipStreamSynchronize(g2->aux);
     (void)hipGetLastError();
     g1->pending = g2->pending = false;

@@ -70,6 +70,11 @@ struct mlhip_msm_plan {
   bool pending = false;
   size_t pending_n = 0;
   float ms[6] = {0, 0, 0, 0, 0, 0};
+  // tiles of device-resident inputs: the entry lists of tile s + 1 are sorted on `sort_stream`, in one of two helper
+  // records that hold sort buffers only, while tile s accumulates (msm_plan.h: sort_ahead_*)
+  mlhip_msm_plan* sort_helper[2] = {nullptr, nullptr};
+  hipStream_t sort_stream = nullptr;
+  hipEvent_t ev_sorted[2] = {nullptr, nullptr}, ev_lists_free[2] = {nullptr, nullptr};
 };
 
 

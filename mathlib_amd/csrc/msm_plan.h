@@ -5,11 +5,9 @@
 
 namespace mlhip {
 
-template <class F>
-int plan_alloc(mlhip_msm_plan* p) {
+// the buffers launch_sort works in (a plan's own, or those of a sort-ahead helper record: sort_ahead_prepare)
+inline int plan_alloc_sort(mlhip_msm_plan* p) {
   const size_t nbuckets = (size_t)p->W * p->M;
-  p->pt_size = sizeof(Affine<F>);
-  p->xyzz_size = sizeof(XYZZ<F>);
   HIPCHK(hipMalloc(&p->d_digits, (size_t)p->W * p->max_n * 4));
   HIPCHK(hipMalloc(&p->d_sorted, (size_t)p->W * p->max_n * 4));
   {
@@ -45,14 +43,6 @@ int plan_alloc(mlhip_msm_plan* p) {
     HIPCHK(hipMalloc(&p->d_blockhist, blocks * p->sort_nb * sizeof(uint16_t)));
   }
   HIPCHK(hipMalloc(&p->d_offsets, nbuckets * 4));
-  HIPCHK(hipMalloc(&p->d_biglist, nbuckets * 4));
-  {
-    // long buckets: at most W n / BIG_BUCKET_MIN of them, and W n / BIG_SLICE + one more slice per bucket
-    const size_t entries = (size_t)p->W * p->max_n;
-    const size_t nbig_max = std::min(nbuckets, entries / BIG_BUCKET_MIN + 1);
-    HIPCHK(hipMalloc(&p->d_bigprefix, (nbig_max + 2) * 4));
-    HIPCHK(hipMalloc(&p->d_bigpart, (entries / BIG_SLICE + nbig_max + 2) * p->xyzz_size));
-  }
   HIPCHK(hipMalloc(&p->d_order, nbuckets * 4));
   {
     const size_t nblk = (nbuckets + 255) / 256;
@@ -60,6 +50,26 @@ int plan_alloc(mlhip_msm_plan* p) {
     HIPCHK(hipMalloc(&p->d_hist, hist_n * 4));
     const size_t tiles = (std::max(nbuckets, hist_n) + SCAN_TILE - 1) / SCAN_TILE;
     HIPCHK(hipMalloc(&p->d_tilesums, (tiles + 1) * 4));
+  }
+  return 0;
+}
+
+template <class F>
+int plan_alloc(mlhip_msm_plan* p) {
+  const size_t nbuckets = (size_t)p->W * p->M;
+  p->pt_size = sizeof(Affine<F>);
+  p->xyzz_size = sizeof(XYZZ<F>);
+  {
+    int rc_sort = plan_alloc_sort(p);
+    if (rc_sort) return rc_sort;
+  }
+  HIPCHK(hipMalloc(&p->d_biglist, nbuckets * 4));
+  {
+    // long buckets: at most W n / BIG_BUCKET_MIN of them, and W n / BIG_SLICE + one more slice per bucket
+    const size_t entries = (size_t)p->W * p->max_n;
+    const size_t nbig_max = std::min(nbuckets, entries / BIG_BUCKET_MIN + 1);
+    HIPCHK(hipMalloc(&p->d_bigprefix, (nbig_max + 2) * 4));
+    HIPCHK(hipMalloc(&p->d_bigpart, (entries / BIG_SLICE + nbig_max + 2) * p->xyzz_size));
   }
   if (const char* e = getenv("MLHIP_RED_BLOCK")) {
     const int v = atoi(e);
@@ -642,6 +652,77 @@ int stream_end(mlhip_msm_plan* p, const StreamCtx& cx, hipStream_t st) {
   return 0;
 }
 
+// ---- sorting ahead (round 3) ----------------------------------------------------------------------------------------------
+// A tiled device-resident MSM ran sort(0), accumulate(0), sort(1), accumulate(1) ... on one stream: the sort kernels are
+// bound by LDS atomics and leave the multipliers idle, the accumulation is the opposite.  The entry lists of tile s + 1
+// are now sorted on a second stream, in one of two helper records that own sort buffers only, while tile s accumulates
+// on the caller's stream from the other record's lists (the `sorter` argument of stream_tile, as the G2 plan of a
+// shared-scalar MSM reads the G1 plan's lists).  Events: ev_sorted[b] (sort stream -> accumulation), ev_lists_free[b]
+// (accumulation -> the next sort into record b; it also orders consecutive MSMs on the plan).  MLHIP_SORT_AHEAD=0: off.
+template <class C>
+int sort_ahead_prepare(mlhip_msm_plan* p, size_t seg, bool& on) {
+  on = false;
+  const char* e = getenv("MLHIP_SORT_AHEAD");
+  if (e && e[0] == '0') return 0;
+  if (p->sort_low <= 0) return 0;  // the legacy sort shares the digits buffer with the accumulation path: not split
+  for (int b = 0; b < 2; b++) {
+    mlhip_msm_plan* h = p->sort_helper[b];
+    if (h && h->max_n < seg) {  // longer tiles than last time: rebuild
+      (void)hipStreamSynchronize(p->sort_stream);
+      mlhip_msm_plan_destroy(h);
+      h = p->sort_helper[b] = nullptr;
+    }
+    if (!h) {
+      h = new mlhip_msm_plan();
+      h->curve = p->curve;
+      h->group = p->group;
+      h->device = p->device;
+      h->c = p->c;
+      h->W = p->W;
+      h->M = p->M;
+      h->L = p->L;
+      h->lgL = p->lgL;
+      h->T = p->T;
+      h->nb = p->nb;
+      h->nsel = p->nsel;
+      h->max_n = seg;
+      p->sort_helper[b] = h;  // owned by p from here on (mlhip_msm_plan_destroy frees what was allocated)
+      int rc = plan_alloc_sort(h);
+      if (rc) return rc;
+      if (h->sort_low <= 0) return 0;  // cannot happen for a shorter max_n; stay on the in-line path if it does
+    }
+    if (!p->ev_sorted[b]) HIPCHK(hipEventCreateWithFlags(&p->ev_sorted[b], hipEventDisableTiming));
+    if (!p->ev_lists_free[b]) HIPCHK(hipEventCreateWithFlags(&p->ev_lists_free[b], hipEventDisableTiming));
+  }
+  if (!p->sort_stream) {
+    // the highest priority: a sort is a chain of a dozen short kernels that must find wave slots between the
+    // accumulation's one-wave workgroups
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char* pe = getenv("MLHIP_SORT_AHEAD_PRIO");
+    if (pe && pe[0] == '0')
+      HIPCHK(hipStreamCreateWithFlags(&p->sort_stream, hipStreamNonBlocking));
+    else
+      HIPCHK(hipStreamCreateWithPriority(&p->sort_stream, hipStreamNonBlocking, hi));
+  }
+  on = true;
+  return 0;
+}
+// queue the sort of tile s into helper record s & 1 (after whatever still reads that record's lists)
+template <class C>
+int sort_ahead_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s) {
+  const int b = s & 1;
+  mlhip_msm_plan* h = p->sort_helper[b];
+  const size_t off = (size_t)s * cx.seg;
+  const size_t len = std::min(cx.seg, cx.n - off);
+  HIPCHK(hipStreamWaitEvent(p->sort_stream, p->ev_lists_free[b], 0));  // never recorded yet: no wait
+  HIPCHK(hipMemsetAsync(h->d_zero, 0, h->zero_bytes, p->sort_stream));
+  int rc = launch_sort<C>(h, (const char*)cx.d_scalars + off * 32, cx.mont, len, p->sort_stream, false);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(p->ev_sorted[b], p->sort_stream));
+  return 0;
+}
+
 template <class C, class F>
 int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* h_points, const void* h_scalars, int mont,
                 size_t n, int K, hipStream_t st) {
@@ -655,9 +736,21 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
   cx.K = K;
   int rc = stream_begin<C, F>(p, cx, st, 2);
   if (rc) return rc;
-  for (int s = 0; (size_t)s * cx.seg < n; s++) {
-    rc = stream_tile<C, F>(p, cx, s, st, nullptr);
+  bool ahead = false;
+  if (!h_scalars && !h_points) {  // device-resident tiles: nothing to upload, the sorts can run ahead
+    rc = sort_ahead_prepare<C>(p, cx.seg, ahead);
     if (rc) return rc;
+  }
+  if (ahead) HIPCHK(hipStreamWaitEvent(p->sort_stream, p->ev_fork, 0));  // the scalars are ready where `st` stood at launch
+  for (int s = 0; (size_t)s * cx.seg < n; s++) {
+    if (ahead) {
+      rc = sort_ahead_tile<C>(p, cx, s);
+      if (rc) return rc;
+      HIPCHK(hipStreamWaitEvent(st, p->ev_sorted[s & 1], 0));
+    }
+    rc = stream_tile<C, F>(p, cx, s, st, ahead ? p->sort_helper[s & 1] : nullptr);
+    if (rc) return rc;
+    if (ahead) HIPCHK(hipEventRecord(p->ev_lists_free[s & 1], st));
   }
   return stream_end<C, F>(p, cx, st);
 }
@@ -706,8 +799,21 @@ int plan_stream_shared(mlhip_msm_plan* p1, mlhip_msm_plan* p2, void* d_points_g1
   if (rc) return rc;
   rc = stream_begin<C, F2>(p2, c2, st, 1);
   if (rc) return rc;
+  bool ahead = false;
+  if (!h_scalars && !h_points_g1 && !h_points_g2 && K >= 2) {
+    rc = sort_ahead_prepare<C>(p1, c1.seg, ahead);
+    if (rc) return rc;
+  }
+  if (ahead) HIPCHK(hipStreamWaitEvent(p1->sort_stream, p1->ev_fork, 0));
   for (int s = 0; (size_t)s * c1.seg < n; s++) {
-    rc = stream_tile<C, F1>(p1, c1, s, st, nullptr);
+    const mlhip_msm_plan* lists = p1;  // whose entry lists the G2 tile reads
+    if (ahead) {
+      rc = sort_ahead_tile<C>(p1, c1, s);
+      if (rc) return rc;
+      HIPCHK(hipStreamWaitEvent(st, p1->ev_sorted[s & 1], 0));
+      lists = p1->sort_helper[s & 1];
+    }
+    rc = stream_tile<C, F1>(p1, c1, s, st, ahead ? lists : nullptr);
     if (rc) return rc;
     if ((size_t)(s + 1) * c1.seg >= n) {
       // G1 is complete: its reduction and its copy to the host go ahead of G2's last accumulation, so that the host
@@ -715,8 +821,9 @@ int plan_stream_shared(mlhip_msm_plan* p1, mlhip_msm_plan* p2, void* d_points_g1
       rc = stream_end<C, F1>(p1, c1, st);
       if (rc) return rc;
     }
-    rc = stream_tile<C, F2>(p2, c2, s, st, p1);
+    rc = stream_tile<C, F2>(p2, c2, s, st, lists);
     if (rc) return rc;
+    if (ahead) HIPCHK(hipEventRecord(p1->ev_lists_free[s & 1], st));
   }
   return stream_end<C, F2>(p2, c2, st);
 }

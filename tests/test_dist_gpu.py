@@ -109,3 +109,27 @@ def test_all_gather_over_rccl_one_rank():
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
     assert ret.get(0, False)
+
+
+@pytest.mark.parametrize("config,log_n", [(2, 14), (4, 15), (3, 12)])
+def test_bench_plain_gpus_n_command(config, log_n):
+    """The driver's command shape for N > 1, `python bench.py --gpus 2 ...` with no torchrun in front: bench.py starts its
+    two ranks itself (a child torch.distributed.run), rank 0's JSON line comes back on stdout and the exit code is the
+    child's.  On a one-GPU box the ranks share device 0 and exchange over gloo (MLHIP_BENCH_REHEARSAL=1: the line says
+    so and is not a measurement); the N > 1 code path -- shard bounds, one all-gather of the partial sums, the local
+    EC additions, the max over ranks -- is the one eight GPUs run."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, MLHIP_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", str(config), "--log-n", str(log_n),
+                        "--kernels-only", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    assert "REHEARSAL" in d["data"] and d["config"]["baseline_config"] == config
+    assert d["config"]["pairs_total"] == 2 * d["config"]["pairs_per_gpu"] == 2 << log_n if d["scaling"] == "weak" else d["config"]["pairs_total"] == 2 * d["config"]["pairs_per_gpu"] == 1 << log_n
