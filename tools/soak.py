@@ -56,6 +56,10 @@ while time.time() - t0 < budget:
         # half of the calls stream the pairs in a random number of segments (the library reads the switch per call)
         segs = rnd.choice([0, 0, 0, 2, 3, 5, 16])
         os.environ["MLHIP_STREAM_SEGMENTS"] = str(segs)
+        # round-3 paths, read per launch: the coarse scatter staged in LDS (default) or one store per entry; the next
+        # tile's sort on a second stream (default) or in line
+        os.environ["MLHIP_SCATTER_STAGED"] = rnd.choice(["1", "1", "0"])
+        os.environ["MLHIP_SORT_AHEAD"] = rnd.choice(["1", "1", "0"])
         mode = rnd.random()
         if mode < 0.2:  # device-resident inputs through a plan: one pass or tiles (MLHIP_TILE_LOG2 is read per launch)
             import torch
