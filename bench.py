@@ -267,7 +267,7 @@ def main() -> None:
         int64_per_pairing = 5.9215e9 * 64 / 65536
         roofline["int_alu"] = {
             "form": "carry-free 28-bit limbs on lane pairs (fp2_lanes28.h)",
-            "int64_valu_per_pairing": int64_per_pairing, "share_of_valu_instructions": 5.9215 / 8.5321,
+            "int64_valu_per_pairing": int64_per_pairing, "share_of_valu_instructions": 5.9215 / 8.5283,
             "frac_of_measured_peak": (int64_per_pairing * npair / (kernel_ms * 1e-3)) / INT_MAC_PEAK if kernel_ms else 0.0,
             "source": "profiles/r03_pmc_issue.txt (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 ...)",
         }
