@@ -45,18 +45,19 @@ import (
 // WindowC is the Pippenger window (0 = chosen from n; BASELINE config 2 uses 16).
 var WindowC = 0
 
-// The GPU is a throughput device.  Measured on one MI355X through this ABI (tools/perf_latency.py): a
-// MultiScalarMul of 2 points takes 0.35 ms, of 2^20 points 4.3 ms; but ONE Miller loop takes 2.4 ms and ONE final
-// exponentiation 5.4 ms, because a single pairing occupies a single quad of lanes (65 536 pairings take 18.7 ms).
-// gnark on the CPU does a single pairing in about a millisecond.  Hence:
+// The GPU is a throughput device.  Measured on one MI355X through this ABI (tools/perf_latency.py,
+// profiles/r03_perf_latency.txt): a MultiScalarMul of 2 points takes 0.3-0.4 ms, of 2^20 points 4.2 ms; but ONE Miller
+// loop takes 2.5 ms and ONE final exponentiation 5.2 ms, because a single pairing occupies a single quad of lanes
+// (65 536 pairings take 17.7 ms).  gnark on the CPU does a single pairing in about a millisecond.  Hence:
 //
 // MinDeviceMSM: MultiScalarMul with fewer pairs stays on the embedded gurvy driver.  A host-slice MSM costs the device
-// a flat 0.35-0.7 ms up to 2^10 pairs and 0.7-0.95 ms from 2^12 to 2^16 (profiles/r02_perf_small_msm.txt).  The CPU
-// side cannot be measured with gnark here (no Go toolchain); the stated stand-in, one thread of the C restatement
-// (oracle/cref, tools/perf_min_device_msm.py, profiles/r02_min_device_msm.txt), needs 0.74 ms for 2 pairs, 4.3 ms for 32
-// and 51 ms for 2^10 -- the device wins from the first pair against it.  gnark with ADX assembly and GLV is roughly an
-// order of magnitude faster than that plain-C port (about 60 us per scalar multiplication), which puts the break-even
-// near 8-32 pairs; 32 keeps the tiny proofs-of-knowledge MSMs (perf_test.go:198-224, 3-7 pairs) on the CPU.
+// a flat 0.39-0.51 ms up to 2^10 pairs and 0.55-0.9 ms from 2^12 to 2^16 (profiles/r03_min_device_msm.txt,
+// profiles/r03_perf_small_msm.txt).  The CPU side cannot be measured with gnark (no Go toolchain here or on the GPU
+// box: profiles/r03_go_probe.txt); the stated stand-in, the C restatement (oracle/cref, tools/perf_min_device_msm.py)
+// timed on the GPU box's own cores, needs on ONE thread 0.40 ms for 2 pairs, 2.6 ms for 32 and 29 ms for 2^10, on 8
+// threads 0.52 / 0.78 / 4.4 ms, and never gets under 2 ms on all 64 -- the device is level with it from the second
+// pair.  gnark with ADX assembly is several times faster than that plain-C port, which puts the break-even near 8-32
+// pairs; 32 keeps the tiny proofs-of-knowledge MSMs (perf_test.go:198-224, 3-7 pairs) on the CPU.
 var MinDeviceMSM = 32
 
 // MinDevicePairingBatch: PairingBatch with fewer pairs stays on the embedded gurvy driver.  Any batch up to 16 384
