@@ -161,6 +161,70 @@ MLHIP_HD void fp28_mul2(Fp28<C>& r, const Fp28<C>& a, const Fp28<C>& b, const Fp
 #endif
 }
 
+// Fp2 product (u^2 = -1) with both components on ONE lane: Karatsuba over the components, the three limb products
+// interleaved column by column so that the unreduced products never exist as values:
+//     c0 = a0 b0 - a1 b1        c1 = (a0 + a1)(b0 + b1) - a0 b0 - a1 b1
+// 3 limb products + 2 reductions instead of the 4 + 2 of two dual products.  All four inputs must be normalized (weight 1):
+// a column of c1 is then below (4 + 1 + 1 + 1) N28 2^56 < 2^63.  The integers that are reduced are exactly those of
+// fp28_mul2(a0, b0, -a1, b1) and fp28_mul2(a0, b1, a1, b0), so the results are bit-identical to the lane-pair product.
+template <class C>
+MLHIP_HD void fp28_k2mul_portable(Fp28<C>& r0, Fp28<C>& r1, const Fp28<C>& a0, const Fp28<C>& a1, const Fp28<C>& b0,
+                                  const Fp28<C>& b1) {
+  constexpr int L = C::N28;
+  int32_t s[L], t[L], m0[L], m1[L], t0[L], t1[L];
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    s[i] = a0.l[i] + a1.l[i];
+    t[i] = b0.l[i] + b1.l[i];
+  }
+  int64_t c0 = 0, c1 = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * L - 1; k++) {
+    const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
+    int64_t p0 = 0, p1 = 0;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      p0 += (int64_t)a0.l[i] * b0.l[k - i];
+      p1 += (int64_t)a1.l[i] * b1.l[k - i];
+      c1 += (int64_t)s[i] * t[k - i];
+    }
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      if (k < L && i == k) continue;
+      c0 += (int64_t)m0[i] * C::P28[k - i];
+      c1 += (int64_t)m1[i] * C::P28[k - i];
+    }
+    c0 += p0 - p1;
+    c1 -= p0 + p1;
+    if (k < L) {
+      m0[k] = (int32_t)(((uint32_t)c0 * C::PINV28) & MASK28);
+      c0 += (int64_t)m0[k] * C::P28[0];
+      m1[k] = (int32_t)(((uint32_t)c1 * C::PINV28) & MASK28);
+      c1 += (int64_t)m1[k] * C::P28[0];
+    } else {
+      t0[k - L] = (int32_t)((uint32_t)c0 & MASK28);
+      t1[k - L] = (int32_t)((uint32_t)c1 & MASK28);
+    }
+    c0 >>= 28;
+    c1 >>= 28;
+  }
+  t0[L - 1] = (int32_t)c0;
+  t1[L - 1] = (int32_t)c1;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    r0.l[i] = t0[i];
+    r1.l[i] = t1[i];
+  }
+}
+template <class C>
+MLHIP_HD void fp28_k2mul(Fp28<C>& r0, Fp28<C>& r1, const Fp28<C>& a0, const Fp28<C>& a1, const Fp28<C>& b0, const Fp28<C>& b1) {
+#ifdef MLHIP_FP28_DEV
+  MLHIP_FP28_DEV(fp28_k2mul_dev, r0, r1, a0, a1, b0, b1);
+#else
+  fp28_k2mul_portable<C>(r0, r1, a0, a1, b0, b1);
+#endif
+}
+
 // ---- conversions to / from the boundary form (canonical, Montgomery R = 2^(32 N)) ---------------------------
 // bits [28 j, 28 j + 28) of a little-endian 32-bit limb string
 template <class C>

@@ -386,6 +386,93 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 }
 
+// ---- the same segment kernel with the pair split by coordinate (ec28_kc.h): lane A owns X and ZZ, lane B owns Y and ZZZ,
+// every Fp2 product is a one-lane Karatsuba product.  State, points and buckets keep their layouts: a lane simply reads
+// both components of its two coordinates (state[2 g] holds the real parts {x, y, zz, zzz}, state[2 g + 1] the imaginary
+// parts) and the x or the y half of a point (56 + 56 contiguous bytes).  Bit-identical state to k_accumulate28_lp_seg.
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_accumulate28_kc_seg(
+    const AffineG2_28<C>* __restrict__ points, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ counts, size_t n_buckets, const uint32_t* __restrict__ order, uint32_t big_threshold,
+    uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count, XYZZ28L<Fp28<C>>* __restrict__ state, int flags,
+    XYZZ<Fp2Field<C>>* __restrict__ buckets) {
+  typedef KcDevice<C> B;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t pair = t >> 1;  // both lanes of a pair share the bucket: every branch below is pair-uniform
+  if (pair >= n_buckets) return;
+  const int hi = (int)(threadIdx.x & 1u);  // 0: lane A (X, ZZ)   1: lane B (Y, ZZZ)
+  const size_t g = order[pair];
+  const uint32_t cnt = counts[g];
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  if (cnt > big_threshold) {
+    if (!hi) {
+      uint32_t pos = atomicAdd(big_count, 1u);
+      big_list[pos] = (uint32_t)g;
+    }
+    return;
+  }
+  const bool to_boundary = last && !(flags & MLHIP_SEG_KEEP28);
+  if (cnt == 0 && !first && !to_boundary) return;
+  Fp2x28<C> u, z;  // A: X, ZZ   B: Y, ZZZ
+  bool inf = true;
+  Fp28<C>* const st = reinterpret_cast<Fp28<C>*>(state + 2 * g);  // {x, y, zz, zzz} real parts, then the imaginary parts
+  if (!first) {
+    u.c0 = st[hi];
+    u.c1 = st[4 + hi];
+    z.c0 = st[2 + hi];
+    z.c1 = st[6 + hi];
+    const bool zf[1] = {fp28_all_zero<C>(z.c0) && fp28_all_zero<C>(z.c1)};
+    inf = B::of_a(zf);  // ZZ = 0 in Fp2
+  }
+  const size_t begin = offsets[g], end = begin + cnt;
+  if (cnt != 0) {
+    uint32_t e = sorted[begin];
+    Fp2x28<C> p, pn;
+    p.c0 = points[e & 0x7fffffffu].c[2 * hi];
+    p.c1 = points[e & 0x7fffffffu].c[2 * hi + 1];
+    for (size_t k = begin; k < end; k++) {
+      uint32_t en = e;
+      pn = p;
+      if (k + 1 < end) {  // prefetch the next index and point under this addition
+        en = sorted[k + 1];
+        pn.c0 = points[en & 0x7fffffffu].c[2 * hi];
+        pn.c1 = points[en & 0x7fffffffu].c[2 * hi + 1];
+      }
+      xyzz28_kc_madd<C, B>(u, z, inf, p, (e >> 31) != 0);
+      e = en;
+      p = pn;
+    }
+  }
+  if (to_boundary) {
+    Fp<C>* const q = reinterpret_cast<Fp<C>*>(buckets + g);  // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+    Fp<C> r0, r1, r2, r3;
+    if (inf) {  // as xyzz_set_inf: X = Y = 1, ZZ = ZZZ = 0
+      fp_one<C>(r0);
+      fp_zero<C>(r1);
+      fp_zero<C>(r2);
+      fp_zero<C>(r3);
+    } else {
+      fp28_to_fp<C>(r0, u.c0);
+      fp28_to_fp<C>(r1, u.c1);
+      fp28_to_fp<C>(r2, z.c0);
+      fp28_to_fp<C>(r3, z.c1);
+    }
+    q[2 * hi] = r0;
+    q[2 * hi + 1] = r1;
+    q[4 + 2 * hi] = r2;
+    q[5 + 2 * hi] = r3;
+  } else {
+    if (inf) {
+#pragma unroll
+      for (int i = 0; i < C::N28; i++) u.c0.l[i] = u.c1.l[i] = z.c0.l[i] = z.c1.l[i] = 0;
+    }
+    st[hi] = u.c0;
+    st[4 + hi] = u.c1;
+    st[2 + hi] = z.c0;
+    st[6 + hi] = z.c1;
+  }
+}
+
 template <class C, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_g2(const uint32_t* __restrict__ big_list,
                                                                  const uint32_t* __restrict__ big_count,

@@ -26,6 +26,7 @@
 
 #include "ec28.h"
 #include "ec28_lp.h"
+#include "ec28_kc.h"
 #include "ec_quad.h"
 #include "ec_quad28.h"
 #include "fp2_lanes.h"

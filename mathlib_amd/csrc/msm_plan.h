@@ -5,6 +5,16 @@
 
 namespace mlhip {
 
+// G2 bucket accumulation (carry-free form): lane pairs split by component with dual products (k_accumulate28_lp_seg, default)
+// or by coordinate with one-lane Karatsuba Fp2 products (k_accumulate28_kc_seg, MLHIP_G2_KC=1: 16 % fewer multiplier
+// instructions per addition, but three 64-bit column combinations per product column and 130 spilled registers instead of
+// 63 -- measured 3-5 % SLOWER; kept as a second implementation for the parity tests).  Read per launch
+// so that a test can switch paths; both leave bit-identical bucket states.
+static inline bool g2_split_by_coordinate() {
+  const char* e = getenv("MLHIP_G2_KC");
+  return e && e[0] == '1';
+}
+
 // the buffers launch_sort works in (a plan's own, or those of a sort-ahead helper record: sort_ahead_prepare)
 inline int plan_alloc_sort(mlhip_msm_plan* p) {
   const size_t nbuckets = (size_t)p->W * p->M;
@@ -423,10 +433,17 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
           HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
           if constexpr (C::N28 == 14) {
             if (p->reduce28) {  // one segment that is first and last, leaving the raw accumulators for k_chunks_lp28
-              k_accumulate28_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-                  (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
-                  big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28,
-                  MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
+              const dim3 grid((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), block(p->acc_block);
+              if (g2_split_by_coordinate())
+                k_accumulate28_kc_seg<C><<<grid, block, 0, st>>>(
+                    (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+                    big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28,
+                    MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
+              else
+                k_accumulate28_lp_seg<C><<<grid, block, 0, st>>>(
+                    (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+                    big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28,
+                    MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
               done28 = true;
             }
           }
@@ -609,9 +626,15 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
     k_accumulate_big_fold<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
                                                                            (const X*)p->d_bigpart, flags, (X*)p->d_buckets);
   } else if constexpr (kG2) {
-    k_accumulate28_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-        (const AffineG2_28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
-        big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
+    const dim3 grid((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), block(p->acc_block);
+    if (g2_split_by_coordinate())
+      k_accumulate28_kc_seg<C><<<grid, block, 0, st>>>(
+          (const AffineG2_28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+          big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
+    else
+      k_accumulate28_lp_seg<C><<<grid, block, 0, st>>>(
+          (const AffineG2_28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+          big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
     constexpr int BB = 128;
     launch_big_slices<F, BB>(p, dpt, st, sv);
     k_accumulate_big_seg_g2<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(

@@ -12,6 +12,7 @@
 #include "../../mathlib_amd/csrc/ec_quad.h"
 #include "../../mathlib_amd/csrc/ec_quad28.h"
 #include "../../mathlib_amd/csrc/ec28_lp.h"
+#include "../../mathlib_amd/csrc/ec28_kc.h"
 #include "../../mathlib_amd/csrc/modinv.h"
 #include "../../mathlib_amd/csrc/fp2_lanes28.h"
 #include "../../mathlib_amd/csrc/pairing_quad.h"
@@ -407,6 +408,62 @@ struct Ops {
       return -2;  // u^2 != -1: this path is not built for the curve
     }
   }
+  // the same accumulation with the pair split by coordinate (ec28_kc.h: lane A owns X and ZZ, lane B Y and ZZZ, one-lane
+  // Karatsuba products); besides the sum it checks that the state is bit-identical to the component split's after every
+  // addition (returns -4 otherwise) and that every stored coordinate has weight 1 (-3)
+  static int madd28_kc_chain(const void* pts, const uint8_t* neg, int n, void* out) {
+    if constexpr (C::BETA == -1) {
+      typedef KcHost<C> B;
+      typedef PairHost<C> BL;
+      const A2* p = (const A2*)pts;
+      typename B::V u, z;
+      XYZZ28L<typename BL::V> ref;
+      bool inf = true, ref_inf = true;
+      for (int i = 0; i < n; i++) {
+        typename B::V q;
+        fp28_from_fp<C>(q.v[0].c0, p[i].x.c0);
+        fp28_from_fp<C>(q.v[0].c1, p[i].x.c1);
+        fp28_from_fp<C>(q.v[1].c0, p[i].y.c0);
+        fp28_from_fp<C>(q.v[1].c1, p[i].y.c1);
+        xyzz28_kc_madd<C, B>(u, z, inf, q, neg[i] != 0);
+        Affine28L<typename BL::V> ql;
+        ql.x.v[0] = q.v[0].c0;
+        ql.x.v[1] = q.v[0].c1;
+        ql.y.v[0] = q.v[1].c0;
+        ql.y.v[1] = q.v[1].c1;
+        xyzz28_lp_madd<C, BL>(ref, ref_inf, ql, neg[i] != 0);
+        if (inf != ref_inf) return -4;
+        if (!inf) {
+          const Fp28<C>* mine[8] = {&u.v[0].c0, &u.v[0].c1, &u.v[1].c0, &u.v[1].c1, &z.v[0].c0, &z.v[0].c1, &z.v[1].c0, &z.v[1].c1};
+          const Fp28<C>* theirs[8] = {&ref.x.v[0], &ref.x.v[1], &ref.y.v[0], &ref.y.v[1], &ref.zz.v[0], &ref.zz.v[1], &ref.zzz.v[0], &ref.zzz.v[1]};
+          for (int k = 0; k < 8; k++) {
+            if (memcmp(mine[k], theirs[k], sizeof(Fp28<C>)) != 0) return -4;
+            for (int j = 0; j < C::N28 - 1; j++)
+              if (mine[k]->l[j] <= -(1 << 28) || mine[k]->l[j] >= (1 << 28)) return -3;  // weight 1 (a negated first point keeps its sign)
+          }
+        }
+      }
+      X2 a;
+      if (inf) {
+        xyzz_set_inf<Fp2Field<C>>(a);
+      } else {
+        fp28_to_fp<C>(a.x.c0, u.v[0].c0);
+        fp28_to_fp<C>(a.x.c1, u.v[0].c1);
+        fp28_to_fp<C>(a.y.c0, u.v[1].c0);
+        fp28_to_fp<C>(a.y.c1, u.v[1].c1);
+        fp28_to_fp<C>(a.zz.c0, z.v[0].c0);
+        fp28_to_fp<C>(a.zz.c1, z.v[0].c1);
+        fp28_to_fp<C>(a.zzz.c0, z.v[1].c0);
+        fp28_to_fp<C>(a.zzz.c1, z.v[1].c1);
+      }
+      A2 r;
+      xyzz_to_affine<Fp2Field<C>>(r, a);
+      memcpy(out, &r, sizeof(A2));
+      return 0;
+    } else {
+      return -2;
+    }
+  }
   static int g2dec(const uint8_t* w, int compressed, int subgroup, void* out) {
     A2 p;
     int st = g2_decode<C>(p, w, compressed != 0, subgroup);
@@ -676,6 +733,7 @@ int hm_quad_chain(int curve, const void* pts, const void* zs, int n, void* out) 
 int hm_quad28_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, quad28_chain(pts, zs, n, out)) }
 int hm_add28_lp_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, add28_lp_chain(pts, zs, n, out)) }
 int hm_madd28_lp_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_lp_chain(pts, neg, n, out)) }
+int hm_madd28_kc_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_kc_chain(pts, neg, n, out)) }
 int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g2dec(w, compressed, subgroup, out)) }
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }
 int hm_lp28_fp12_op(int op, const void* a, const void* b, void* out) { return Lp28::fp12_op(op, a, b, out); }

@@ -459,6 +459,11 @@ def test_madd28_lane_pair_g2_accumulation(hostmath, name):
         out = ctypes.create_string_buffer(4 * n)
         assert L.hm_madd28_lp_chain(cid, pts, neg, len(seq), out) == 0
         assert out.raw == R.g2_to_mont_bytes(cp, want)
+        # ec28_kc.h: the pair split by coordinate, one-lane Karatsuba Fp2 products; also checks (inside) that the
+        # bucket state equals the component split's bit for bit after every addition
+        out = ctypes.create_string_buffer(4 * n)
+        assert L.hm_madd28_kc_chain(cid, pts, neg, len(seq), out) == 0
+        assert out.raw == R.g2_to_mont_bytes(cp, want)
     # the full addition of the carry-free G2 reduction (xyzz28_lp_add): operands with random Z, doubling, cancellation
     for seq in cases:
         pts = b"".join(R.g2_to_mont_bytes(cp, R.g2_neg(cp, q) if s else q) for q, s in seq)

@@ -29,6 +29,72 @@ def emit_chain(out, prods):
         out.append('    asm("%s" : "+v"(acc) : %s : "vcc");' % ("\\n\\t".join(lines), ", ".join(ops)))
 
 
+def emit_chain_from(out, dst, start, prods):
+    """dst = start + sum x*y (start: '0' or a C expression of an int64 VGPR pair); dst is a fresh register pair, so the
+    value in `start` survives."""
+    per = (MAXOPS - 2) // 2
+    assert len(prods) <= per
+    ops, lines = [], []
+    for n, (x, xc, y, yc) in enumerate(prods):
+        if n == 0:
+            c = "0" if start == "0" else "%%%d" % (1 + 2 * len(prods))
+        else:
+            c = "%0"
+        lines.append("v_mad_i64_i32 %%0, vcc, %%%d, %%%d, %s" % (1 + len(ops), 2 + len(ops), c))
+        ops.append('"%s"(%s)' % (xc, x))
+        ops.append('"%s"(%s)' % (yc, y))
+    if start != "0":
+        ops.append('"v"(%s)' % start)
+    out.append('    asm("%s" : "=&v"(%s) : %s : "vcc");' % ("\\n\\t".join(lines), dst, ", ".join(ops)))
+
+
+def gen_k2(L):
+    """Fp2 product (u^2 = -1) on ONE lane, Karatsuba over the components with the three limb products interleaved
+    column by column: c0 = a0 b0 - a1 b1, c1 = (a0 + a1)(b0 + b1) - a0 b0 - a1 b1, two Montgomery reductions.  Per column:
+    P0 = sum a0 b0 (fresh chain), S = P0 + sum a1 b1 (chain that starts from P0), c1 += sum s t + sum m1 p, c0 += sum m0 p
+    (chains that start from the carries), then c1 -= S and c0 += 2 P0 - S in plain 64-bit arithmetic."""
+    out = []
+    out.append("template <class C>")
+    out.append("__device__ __forceinline__ void fp28_k2mul_dev%d(Fp28<C>& r0, Fp28<C>& r1, const Fp28<C>& a0, const Fp28<C>& a1, const Fp28<C>& b0, const Fp28<C>& b1) {" % L)
+    out.append('  static_assert(C::N28 == %d, "limb count");' % L)
+    out.append("  int32_t s[%d], t[%d], m0[%d], m1[%d], t0[%d], t1[%d];" % (L, L, L, L, L, L))
+    out.append("  for (int i = 0; i < %d; i++) { s[i] = a0.l[i] + a1.l[i]; t[i] = b0.l[i] + b1.l[i]; }" % L)
+    out.append("  int64_t c0 = 0, c1 = 0;")
+    for k in range(2 * L - 1):
+        lo, hi = max(0, k - L + 1), min(k, L - 1)
+        out.append("  {  // column %d" % k)
+        out.append("    int64_t p0, sm;")
+        emit_chain_from(out, "p0", "0", [("a0.l[%d]" % i, "v", "b0.l[%d]" % (k - i), "v") for i in range(lo, hi + 1)])
+        emit_chain_from(out, "sm", "p0", [("a1.l[%d]" % i, "v", "b1.l[%d]" % (k - i), "v") for i in range(lo, hi + 1)])
+        red = [i for i in range(lo, hi + 1) if not (k < L and i == k)]
+        # c1 chain: s t products, then the reduction terms
+        tmp = []
+        emit_chain(tmp, [("s[%d]" % i, "v", "t[%d]" % (k - i), "v") for i in range(lo, hi + 1)] + [("m1[%d]" % i, "v", "C::P28[%d]" % (k - i), "s") for i in red])
+        out.extend(x.replace('"+v"(acc)', '"+v"(c1)') for x in tmp)
+        tmp = []
+        emit_chain(tmp, [("m0[%d]" % i, "v", "C::P28[%d]" % (k - i), "s") for i in red])
+        out.extend(x.replace('"+v"(acc)', '"+v"(c0)') for x in tmp)
+        out.append("    c1 -= sm;")
+        out.append("    c0 += 2 * p0 - sm;")
+        if k < L:
+            for c, m in (("c0", "m0"), ("c1", "m1")):
+                out.append("    %s[%d] = (int32_t)(((uint32_t)%s * C::PINV28) & MASK28);" % (m, k, c))
+                tmp = []
+                emit_chain(tmp, [("%s[%d]" % (m, k), "v", "C::P28[0]", "s")])
+                out.extend(x.replace('"+v"(acc)', '"+v"(%s)' % c) for x in tmp)
+        else:
+            out.append("    t0[%d] = (int32_t)((uint32_t)c0 & MASK28);" % (k - L))
+            out.append("    t1[%d] = (int32_t)((uint32_t)c1 & MASK28);" % (k - L))
+        out.append("    c0 = fp28_shift_dev(c0);")
+        out.append("    c1 = fp28_shift_dev(c1);")
+        out.append("  }")
+    out.append("  t0[%d] = (int32_t)c0;" % (L - 1))
+    out.append("  t1[%d] = (int32_t)c1;" % (L - 1))
+    out.append("  for (int i = 0; i < %d; i++) { r0.l[i] = t0[i]; r1.l[i] = t1[i]; }" % L)
+    out.append("}")
+    return "\n".join(out)
+
+
 def gen(L, kind):
     name = {"mul": "fp28_mul_dev%d", "sqr": "fp28_sqr_dev%d", "mul2": "fp28_mul2_dev%d"}[kind] % L
     args = {"mul": "const Fp28<C>& a, const Fp28<C>& b", "sqr": "const Fp28<C>& a",
@@ -96,3 +162,5 @@ for L in (10, 14):
     for kind in ("mul", "sqr", "mul2"):
         print(gen(L, kind))
         print()
+    print(gen_k2(L))
+    print()
