@@ -504,7 +504,8 @@ def test_msm_alternate_paths(lib, mlhip, curve, switch, monkeypatch):
 @pytest.mark.parametrize("curve", CURVES)
 @pytest.mark.parametrize("switches", [("MLHIP_ACC32",), ("MLHIP_ACC32", "MLHIP_STREAM_SEGMENTS=2"), ("MLHIP_LEGACY_SORT",),
                                       ("MLHIP_REDUCE32",), ("MLHIP_REDUCE32", "MLHIP_STREAM_SEGMENTS=3"),
-                                      ("MLHIP_G2_KC",), ("MLHIP_G2_KC", "MLHIP_STREAM_SEGMENTS=3")])
+                                      ("MLHIP_G2_KC",), ("MLHIP_G2_KC", "MLHIP_STREAM_SEGMENTS=3"),
+                                      ("MLHIP_G2_KC", "MLHIP_REDUCE32", "MLHIP_STREAM_SEGMENTS=2")])
 def test_msm_g2_alternate_paths(lib, mlhip, curve, switches, monkeypatch):
     """G2 on the boundary-form accumulation (MLHIP_ACC32=1), alone and together with a forced segment count: with no
     carry-free copy of the points a BLS12-381 G2 plan cannot stream and must fall back to one pass, not fail.
