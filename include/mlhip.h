@@ -159,8 +159,20 @@ int mlhip_msm_launch_shared(mlhip_msm_plan* g1_plan, mlhip_msm_plan* g2_plan, co
  * points on are accumulated tile by tile; [1] and [2] are then sums over the tiles' launches).  A streamed host-buffer
  * MSM (mlhip_msm_g1 and friends on a pooled plan) records no phase events: [0..5] are then 0.  [7] and [8] are not times:
  * the window width c the plan runs with (the library's pick when it was created with window_c = 0) and its number of
- * windows W.  Returns the number of values written (at most `cap`, at most 9). */
+ * windows W; [9] is 1 when the last launch summed its buckets in twisted Edwards coordinates (a subgroup-trusted
+ * BLS12-377 G1 plan or table with the SRS promise, mlhip_msm_plan_assume_srs), else 0.  Returns the number of values written (at most `cap`, at
+ * most 10). */
 int mlhip_msm_plan_set_profiling(mlhip_msm_plan* plan, int on);
+/* The caller declares (on != 0) that this plan's points are a fixed SRS: (1) the point buffer at a given device address
+ * holds the same points at every launch until the promise is taken back (the plan keeps its converted copy of them and
+ * converts nothing on later launches), and (2) every point lies in the prime-order subgroup or is the point at infinity --
+ * what gnark's SetBytes checks on the way in, and what an SRS is by construction.  The reference's MultiScalarMul
+ * (driver/gurvy/bls12-377.go:229-242, gnark MultiExp) accepts any curve points in fresh slices, and so does a plan without
+ * this promise.  With it, a BLS12-377 G1 plan sums its buckets in twisted Edwards coordinates (7 field products per
+ * addition instead of 10; that addition law is complete on the subgroup only): same result bytes, less time.  On the other
+ * curves and for G2 only (1) matters.  mlhip_bases_create makes the same promise for its own table after checking (2) on
+ * the device.  A promise that does not hold gives an undefined RESULT, never a fault. */
+int mlhip_msm_plan_assume_srs(mlhip_msm_plan* plan, int on);
 int mlhip_msm_plan_timings(mlhip_msm_plan* plan, float* ms, int cap);
 
 int mlhip_miller_loop_device(int curve, const void* d_g1, const void* d_g2, size_t pairs_per_product,
@@ -196,6 +208,11 @@ int mlhip_bases_create(int curve, int group, const void* points, size_t n, int w
 int mlhip_bases_create_multi(int curve, int group, const int* devices, int n_devices, const void* points, size_t n,
                              int window_c, mlhip_bases** bases);
 int mlhip_bases_msm(mlhip_bases* bases, const void* scalars, int scalars_mont, size_t n, void* out_affine);
+/* 1 when mlhip_bases_create verified, on the device, that every point of the table is on the curve and in the prime-order
+ * subgroup (or the point at infinity) -- done for BLS12-377 G1 tables, whose MSMs then sum their buckets in twisted
+ * Edwards coordinates (see mlhip_msm_plan_assume_srs); 0 otherwise (other curves, G2, a table with a point outside the
+ * subgroup, MLHIP_EDWARDS=0): such tables take the Weierstrass kernels and give the reference's result for any input. */
+int mlhip_bases_checked_subgroup(mlhip_bases* bases);
 int mlhip_bases_destroy(mlhip_bases* bases);
 
 /* The host-buffer MSM entry points above keep up to 16 plans + input buffers (at most 32 GB) alive between calls (creating and

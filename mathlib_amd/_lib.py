@@ -46,6 +46,7 @@ SYMBOLS = [
     "mlhip_msm_g1g2",
     "mlhip_msm_finish",
     "mlhip_msm_plan_set_profiling",
+    "mlhip_msm_plan_assume_srs",
     "mlhip_msm_plan_timings",
     "mlhip_miller_loop_device",
     "mlhip_final_exp_device",
@@ -56,6 +57,7 @@ SYMBOLS = [
     "mlhip_scalar_mul",
     "mlhip_bases_create",
     "mlhip_bases_msm",
+    "mlhip_bases_checked_subgroup",
     "mlhip_bases_destroy",
     "mlhip_release_cache",
     "mlhip_g1_from_bytes",
@@ -127,6 +129,7 @@ def load() -> ctypes.CDLL:
     lib.mlhip_msm_launch_shared.argtypes = [vp, vp, vp, vp, vp, ci, sz, vp]
     lib.mlhip_msm_finish.argtypes = [vp, vp, vp]
     lib.mlhip_msm_plan_set_profiling.argtypes = [vp, ci]
+    lib.mlhip_msm_plan_assume_srs.argtypes = [vp, ci]
     lib.mlhip_msm_plan_timings.argtypes = [vp, POINTER(c_float), ci]
     lib.mlhip_miller_loop_device.argtypes = [ci, vp, vp, sz, sz, vp, vp]
     lib.mlhip_final_exp_device.argtypes = [ci, vp, sz, vp, vp]
@@ -137,6 +140,7 @@ def load() -> ctypes.CDLL:
     lib.mlhip_bases_create.argtypes = [ci, ci, vp, sz, ci, ctypes.POINTER(c_void_p)]
     lib.mlhip_bases_msm.argtypes = [vp, vp, ci, sz, vp]
     lib.mlhip_bases_destroy.argtypes = [vp]
+    lib.mlhip_bases_checked_subgroup.argtypes = [vp]
     lib.mlhip_g1_from_bytes.argtypes = [ci, vp, sz, ci, ci, vp, vp]
     lib.mlhip_g1_to_bytes.argtypes = [ci, vp, sz, ci, vp]
     lib.mlhip_g1_from_bytes_device.argtypes = [ci, vp, sz, ci, ci, vp, vp, vp]
@@ -202,11 +206,18 @@ class MsmPlan:
     def set_profiling(self, on: bool) -> None:
         check(load().mlhip_msm_plan_set_profiling(self._h, 1 if on else 0))
 
+    def assume_srs(self, on: bool) -> None:
+        """the points are a fixed SRS: immutable at their address and in the prime-order subgroup (include/mlhip.h)"""
+        check(load().mlhip_msm_plan_assume_srs(self._h, 1 if on else 0))
+
     def timings(self):
-        buf = (c_float * 9)()
-        k = load().mlhip_msm_plan_timings(self._h, buf, 9)
+        buf = (c_float * 10)()
+        k = load().mlhip_msm_plan_timings(self._h, buf, 10)
         names = ["digits", "sort", "accumulate", "reduce", "device_total", "host_tail", "tiles"]
-        return {names[i]: float(buf[i]) for i in range(min(k, 7))}
+        t = {names[i]: float(buf[i]) for i in range(min(k, 7))}
+        if k >= 10:
+            t["edwards"] = float(buf[9])
+        return t
 
     def window(self):
         """(c, W): the window width the plan runs with (the library's pick for window_c = 0) and its number of windows"""

@@ -983,13 +983,22 @@ int mlhip_msm_plan_set_profiling(mlhip_msm_plan* p, int on) {
   return 0;
 }
 
+int mlhip_msm_plan_assume_srs(mlhip_msm_plan* p, int on) {
+  if (!p) return mlhip_rt::fail(MLHIP_EINVAL, "null plan");
+  if (p->pending) return mlhip_rt::fail(MLHIP_EINVAL, "mlhip_msm_plan_assume_srs with a launch pending");
+  p->conv_src = nullptr;  // whatever carry-free copy the plan holds was made under the other promise
+  p->points_static = p->trust_subgroup = on != 0;
+  return 0;
+}
+
 int mlhip_msm_plan_timings(mlhip_msm_plan* p, float* ms, int cap) {
   if (!p || !ms) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
-  int k = cap < 9 ? cap : 9;
+  int k = cap < 10 ? cap : 10;
   for (int i = 0; i < k && i < 6; i++) ms[i] = p->ms[i];
   if (k >= 7) ms[6] = p->tiles_timed > 0 ? (float)p->tiles_timed : 1.0f;
   if (k >= 8) ms[7] = (float)p->c;
   if (k >= 9) ms[8] = (float)p->W;
+  if (k >= 10) ms[9] = p->last_ed ? 1.0f : 0.0f;
   return k;
 }
 
@@ -1042,6 +1051,24 @@ static int bases_create_single(int curve, int group, const void* points, size_t 
     return rc;
   }
   b->plan->points_static = true;  // the buffer is ours and never rewritten: convert it on the first MSM only
+  // BLS12-377 G1: a table whose every point is in the prime-order subgroup (what an SRS is; checked here, once, on the
+  // device: on the curve and phi(P) = [-x^2]P) has its buckets summed in twisted Edwards coordinates (ed28.h)
+  if (curve == MLHIP_CURVE_BLS12_377 && group == MLHIP_GROUP_G1) {
+    const char* e = getenv("MLHIP_EDWARDS");
+    if (!(e && e[0] == '0')) {
+      uint32_t* d_bad = nullptr;
+      uint32_t bad = 1;
+      if (hipMalloc(&d_bad, 4) == hipSuccess) {
+        if (hipMemsetAsync(d_bad, 0, 4, b->stream) == hipSuccess &&
+            mlhip_tu_g1_count_outside_subgroup_Bls377(b->d_pts, n, d_bad, b->stream) == 0 &&
+            hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, b->stream) == hipSuccess &&
+            hipStreamSynchronize(b->stream) == hipSuccess) {
+          b->plan->trust_subgroup = bad == 0;
+        }
+        (void)hipFree(d_bad);
+      }
+    }
+  }
   *out = b;
   return 0;
 }
@@ -1096,6 +1123,16 @@ int mlhip_bases_create_multi(int curve, int group, const int* devices, int n_dev
     if (d < 0 || d >= MLHIP_MAX_DEVICES) return mlhip_rt::fail(MLHIP_EINVAL, "device list: index out of range (0 .. 63)");
   if (devs.size() > n) devs.resize(n);
   return bases_create_on(devs, curve, group, points, n, window_c, group == MLHIP_GROUP_G1 ? sz.g1 : sz.g2, out);
+}
+
+int mlhip_bases_checked_subgroup(mlhip_bases* b) {
+  if (!b) return 0;
+  if (!b->shards.empty()) {
+    for (mlhip_bases* s : b->shards)
+      if (!s || !mlhip_bases_checked_subgroup(s)) return 0;
+    return 1;
+  }
+  return b->plan && b->plan->trust_subgroup ? 1 : 0;
 }
 
 int mlhip_bases_msm(mlhip_bases* b, const void* scalars, int scalars_mont, size_t n, void* out_affine) {

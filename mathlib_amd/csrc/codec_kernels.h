@@ -44,6 +44,32 @@ __global__ void __launch_bounds__(256) k_wire_encode(const typename W::Aff* __re
     dst[k] = (uint32_t)w[4 * k] | ((uint32_t)w[4 * k + 1] << 8) | ((uint32_t)w[4 * k + 2] << 16) | ((uint32_t)w[4 * k + 3] << 24);
 }
 
+// every point of an array of affine G1 points (boundary form) is the point at infinity or a curve point of the prime-order
+// subgroup?  `bad` counts the others.  mlhip_bases_create runs it once per table before it lets a curve with a twisted
+// Edwards model (BLS12-377) sum its buckets in those coordinates (ed28.h: the addition law is complete on G1 only).
+template <class C>
+__global__ void __launch_bounds__(64) k_g1_count_outside_subgroup(const Affine<FpField<C>>* __restrict__ pts, size_t n,
+                                                                  uint32_t* __restrict__ bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Affine<FpField<C>> P = pts[i];
+  if (fp_is_zero<C>(P.x) && fp_is_zero<C>(P.y)) return;
+  Fp<C> l, r, b;
+  fp_sqr<C>(l, P.y);
+  fp_sqr<C>(r, P.x);
+  fp_mul<C>(r, r, P.x);
+  fp_from_const<C>(b, C::B_G1);
+  fp_add<C>(r, r, b);
+  if (!fp_eq<C>(l, r) || !g1_in_subgroup<C>(P, 1)) atomicAdd(bad, 1u);
+}
+template <class C>
+int g1_count_outside_subgroup_device(const void* d_pts, size_t n, uint32_t* d_bad, hipStream_t st) {
+  if (n == 0) return 0;
+  k_g1_count_outside_subgroup<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Affine<FpField<C>>*)d_pts, n, d_bad);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 template <class W>
 int wire_codec_device(int encode, const void* d_in, size_t n, int compressed, int subgroup, void* d_out, void* d_status,
                     hipStream_t st) {

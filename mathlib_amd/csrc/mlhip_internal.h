@@ -61,6 +61,11 @@ struct mlhip_msm_plan {
   bool points_static = false;
   const void* conv_src = nullptr;
   size_t conv_n = 0;
+  bool conv_ed = false;  // ... and it holds the twisted Edwards form (ed28.h) rather than the Weierstrass one
+  // the caller vouches that every point handed to this plan lies in the prime-order subgroup (or is the point at infinity):
+  // curves with C::HAS_EDWARDS may then sum their G1 buckets in twisted Edwards coordinates (mlhip_msm_plan_assume_srs)
+  bool trust_subgroup = false;
+  bool last_ed = false;  // the last launch summed its buckets in twisted Edwards coordinates (mlhip_msm_plan_timings [9])
   // streamed host-buffer MSMs (plan_stream): raw carry-free bucket accumulators between segments, one event per segment
   void* d_state28 = nullptr;
   hipEvent_t ev_seg[MLHIP_MAX_SEGMENTS] = {};
@@ -99,6 +104,8 @@ struct mlhip_msm_plan {
                                  void* d_out, void* d_status, hipStream_t st);                                     \
   int mlhip_tu_scalar_mul_##NAME(int group, const void* d_points, size_t point_stride, const void* d_scalars,     \
                                  int mont, size_t n, void* d_out, hipStream_t st);
+// G1 points outside the prime-order subgroup (or off the curve) in an array of affine points: mlhip_bases_create's check
+int mlhip_tu_g1_count_outside_subgroup_Bls377(const void* d_pts, size_t n, uint32_t* d_bad, hipStream_t st);
 MLHIP_DECLARE_CURVE(Bn254)
 MLHIP_DECLARE_CURVE(Bls381)
 MLHIP_DECLARE_CURVE(Bls377)

@@ -6,6 +6,8 @@
 //   k_points_to28 / k_accumulate28      G1: points into the carry-free form (fp28.h), one thread per bucket:
 //                 XYZZ += points[idx] (mixed additions, gathered reads); k_accumulate is the boundary-form variant
 //   k_points_to28_g2 / k_accumulate28_lp / k_accumulate_lp   G2: two lanes per bucket (one Fp2 component each)
+//   k_points_to_ed28 / k_accumulate_ed28_seg   G1 of a subgroup-trusted plan on a curve with a twisted Edwards model
+//                 (BLS12-377): 7-product unified mixed additions (ed28.h, msm_ed.h), buckets handed on as XYZZ28
 //   k_big_prefix / k_big_slices / k_accumulate_big  buckets longer than the threshold (skewed scalars): slices of 4096
 //                 entries, one workgroup per slice (LDS tree), then the slice sums of each bucket
 //   k_chunks_q / k_masked_sums_q   G1 bucket reduction, one point per quad of lanes (ec_quad.h): per 16 consecutive
@@ -25,6 +27,7 @@
 #include <type_traits>
 
 #include "ec28.h"
+#include "ed28.h"
 #include "ec28_lp.h"
 #include "ec28_kc.h"
 #include "ec_quad.h"
@@ -43,6 +46,7 @@ constexpr int CHUNK_L = 8;            // buckets per level-1 reduction thread
 
 #include "msm_sort.h"
 #include "msm_accumulate.h"
+#include "msm_ed.h"
 #include "msm_reduce.h"
 #include "msm_g2.h"
 #include "msm_scalar_mul.h"

@@ -15,6 +15,21 @@ static inline bool g2_split_by_coordinate() {
   return e && e[0] == '1';
 }
 
+// Does this plan sum its buckets in twisted Edwards coordinates (ed28.h)?  G1 of a curve with the model, the SRS promise
+// (mlhip_msm_plan_assume_srs, or a table mlhip_bases_create has checked: every point in the subgroup, and the converted copy
+// made once -- converting per launch costs what the cheaper additions save: 0.95 ms for 2^20 points), the carry-free
+// state the reduction reads, and enough buckets for one lane each (the quad-lane kernel of small MSMs stays on XYZZ).
+// MLHIP_EDWARDS=0: never (the Weierstrass kernels stay the second implementation).
+template <class C, class F>
+inline bool plan_use_edwards(const mlhip_msm_plan* p) {
+  if constexpr (C::HAS_EDWARDS && std::is_same<F, FpField<C>>::value) {
+    const char* e = getenv("MLHIP_EDWARDS");
+    return p->trust_subgroup && p->points_static && p->reduce28 && p->d_points28 && (size_t)p->W * p->M > QUAD_ACC_MAX_BUCKETS &&
+           !(e && e[0] == '0');
+  }
+  return false;
+}
+
 // the buffers launch_sort works in (a plan's own, or those of a sort-ahead helper record: sort_ahead_prepare)
 inline int plan_alloc_sort(mlhip_msm_plan* p) {
   const size_t nbuckets = (size_t)p->W * p->M;
@@ -98,7 +113,9 @@ int plan_alloc(mlhip_msm_plan* p) {
     // MLHIP_ACC32=1 selects the boundary-form kernel (kept as the second implementation the tests compare with).
     const char* acc32 = getenv("MLHIP_ACC32");
     const bool want28 = !(acc32 && acc32[0] == '1');
-    if (want28) HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(Affine28<typename F::Curve>)));
+    // (a curve with a twisted Edwards model keeps room for the Niels triples of a subgroup-trusted launch: 168 B a point)
+    constexpr size_t kPoint28 = F::Curve::HAS_EDWARDS ? sizeof(EdNiels28<typename F::Curve>) : sizeof(Affine28<typename F::Curve>);
+    if (want28) HIPCHK(hipMalloc(&p->d_points28, p->max_n * kPoint28));
     // ... and so does the quad-lane reduction, on the accumulators as the kernel leaves them (MLHIP_REDUCE32=1: the
     // boundary-form reduction kernels, kept as the second implementation)
     const char* red32 = getenv("MLHIP_REDUCE32");
@@ -356,6 +373,10 @@ int resident_tiles(const mlhip_msm_plan* p, size_t n) {
   if (!p->aux || (!kBoundary && !p->d_points28)) return 1;
   int lg = kG2 ? 20 : 21;
   size_t from = (size_t)1 << (kG2 ? 23 : 22);
+  if (plan_use_edwards<C, F>(p)) {  // 168-byte Niels triples: 2^20 of them are what 2^21 Weierstrass points weigh
+    lg = 20;
+    from = (size_t)1 << 21;
+  }
   if (const char* e = getenv("MLHIP_TILE_LOG2")) {
     const int v = atoi(e);
     if (v <= 0) return 1;
@@ -380,6 +401,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
   p->tiles_timed = 0;
   p->pending_n = n;
   p->pending = true;
+  p->last_ed = false;
   if (n != 0) {
     const size_t nbuckets = (size_t)p->W * p->M;
     const bool prof = p->profiling;
@@ -403,7 +425,9 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
       if (rc_sort) return rc_sort;
     }
     // resident bases: the carry-free copy of the first conv_n points of this very buffer is already there
-    const bool conv_cached = p->points_static && p->conv_src == d_points && n <= p->conv_n && !p->upload_src;
+    const bool use_ed = plan_use_edwards<C, F>(p);
+    p->last_ed = use_ed;
+    const bool conv_cached = p->points_static && p->conv_src == d_points && n <= p->conv_n && !p->upload_src && p->conv_ed == use_ed;
     if (p->d_points28 && conv_cached) {
       HIPCHK(hipEventRecord(p->ev_join, st));  // nothing to wait for
     } else if (p->d_points28) {
@@ -417,12 +441,22 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
           k_points_to28_g2<C><<<dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, p->aux>>>(
               (const A*)d_points, n, (AffineG2_28<C>*)p->d_points28);
       } else {
-        k_points_to28<C><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->aux>>>((const A*)d_points, n,
-                                                                                     (Affine28<C>*)p->d_points28);
+        bool converted = false;
+        if constexpr (C::HAS_EDWARDS) {
+          if (use_ed) {
+            k_points_to_ed28<C><<<dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, p->aux>>>(
+                (const A*)d_points, n, (EdNiels28<C>*)p->d_points28);
+            converted = true;
+          }
+        }
+        if (!converted)
+          k_points_to28<C><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->aux>>>((const A*)d_points, n,
+                                                                                       (Affine28<C>*)p->d_points28);
       }
       HIPCHK(hipEventRecord(p->ev_join, p->aux));
       p->conv_src = d_points;
       p->conv_n = n;
+      p->conv_ed = use_ed;
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[2], st));
     constexpr bool kLanePairs = std::is_same<F, Fp2Field<C>>::value;  // G2: two lanes per bucket
@@ -465,7 +499,12 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
         k_accumulate_q28<C><<<dim3((unsigned)((4 * nbuckets + 255) / 256)), dim3(256), 0, st>>>(
             (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, big_threshold, p->d_biglist,
             p->d_bigcount, (XYZZ28<C>*)p->d_state28);
-      else if (p->reduce28)  // one segment that is first and last, leaving the raw accumulators for k_chunks_q28
+      else if (use_ed) {  // (implies reduce28) the same single segment in twisted Edwards coordinates
+        if constexpr (C::HAS_EDWARDS)
+          k_accumulate_ed28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+              (const EdNiels28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
+              p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, MLHIP_SEG_FIRST | MLHIP_SEG_LAST);
+      } else if (p->reduce28)  // one segment that is first and last, leaving the raw accumulators for k_chunks_q28
         k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
             (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
             p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28,
@@ -485,7 +524,15 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
       launch_big_slices<F, BB>(p, (const A*)d_points, st);
       bool folded = false;
       if constexpr (!kLanePairs) {
-        if (p->reduce28) {
+        if constexpr (C::HAS_EDWARDS) {
+          if (use_ed) {
+            k_accumulate_big_seg_ed<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+                p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28,
+                MLHIP_SEG_FIRST | MLHIP_SEG_LAST);
+            folded = true;
+          }
+        }
+        if (!folded && p->reduce28) {
           k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
               p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28,
               MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
@@ -537,6 +584,7 @@ struct StreamCtx {
   size_t n = 0, seg = 0;
   int K = 0;
   bool resident = false, conv_cached = false, prof = false;
+  bool ed = false;  // the buckets are summed in twisted Edwards coordinates (plan_use_edwards)
 };
 
 template <class C, class F>
@@ -555,7 +603,9 @@ int stream_begin(mlhip_msm_plan* p, StreamCtx& cx, hipStream_t st, int min_K) {
   // resident points (h_points == nullptr): only the scalars travel (or nothing: h_scalars == nullptr); their carry-free
   // copy is either the plan's (resident bases) or made tile by tile
   cx.resident = cx.h_points == nullptr;
-  cx.conv_cached = cx.resident && p->points_static && p->conv_src == cx.d_points && cx.n <= p->conv_n;
+  cx.ed = plan_use_edwards<C, F>(p);
+  p->last_ed = cx.ed;
+  cx.conv_cached = cx.resident && p->points_static && p->conv_src == cx.d_points && cx.n <= p->conv_n && p->conv_ed == cx.ed;
   cx.prof = p->profiling && cx.h_scalars == nullptr;  // tiles of device-resident inputs: per-tile phase events
   if (cx.prof)
     for (int s = 0; s < cx.K; s++)
@@ -598,9 +648,19 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
     } else if constexpr (kG2)
       k_points_to28_g2<C><<<dim3((unsigned)((4 * len + 255) / 256)), dim3(256), 0, p->aux>>>(
           dpt, len, (AffineG2_28<C>*)p->d_points28 + off);
-    else
-      k_points_to28<C><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, p->aux>>>(dpt, len,
-                                                                                     (Affine28<C>*)p->d_points28 + off);
+    else {
+      bool converted = false;
+      if constexpr (C::HAS_EDWARDS) {
+        if (cx.ed) {
+          k_points_to_ed28<C><<<dim3((unsigned)(((len + 3) / 4 + 255) / 256)), dim3(256), 0, p->aux>>>(
+              dpt, len, (EdNiels28<C>*)p->d_points28 + off);
+          converted = true;
+        }
+      }
+      if (!converted)
+        k_points_to28<C><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, p->aux>>>(dpt, len,
+                                                                                       (Affine28<C>*)p->d_points28 + off);
+    }
   }
   HIPCHK(hipEventRecord(p->ev_seg[s], p->aux));
   if (prof && first) HIPCHK(hipEventRecord(p->ev[0], st));
@@ -641,14 +701,28 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
         p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28L<Fp28<C>>*)p->d_state28, flags,
         (X*)p->d_buckets);
   } else {
-    k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-        (const Affine28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
-        big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
     constexpr int BB = 256;
-    launch_big_slices<F, BB>(p, dpt, st, sv);
-    k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
-        p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28, flags,
-        (X*)p->d_buckets);
+    bool done_ed = false;
+    if constexpr (C::HAS_EDWARDS) {
+      if (cx.ed) {  // (implies MLHIP_SEG_KEEP28: the last tile leaves XYZZ28 for the reduction)
+        k_accumulate_ed28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+            (const EdNiels28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+            big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags);
+        launch_big_slices<F, BB>(p, dpt, st, sv);
+        k_accumulate_big_seg_ed<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+            p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28, flags);
+        done_ed = true;
+      }
+    }
+    if (!done_ed) {
+      k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+          (const Affine28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+          big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
+      launch_big_slices<F, BB>(p, dpt, st, sv);
+      k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
+          p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28, flags,
+          (X*)p->d_buckets);
+    }
   }
   if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][2], st));
   return 0;
@@ -662,6 +736,7 @@ int stream_end(mlhip_msm_plan* p, const StreamCtx& cx, hipStream_t st) {
   if (cx.resident && !cx.conv_cached && p->points_static && !kBoundary) {  // every tile was converted: the copy is whole again
     p->conv_src = cx.d_points;
     p->conv_n = cx.n;
+    p->conv_ed = cx.ed;
   }
   if (cx.prof) HIPCHK(hipEventRecord(p->ev[3], st));
   {

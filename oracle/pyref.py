@@ -489,6 +489,79 @@ def _jac_add_affine(p, X1, Y1, Z1, x2, y2):
     return (X3, Y3, Z3)
 
 
+# ---- twisted Edwards model of a j = 0 curve with a point of order two (BLS12-377's G1: y^2 = x^3 + 1) -------------------
+# Not in the reference: gnark's MultiExp stays on the Weierstrass curve.  The kernels may run the bucket accumulation of a
+# BLS12-377 G1 MSM in extended twisted Edwards coordinates with a = -1 when the caller vouches for the prime-order
+# subgroup (the addition law is complete there; d is a square, so it is not complete on the whole curve).  These
+# functions are the test-side statement of the birational map:
+#   Weierstrass (x, y), alpha = -1 the root of x^3 + 1, s = 1/sqrt(3):  Montgomery u = s (x + 1), v = s y,
+#   twisted Edwards x_E = u / v, y_E = (u - 1)/(u + 1) on a_E x^2 + y^2 = 1 + d_E x^2 y^2, a_E = (A + 2)/B,
+#   d_E = (A - 2)/B with A = -3 s, B = s; scaling x' = f x_E with f = sqrt(-a_E) gives -x'^2 + y^2 = 1 + d x'^2 y^2,
+#   d = -d_E / a_E.
+_ED_CACHE: dict = {}
+
+
+def edwards_params(cp: CurveParams):
+    """(s, f, d) of the a = -1 twisted Edwards model; the smaller square roots are taken so that the constants are fixed"""
+    if cp.name in _ED_CACHE:
+        return _ED_CACHE[cp.name]
+    p = cp.p
+    assert cp.b == 1 and cp.name == "BLS12-377"
+    r3 = fp_sqrt(3, p)
+    assert r3 is not None
+    r3 = min(r3, p - r3)
+    s = pow(r3, -1, p)
+    A, B = (-3 * s) % p, s
+    a_e = (A + 2) * pow(B, -1, p) % p
+    d_e = (A - 2) * pow(B, -1, p) % p
+    f = fp_sqrt((-a_e) % p, p)
+    assert f is not None
+    f = min(f, p - f)
+    d = (-d_e) * pow(a_e, -1, p) % p
+    _ED_CACHE[cp.name] = (s, f, d)
+    return s, f, d
+
+
+def g1_to_edwards(cp: CurveParams, P):
+    """affine Weierstrass point (None = infinity) of ODD order -> affine (x', y) on -x^2 + y^2 = 1 + d x^2 y^2"""
+    s, f, d = edwards_params(cp)
+    p = cp.p
+    if P is None:
+        return (0, 1)
+    x, y = P
+    u = s * (x + 1) % p
+    xe = f * (x + 1) % p * pow(y, -1, p) % p
+    ye = (u - 1) * pow(u + 1, -1, p) % p
+    assert (-xe * xe + ye * ye - 1 - d * xe * xe % p * ye * ye) % p == 0
+    return (xe, ye)
+
+
+def edwards_to_g1(cp: CurveParams, E):
+    s, f, d = edwards_params(cp)
+    p = cp.p
+    xe, ye = E
+    if xe == 0 and ye == 1:
+        return None
+    u = (1 + ye) * pow(1 - ye, -1, p) % p
+    v = f * u % p * pow(xe, -1, p) % p
+    x = (u * pow(s, -1, p) - 1) % p
+    y = v * pow(s, -1, p) % p
+    assert (y * y - x * x * x - cp.b) % p == 0
+    return (x, y)
+
+
+def edwards_add(cp: CurveParams, E1, E2):
+    """the unified addition law of -x^2 + y^2 = 1 + d x^2 y^2 (affine)"""
+    _, _, d = edwards_params(cp)
+    p = cp.p
+    x1, y1 = E1
+    x2, y2 = E2
+    t = d * x1 % p * x2 % p * y1 % p * y2 % p
+    x3 = (x1 * y2 + y1 * x2) * pow(1 + t, -1, p) % p
+    y3 = (y1 * y2 + x1 * x2) * pow(1 - t, -1, p) % p
+    return (x3, y3)
+
+
 def g1_mul(cp: CurveParams, P, k: int):
     """[k]P with k reduced mod r first (scalars may be negative or >= r: driver/common/big.go:101-113)."""
     p = cp.p

@@ -13,6 +13,7 @@
 #include "../../mathlib_amd/csrc/ec_quad28.h"
 #include "../../mathlib_amd/csrc/ec28_lp.h"
 #include "../../mathlib_amd/csrc/ec28_kc.h"
+#include "../../mathlib_amd/csrc/ed28.h"
 #include "../../mathlib_amd/csrc/modinv.h"
 #include "../../mathlib_amd/csrc/fp2_lanes28.h"
 #include "../../mathlib_amd/csrc/pairing_quad.h"
@@ -464,6 +465,59 @@ struct Ops {
       return -2;
     }
   }
+  // G1 bucket accumulation in extended twisted Edwards coordinates (ed28.h; curves with the model: BLS12-377).  mode 0:
+  // points converted in batches of four (one shared inversion), ed28_madd chain; mode 1: every point converted alone to
+  // extended coordinates and folded with the full addition ed28_add.  The sum returns through ed28_to_xyzz28.
+  static int ed28_chain(const void* pts, const uint8_t* neg, int n, int mode, void* out) {
+    if constexpr (C::HAS_EDWARDS) {
+      const A1* p = (const A1*)pts;
+      EdExt28<C> acc;
+      ed28_set_identity<C>(acc);
+      if (mode == 0) {
+        for (int i0 = 0; i0 < n; i0 += 4) {
+          A1 in[4];
+          Fp<C> xh[4], yh[4];
+          for (int j = 0; j < 4; j++) {
+            if (i0 + j < n) {
+              in[j] = p[i0 + j];
+            } else {
+              fp_zero<C>(in[j].x);
+              fp_zero<C>(in[j].y);
+            }
+          }
+          ed_affine_halves_batch<C, 4>(xh, yh, in);
+          for (int j = 0; j < 4 && i0 + j < n; j++) {
+            EdNiels28<C> q;
+            ed_niels_from_halves<C>(q, xh[j], yh[j]);
+            ed28_madd<C>(acc, q, neg[i0 + j] != 0);
+            const Fp28<C>* co[4] = {&acc.x, &acc.y, &acc.z, &acc.t};
+            for (int k = 0; k < 4; k++)  // every stored coordinate stays normalized
+              for (int l = 0; l < C::N28 - 1; l++)
+                if (co[k]->l[l] < 0 || co[k]->l[l] >= (1 << 28)) return -3;
+          }
+        }
+      } else {
+        for (int i = 0; i < n; i++) {
+          A1 q = p[i];
+          if (neg[i]) fp_neg<C>(q.y, q.y);
+          EdExt28<C> e;
+          ed28_from_affine<C>(e, q);
+          ed28_add<C>(acc, e);
+        }
+      }
+      XYZZ28<C> w;
+      bool inf;
+      ed28_to_xyzz28<C>(w, inf, acc);
+      X1 r;
+      xyzz28_to<C>(r, w, inf);
+      A1 a;
+      xyzz_to_affine<FpField<C>>(a, r);
+      memcpy(out, &a, sizeof(A1));
+      return 0;
+    } else {
+      return -2;
+    }
+  }
   static int g2dec(const uint8_t* w, int compressed, int subgroup, void* out) {
     A2 p;
     int st = g2_decode<C>(p, w, compressed != 0, subgroup);
@@ -733,6 +787,7 @@ int hm_quad_chain(int curve, const void* pts, const void* zs, int n, void* out) 
 int hm_quad28_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, quad28_chain(pts, zs, n, out)) }
 int hm_add28_lp_chain(int curve, const void* pts, const void* zs, int n, void* out) { DISPATCH(curve, add28_lp_chain(pts, zs, n, out)) }
 int hm_madd28_lp_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_lp_chain(pts, neg, n, out)) }
+int hm_ed28_chain(int curve, const void* pts, const uint8_t* neg, int n, int mode, void* out) { DISPATCH(curve, ed28_chain(pts, neg, n, mode, out)) }
 int hm_madd28_kc_chain(int curve, const void* pts, const uint8_t* neg, int n, void* out) { DISPATCH(curve, madd28_kc_chain(pts, neg, n, out)) }
 int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g2dec(w, compressed, subgroup, out)) }
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }

@@ -848,6 +848,119 @@ def test_msm_resident_tiles(lib, mlhip, curve, group, monkeypatch):
             plan.close()
 
 
+def test_msm_edwards_trusted_plan(lib, mlhip, monkeypatch):
+    """mlhip_msm_plan_assume_srs: a BLS12-377 G1 plan whose caller vouches for the prime-order subgroup sums its
+    buckets in twisted Edwards coordinates (ed28.h / msm_ed.h).  Same bytes as the oracle and as the plan without the
+    promise: uniform scalars, skewed ones (long buckets: the Weierstrass slice sums folded into the Edwards state, in the
+    last tile and in earlier ones), points at infinity, one pass and tiles, a prefix of the points, the promise taken
+    back.  Small bucket sets (one bucket per quad of lanes) and the other curves ignore the promise."""
+    import numpy as np
+    import torch
+    from oracle import cref
+
+    g = load_golden("BLS12-377")
+    cid = g["curve_id"]
+    _, g1b, _, _ = mlhip.sizes(cid)
+    n = 6000
+    pts = bytearray(cref.gen_points(cid, 1, 777, 31, n))
+    pts[5 * g1b : 6 * g1b] = bytes(g1b)
+    pts[(n - 1) * g1b : n * g1b] = bytes(g1b)
+    pts = bytes(pts)
+    uniform = _rand_scalars(n, 4077, 252)
+    skew = np.zeros((n, 4), dtype=np.uint64)
+    skew[:, 0] = np.random.default_rng(377).integers(0, 1 << 22, size=n, dtype=np.uint64)
+    skew[::3] = skew[0]
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    dp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
+    for name, sc in (("uniform", uniform), ("skewed", skew)):
+        ds = torch.frombuffer(bytearray(sc.tobytes()), dtype=torch.uint8).to(dev)
+        want = cref.msm(cid, 1, pts, sc, n, False, 0, 8)
+        want_head = cref.msm(cid, 1, pts, sc, 2999, False, 0, 8)
+        for c in (13, 16):
+            plan = mlhip.MsmPlan(cid, 1, n, c)
+            plan.set_profiling(True)
+            plan.assume_srs(True)
+            for tile in ("0", "11", "10", "12"):  # one pass; 3 tiles (ragged); 6 tiles; 2 tiles
+                monkeypatch.setenv("MLHIP_TILE_LOG2", tile)
+                assert plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st) == want, (name, c, tile)
+                assert plan.timings()["edwards"] == 1.0
+                assert plan.run(dp.data_ptr(), ds.data_ptr(), 2999, False, st) == want_head, (name, c, tile)
+            monkeypatch.setenv("MLHIP_EDWARDS", "0")  # the switch: the Weierstrass kernels, whatever the promise
+            assert plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st) == want
+            assert plan.timings()["edwards"] == 0.0
+            monkeypatch.delenv("MLHIP_EDWARDS")
+            plan.assume_srs(False)
+            assert plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st) == want
+            assert plan.timings()["edwards"] == 0.0
+            plan.close()
+    monkeypatch.setenv("MLHIP_TILE_LOG2", "0")
+    ds = torch.frombuffer(bytearray(uniform.tobytes()), dtype=torch.uint8).to(dev)
+    small = mlhip.MsmPlan(cid, 1, n, 8)  # 32 x 128 buckets: one bucket per quad of lanes, on XYZZ
+    small.assume_srs(True)
+    assert small.run(dp.data_ptr(), ds.data_ptr(), n, False, st) == cref.msm(cid, 1, pts, uniform, n, False, 0, 8)
+    assert small.timings()["edwards"] == 0.0
+    small.close()
+    g381 = load_golden("BLS12-381")  # no Edwards model: the promise changes nothing
+    c381 = g381["curve_id"]
+    p381 = cref.gen_points(c381, 1, 778, 32, 2000)
+    s381 = _rand_scalars(2000, 4078, 252)
+    plan = mlhip.MsmPlan(c381, 1, 2000, 13)
+    plan.assume_srs(True)
+    d1 = torch.frombuffer(bytearray(p381), dtype=torch.uint8).to(dev)
+    d2 = torch.frombuffer(bytearray(s381.tobytes()), dtype=torch.uint8).to(dev)
+    assert plan.run(d1.data_ptr(), d2.data_ptr(), 2000, False, st) == cref.msm(c381, 1, p381, s381, 2000, False, 0, 8)
+    assert plan.timings()["edwards"] == 0.0
+    plan.close()
+
+
+def test_bases_edwards_only_for_subgroup_tables(lib, mlhip, monkeypatch):
+    """mlhip_bases_create checks a BLS12-377 G1 table on the device: all points in the prime-order subgroup -> the table's
+    MSMs sum their buckets in twisted Edwards coordinates; one curve point outside G1 (or one point off the curve) -> the
+    Weierstrass kernels, and the reference's answer for that input.  Either way the bytes are the oracle's."""
+    from oracle import cref
+    from oracle import pyref as R
+
+    cp = R.CURVES["BLS12-377"]
+    cid = cp.curve_id
+    _, g1b, _, _ = mlhip.sizes(cid)
+    n = 5000
+    good = cref.gen_points(cid, 1, 91, 17, n)
+    sc = _rand_scalars(n, 8377, 252)
+    x = 5
+    while True:  # a curve point outside G1: almost every curve point is (the cofactor has 94 bits)
+        y = R.fp_sqrt((x * x * x + cp.b) % cp.p, cp.p)
+        if y is not None and R.g1_mul_unreduced(cp, (x, y), cp.r) is not None:
+            break
+        x += 1
+    outside = bytearray(good)
+    outside[11 * g1b : 12 * g1b] = R.g1_to_mont_bytes(cp, (x, y))
+    off_curve = bytearray(good)
+    off_curve[3 * g1b : 3 * g1b + 4] = bytes(4)  # some x limb zeroed: not on the curve
+    for c in (13, 16):
+        for name, pts, checked in (("subgroup", good, 1), ("outside", bytes(outside), 0), ("off-curve", bytes(off_curve), 0)):
+            h = ctypes.c_void_p()
+            mlhip.check(lib.mlhip_bases_create(cid, 1, pts, n, c, ctypes.byref(h)))
+            assert lib.mlhip_bases_checked_subgroup(h) == checked, name
+            if name != "off-curve":  # (the oracle's formulas are for curve points)
+                want = cref.msm(cid, 1, pts, sc, n, False, 0, 8)
+                for k in (n, 1234, n):
+                    out = ctypes.create_string_buffer(g1b)
+                    mlhip.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, k, out))
+                    assert out.raw == (want if k == n else cref.msm(cid, 1, pts, sc, k, False, 0, 8)), (name, c, k)
+            mlhip.check(lib.mlhip_bases_destroy(h))
+    monkeypatch.setenv("MLHIP_EDWARDS", "0")
+    h = ctypes.c_void_p()
+    mlhip.check(lib.mlhip_bases_create(cid, 1, good, n, 13, ctypes.byref(h)))
+    assert lib.mlhip_bases_checked_subgroup(h) == 0
+    mlhip.check(lib.mlhip_bases_destroy(h))
+    g381 = load_golden("BLS12-381")
+    h = ctypes.c_void_p()
+    mlhip.check(lib.mlhip_bases_create(g381["curve_id"], 1, cref.gen_points(g381["curve_id"], 1, 1, 2, 100), 100, 0, ctypes.byref(h)))
+    assert lib.mlhip_bases_checked_subgroup(h) == 0  # no Edwards model: nothing to check
+    mlhip.check(lib.mlhip_bases_destroy(h))
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_msm_shared_scalars(lib, mlhip, curve, monkeypatch):
     """mlhip_msm_launch_shared: the G1 and the G2 MSM of one scalar vector, sorted once in the G1 plan and accumulated

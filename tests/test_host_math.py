@@ -476,6 +476,45 @@ def test_madd28_lane_pair_g2_accumulation(hostmath, name):
         assert out.raw == R.g2_to_mont_bytes(cp, want)
 
 
+def test_ed28_twisted_edwards_g1_accumulation(hostmath):
+    """ed28.h (BLS12-377 G1): bucket sums in extended twisted Edwards coordinates over the carry-free form -- the batched
+    Weierstrass -> Edwards conversion (one shared inversion per four points, infinity inputs), the 7-product mixed
+    addition incl. doubling (P + P), cancellation (P - P), negated inputs, the full addition and the way back to XYZZ --
+    against the oracle's Weierstrass sums; also the oracle's own statement of the map."""
+    cp = R.CURVES["BLS12-377"]
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("host/ed28")
+    P = [R.g1_mul(cp, cp.g1, 1 + d.below(cp.r - 1)) for _ in range(6)]
+    for q in P[:3]:  # the oracle's map is a group isomorphism on G1
+        e = R.g1_to_edwards(cp, q)
+        assert R.edwards_to_g1(cp, e) == q
+        assert R.edwards_to_g1(cp, R.edwards_add(cp, e, R.g1_to_edwards(cp, P[3]))) == R.g1_add(cp, q, P[3])
+    cases = [
+        [(P[0], 0)],
+        [(P[0], 1)],
+        [(P[i], i & 1) for i in range(6)],
+        [(P[0], 0), (P[0], 0), (P[1], 0)],
+        [(P[0], 0), (P[0], 1)],
+        [(P[0], 0), (P[0], 1), (P[1], 1), (P[2], 0)],
+        [(None, 0), (P[3], 0), (None, 1), (P[3], 0), (P[3], 0)],
+        [(None, 0), (None, 1)],
+        [(P[0], 0), (P[1], 0), (R.g1_add(cp, P[0], P[1]), 1)],
+        [(P[i % 6], (i * 7) & 1) for i in range(37)],
+    ]
+    for seq in cases:
+        pts = b"".join(R.g1_to_mont_bytes(cp, q) for q, _ in seq)
+        neg = bytes(s for _, s in seq)
+        want = None
+        for q, s in seq:
+            want = R.g1_add(cp, want, R.g1_neg(cp, q) if s else q)
+        for mode in (0, 1):
+            out = ctypes.create_string_buffer(2 * n)
+            assert L.hm_ed28_chain(cid, pts, neg, len(seq), mode, out) == 0
+            assert out.raw == R.g1_to_mont_bytes(cp, want), (mode, len(seq))
+    out = ctypes.create_string_buffer(2 * R.CURVES["BLS12-381"].fp_bytes)
+    assert L.hm_ed28_chain(R.CURVES["BLS12-381"].curve_id, b"", b"", 0, 0, out) == -2  # no Edwards model of that curve
+
+
 @pytest.mark.parametrize("name", list(R.CURVES))
 def test_divsteps_inversion(hostmath, name):
     """modinv.h (Bernstein-Yang divsteps, fixed iteration count) against Python's pow(x, -1, p): edge values, values
