@@ -460,6 +460,31 @@ def main() -> None:
                 ts.append((time.perf_counter() - t1) * 1e3)
             extra["skewed_scalars_below_2^32_1pct_duplicates"] = {"ms_per_msm_median": statistics.median(ts[1:]), "ms_per_msm_min": min(ts[1:]), "group": "G1" if g0 == G1 else "G2"}
             del sk, pts_sk
+            # BLS12-377 G1 (config 5): the same steps with the caller's SRS promise (mlhip_msm_plan_assume_srs: the points
+            # are fixed at their address and lie in the prime-order subgroup -- true of this shard, P_i = [k_i]G): bucket
+            # sums in twisted Edwards coordinates, the converted copy of the points kept between launches.  Never `value`:
+            # the reference's MultiScalarMul takes any curve points in fresh slices, and `value` is measured that way.
+            if CURVE == _lib.CURVE_BLS12_377 and groups == [G1]:
+                pl = plans[(0, G1)]
+                pl.assume_srs(True)
+                ts, ed_ph = [], {}
+                for i in range(args.steps + 2):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    pl.launch(points[G1].data_ptr(), scalars.data_ptr(), n, False, streams[(0, G1)].cuda_stream)
+                    out_srs = pl.finish()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                    ed_ph = pl.timings()
+                pl.assume_srs(False)
+                acc_ed = ed_ph.get("accumulate", 0.0)
+                extra["fixed_srs_promise"] = {
+                    "ms_per_msm_median": statistics.median(ts[2:]), "ms_per_msm_min": min(ts[2:]),
+                    "scalar_muls_per_s": n / (statistics.median(ts[2:]) * 1e-3), "edwards_bucket_sums": ed_ph.get("edwards", 0.0) == 1.0,
+                    "kernel": "k_accumulate_ed28_seg<Bls377>", "accumulate_ms": acc_ed, "tiles": int(ed_ph.get("tiles", 1)),
+                    # 7 products per unified mixed addition: 7 x (196 + 196) v_mad_i64_i32 + 7 x 14 v_mul_lo_u32
+                    "v_mad_frac_of_measured_peak": ((n * n_windows * (7 * 392 + 7 * 14)) / (acc_ed * 1e-3)) / INT_MAC_PEAK if acc_ed > 0 else 0.0,
+                    "same_result_as_the_timed_steps": out_srs == res[G1] if world == 1 else None,
+                }
             # PCIe-inclusive protocols of SURVEY 8d on this rank's G1 shard: (b) resident bases + scalars from host
             # memory per call, (c) points and scalars from host memory per call (the reference-shaped MultiScalarMul)
             if rank == 0 and G1 in groups:

@@ -362,6 +362,13 @@ func (b *Bases) MultiScalarMul(scalars []driver.Zr) driver.G1 {
 	return out
 }
 
+// CheckedSubgroup reports whether the library verified, on the device, that every point of the table lies in G1.  A
+// BLS12-377 table that passes has its bucket sums done in twisted Edwards coordinates (7 field products per addition
+// instead of 10); one that does not keeps the Weierstrass kernels and gnark's result for that input.
+func (b *Bases) CheckedSubgroup() bool {
+	return b.h != nil && C.mlhip_bases_checked_subgroup(b.h) == 1
+}
+
 func (b *Bases) Close() {
 	if b.h != nil {
 		C.mlhip_bases_destroy(b.h)

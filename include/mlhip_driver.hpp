@@ -533,6 +533,9 @@ class Bases {
     check(mlhip_bases_msm(h_, sc.data(), curve_->scalars_mont ? 1 : 0, b.size(), out.raw.data()));
     return out;
   }
+  // every point of the table was verified on the device to lie in G1 (BLS12-377: its MSMs then sum their buckets in
+  // twisted Edwards coordinates; a table with a point outside G1 keeps the Weierstrass kernels and the reference's result)
+  bool CheckedSubgroup() const { return mlhip_bases_checked_subgroup(h_) == 1; }
 
  private:
   const Curve* curve_;

@@ -30,6 +30,12 @@ struct QuadHost28 {
   static void sub(V& r, const V& x, const V& y) {
     for (int i = 0; i < 4; i++) fp28_sub<C>(r.v[i], x.v[i], y.v[i]);
   }
+  static void add(V& r, const V& x, const V& y) {
+    for (int i = 0; i < 4; i++) fp28_add<C>(r.v[i], x.v[i], y.v[i]);
+  }
+  static void konst(V& r, const int32_t (&k)[C::N28]) {
+    for (int i = 0; i < 4; i++) fp28_from_const<C>(r.v[i], k);
+  }
   static void norm(V& r, const V& x) {
     for (int i = 0; i < 4; i++) fp28_normalize<C>(r.v[i], x.v[i]);
   }
@@ -73,6 +79,8 @@ struct QuadDevice28 {
   static __device__ __forceinline__ unsigned lane() { return threadIdx.x & 3u; }
   static __device__ __forceinline__ void mul(V& r, const V& x, const V& y) { fp28_mul<C>(r, x, y); }
   static __device__ __forceinline__ void sub(V& r, const V& x, const V& y) { fp28_sub<C>(r, x, y); }
+  static __device__ __forceinline__ void add(V& r, const V& x, const V& y) { fp28_add<C>(r, x, y); }
+  static __device__ __forceinline__ void konst(V& r, const int32_t (&k)[C::N28]) { fp28_from_const<C>(r, k); }
   static __device__ __forceinline__ void norm(V& r, const V& x) { fp28_normalize<C>(r, x); }
   template <int CTRL>
   static __device__ __forceinline__ int32_t xlane(int32_t v) {

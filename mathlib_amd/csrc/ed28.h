@@ -187,4 +187,41 @@ MLHIP_HD void ed28_from_affine(EdExt28<C>& r, const Affine<FpField<C>>& p) {
   fp28_from_const<C>(r.z, C::ONE28);
 }
 
+// ---- the unified addition over the four lanes of a quad (the bucket reduction; backends: ec_quad28.h) -------------------
+// Lane q of a quad holds coordinate q of (X : Y : Z : T), as the XYZZ reduction holds X, Y, ZZ, ZZZ.  add-2008-hwcd-3 is then
+// THREE rounds of one product per lane -- A | B | D | T1 T2, then C = 2 d T1 T2 on the fourth lane, then X3 | Y3 | Z3 | T3 --
+// against four for XYZZ, with no carry propagation, no zero test and no branch: the identity (0 : 1 : 1 : 0) and equal
+// operands go through the same instructions.
+template <class C, class B>
+MLHIP_HD void ed_quad28_add(typename B::V& a, const typename B::V& b) {
+  typedef typename B::V V;
+  V t, s, d, x, y, k, m1, m2, v, p1, sum, diff, ea, fa, ha, ga;
+  B::template perm<0xE1>(t, a);  // Y1 | X1 | Z1 | T1   (quad_perm [1,0,2,3])
+  B::add(s, a, t);               // Y1 + X1 | . | 2 Z1 | 2 T1
+  B::sub(d, t, a);               // Y1 - X1 | . | 0 | 0
+  B::sel(x, 0x1u, d, s);
+  B::sel(x, 0x8u, a, x);  // Y1 - X1 | Y1 + X1 | 2 Z1 | T1                              weight 2
+  B::template perm<0xE1>(t, b);
+  B::add(s, b, t);
+  B::sub(d, t, b);
+  B::sel(y, 0x1u, d, b);
+  B::sel(y, 0x2u, s, y);  // Y2 - X2 | Y2 + X2 | Z2 | T2
+  B::mul(m1, x, y);       // A | B | D | T1 T2                                           <= 2 x 2
+  B::konst(k, C::ED_2D28);
+  B::mul(m2, m1, k);      // . | . | . | C
+  B::sel(v, 0x8u, m2, m1);             // A | B | D | C
+  B::template perm<0xB1>(p1, v);       // B | A | C | D   (quad_perm [1,0,3,2])
+  B::add(sum, v, p1);                  // H | H | G | G                                  weight 2
+  B::sub(diff, p1, v);                 // E | -E | -F | F
+  B::template perm<0x00>(ea, diff);    // E on every lane
+  B::template perm<0xFF>(fa, diff);    // F
+  B::template perm<0x00>(ha, sum);     // H
+  B::template perm<0xAA>(ga, sum);     // G
+  B::sel(x, 0x2u, ga, ea);
+  B::sel(x, 0x4u, fa, x);  // E | G | F | E
+  B::sel(y, 0x1u, fa, ha);
+  B::sel(y, 0x4u, ga, y);  // F | H | G | H
+  B::mul(a, x, y);         // X3 | Y3 | Z3 | T3                                          2 x 2
+}
+
 }  // namespace mlhip

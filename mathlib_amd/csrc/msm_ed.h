@@ -1,8 +1,9 @@
 // msm_ed.h -- G1 bucket accumulation in extended twisted Edwards coordinates (ed28.h) for plans whose caller vouches for
 // the prime-order subgroup (mlhip_msm_plan_assume_srs; curves with C::HAS_EDWARDS: BLS12-377).  Part of msm_kernels.h.
 // The kernels mirror k_points_to28 / k_accumulate28_seg / k_accumulate_big_seg (msm_accumulate.h): same entry lists, same
-// state buffer (an EdExt28 has the footprint of an XYZZ28), and the LAST segment leaves every bucket as the XYZZ28 the
-// reduction kernels read -- nothing after the accumulation knows which curve model summed the buckets.
+// state buffer (an EdExt28 has the footprint of an XYZZ28).  The buckets STAY in extended Edwards coordinates: the quad-lane
+// reduction kernels run their Edwards instantiation on them (msm_reduce.h: k_chunks_q28<C, true>, ed_quad28_add) and
+// only the W x nsel window sums return to the Weierstrass curve, for the host tail.
 #pragma once
 // (included by msm_kernels.h after msm_accumulate.h)
 
@@ -37,7 +38,7 @@ __global__ void __launch_bounds__(256) k_points_to_ed28(const Affine<FpField<C>>
   }
 }
 
-// one thread per bucket; state[g] is the bucket in extended coordinates between segments and its XYZZ28 after the last
+// one thread per bucket; state[g] is the bucket in extended coordinates, between segments and for the reduction
 template <class C>
 __global__ void __launch_bounds__(256) k_accumulate_ed28_seg(const EdNiels28<C>* __restrict__ points,
                                                              const uint32_t* __restrict__ sorted,
@@ -51,13 +52,13 @@ __global__ void __launch_bounds__(256) k_accumulate_ed28_seg(const EdNiels28<C>*
   if (tid >= n_buckets) return;
   const size_t g = order[tid];
   const uint32_t cnt = counts[g];
-  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0;
   if (cnt > big_threshold) {  // k_accumulate_big_seg_ed adds this segment's entries to the bucket's state
     uint32_t pos = atomicAdd(big_count, 1u);
     big_list[pos] = (uint32_t)g;
     return;
   }
-  if (cnt == 0 && !first && !last) return;
+  if (cnt == 0 && !first) return;
   EdExt28<C>* const st = reinterpret_cast<EdExt28<C>*>(state);
   EdExt28<C> acc;
   if (first)
@@ -80,24 +81,12 @@ __global__ void __launch_bounds__(256) k_accumulate_ed28_seg(const EdNiels28<C>*
       p = pn;
     }
   }
-  if (last) {
-    XYZZ28<C> w;
-    bool inf;
-    ed28_to_xyzz28<C>(w, inf, acc);
-    if (inf) {
-#pragma unroll
-      for (int i = 0; i < C::N28; i++) w.x.l[i] = w.y.l[i] = w.zz.l[i] = w.zzz.l[i] = 0;
-    }
-    state[g] = w;
-  } else {
-    st[g] = acc;
-  }
+  st[g] = acc;
 }
 
 // the long buckets of a segment: their slice sums come from the Weierstrass long-bucket kernels on the original points
-// (k_big_slices: boundary form); thread 0 adds the bucket's earlier state on the Weierstrass side and stores the total as
-// the state's form of the moment -- XYZZ28 after the last segment, extended Edwards coordinates (two inversions; a
-// handful of buckets per segment) otherwise
+// (k_big_slices: boundary form); thread 0 adds the bucket's earlier state on the Weierstrass side and maps the total back
+// to extended Edwards coordinates (two inversions; a handful of buckets per segment)
 template <class C, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_ed(const uint32_t* __restrict__ big_list,
                                                                  const uint32_t* __restrict__ big_count,
@@ -109,7 +98,7 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_ed(const uint32_t*
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
   EdExt28<C>* const st = reinterpret_cast<EdExt28<C>*>(state);
   const uint32_t nbig = *big_count;
-  const bool first = (flags & MLHIP_SEG_FIRST) != 0, last = (flags & MLHIP_SEG_LAST) != 0;
+  const bool first = (flags & MLHIP_SEG_FIRST) != 0;
   for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
     const uint32_t g = big_list[bi];
     XYZZ<F> sum;
@@ -124,25 +113,11 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_ed(const uint32_t*
         xyzz28_to<C>(prev, w, inf);
         xyzz_add_ool<F>(sum, prev);
       }
-      if (last) {
-        XYZZ28<C> s28;
-        if (xyzz_is_inf<F>(sum)) {
-#pragma unroll
-          for (int i = 0; i < C::N28; i++) s28.x.l[i] = s28.y.l[i] = s28.zz.l[i] = s28.zzz.l[i] = 0;
-        } else {
-          fp28_from_fp<C>(s28.x, sum.x);
-          fp28_from_fp<C>(s28.y, sum.y);
-          fp28_from_fp<C>(s28.zz, sum.zz);
-          fp28_from_fp<C>(s28.zzz, sum.zzz);
-        }
-        state[g] = s28;
-      } else {
-        Affine<F> a;
-        xyzz_to_affine<F>(a, sum);  // (0, 0) for the point at infinity: ed28_from_affine maps it to the identity
-        EdExt28<C> e;
-        ed28_from_affine<C>(e, a);
-        st[g] = e;
-      }
+      Affine<F> a;
+      xyzz_to_affine<F>(a, sum);  // (0, 0) for the point at infinity: ed28_from_affine maps it to the identity
+      EdExt28<C> e;
+      ed28_from_affine<C>(e, a);
+      st[g] = e;
     }
     __syncthreads();
   }

@@ -334,11 +334,22 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
       if (p->reduce28) {
         // the accumulation left its carry-free bucket state in d_state28 (MLHIP_SEG_KEEP28)
         typedef XYZZ28<C> X28;
-        k_chunks_q28<C><<<dim3((unsigned)((4 * n_chunks + p->red_block - 1) / p->red_block)), dim3(p->red_block), 0, st>>>(
-            (const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
         constexpr int RB = 512;  // 128 quads, 28 KB of LDS per block
-        k_masked_sums_q28<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X28), st>>>(
-            (const X28*)p->d_A, (const X28*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+        const dim3 cgrid((unsigned)((4 * n_chunks + p->red_block - 1) / p->red_block)), cblock(p->red_block);
+        bool done_ed = false;
+        if constexpr (C::HAS_EDWARDS) {
+          if (p->last_ed) {  // ... in extended twisted Edwards coordinates (msm_ed.h): the same kernels on that addition
+            k_chunks_q28<C, true><<<cgrid, cblock, 0, st>>>((const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
+            k_masked_sums_q28<C, RB, true><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X28), st>>>(
+                (const X28*)p->d_A, (const X28*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+            done_ed = true;
+          }
+        }
+        if (!done_ed) {
+          k_chunks_q28<C><<<cgrid, cblock, 0, st>>>((const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
+          k_masked_sums_q28<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X28), st>>>(
+              (const X28*)p->d_A, (const X28*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+        }
       } else if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created
         k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
                                                                                      p->L, (X*)p->d_A, (X*)p->d_W0);

@@ -172,16 +172,36 @@ __global__ void __launch_bounds__(256) k_accumulate_q28(const Affine28<C>* __res
   quad28_store<C>(state, g, acc);
 }
 
-template <class C>
+// the empty sum of a quad: all-zero limbs (XYZZ: ZZ = 0), or the twisted Edwards identity (0 : 1 : 1 : 0) when the
+// buckets arrive in extended Edwards coordinates (ED: a subgroup-trusted BLS12-377 plan, msm_ed.h) -- the same kernels
+// then add with ed_quad28_add: three product rounds instead of four, no exceptional case
+template <class C, bool ED>
+__device__ __forceinline__ void quad28_empty(Fp28<C>& v) {
+  fp28_zero<C>(v);
+  if constexpr (ED) {
+    Fp28<C> one;
+    fp28_from_const<C>(one, C::ONE28);
+    const unsigned q = threadIdx.x & 3u;
+    fp28_select<C>(v, q == 1 || q == 2, one, v);
+  }
+}
+template <class C, bool ED>
+__device__ __forceinline__ void quad28_add_any(Fp28<C>& a, const Fp28<C>& b) {
+  if constexpr (ED)
+    ed_quad28_add<C, QuadDevice28<C>>(a, b);
+  else
+    quad28_xyzz_add<C, QuadDevice28<C>>(a, b);
+}
+
+template <class C, bool ED = false>
 __global__ void __launch_bounds__(256) k_chunks_q28(const XYZZ28<C>* __restrict__ buckets, size_t n_chunks, int l_eff,
                                                     XYZZ28<C>* __restrict__ A, XYZZ28<C>* __restrict__ W0) {
-  typedef QuadDevice28<C> B;
   const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   if (g >= n_chunks) return;  // quad-uniform
   const XYZZ28<C>* b = buckets + g * (size_t)l_eff;
   Fp28<C> acc, w0, cur, x, y;
-  fp28_zero<C>(acc);
-  fp28_zero<C>(w0);
+  quad28_empty<C, ED>(acc);
+  quad28_empty<C, ED>(w0);
   quad28_load<C>(cur, b, l_eff - 1);
   const int steps = 2 * (l_eff - 1) + 1;  // acc += b[i]; w0 += acc; ... ; acc += b[0]
 #pragma unroll 1
@@ -191,7 +211,7 @@ __global__ void __launch_bounds__(256) k_chunks_q28(const XYZZ28<C>* __restrict_
     fp28_select<C>(x, odd, w0, acc);
     fp28_select<C>(y, odd, acc, cur);
     if (!odd && i > 0) quad28_load<C>(cur, b, i - 1);  // the next bucket arrives under this addition
-    quad28_xyzz_add<C, B>(x, y);
+    quad28_add_any<C, ED>(x, y);
     fp28_select<C>(w0, odd, x, w0);
     fp28_select<C>(acc, odd, acc, x);
   }
@@ -200,7 +220,7 @@ __global__ void __launch_bounds__(256) k_chunks_q28(const XYZZ28<C>* __restrict_
 }
 
 // same selections as k_masked_sums; BLOCK / 4 quads per block; the result leaves in the boundary form
-template <class C, int BLOCK>
+template <class C, int BLOCK, bool ED = false>
 __global__ void __launch_bounds__(BLOCK) k_masked_sums_q28(const XYZZ28<C>* __restrict__ A, const XYZZ28<C>* __restrict__ W0,
                                                            uint32_t T, int nsel, XYZZ<FpField<C>>* __restrict__ out) {
   typedef QuadDevice28<C> B;
@@ -213,7 +233,7 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums_q28(const XYZZ28<C>* __re
   const int sel = blockIdx.x % nsel;
   const X* src = (sel < 2 ? W0 : A) + (size_t)w * T;
   Fp28<C> acc, v;
-  fp28_zero<C>(acc);
+  quad28_empty<C, ED>(acc);
   uint32_t count, lo = 0;
   int k = 0;
   if (sel < 4) {
@@ -229,7 +249,7 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums_q28(const XYZZ28<C>* __re
   for (uint32_t j = quad; j < count; j += NQ) {
     const uint32_t t = sel < 4 ? lo + j : (((j >> k) << (k + 1)) | (1u << k) | (j & lowmask));
     quad28_load<C>(v, src, t);
-    quad28_xyzz_add<C, B>(acc, v);
+    quad28_add_any<C, ED>(acc, v);
   }
   quad28_store<C>(sh, quad, acc);
   __syncthreads();
@@ -237,16 +257,38 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums_q28(const XYZZ28<C>* __re
   for (uint32_t s = NQ / 2; s > 0; s >>= 1) {
     if (quad < s) {  // quad-uniform
       quad28_load<C>(v, sh, quad + s);
-      quad28_xyzz_add<C, B>(acc, v);
+      quad28_add_any<C, ED>(acc, v);
       quad28_store<C>(sh, quad, acc);
     }
     __syncthreads();
   }
   if (quad == 0) {
-    // (an empty sum is ZZ = 0 limbs, which converts to the boundary form's ZZ = 0)
-    Fp<C> r;
-    fp28_to_fp<C>(r, acc);
-    quad_store<C>(out, blockIdx.x, r);
+    if constexpr (ED) {
+      // the W x nsel sums leave as Weierstrass points in the boundary form, like every other path's: each lane of the
+      // quad rebuilds the point from the four coordinates and keeps its own
+      XYZZ28<C> g4, w;
+      B::gather(g4, acc);
+      EdExt28<C> e;
+      e.x = g4.x;
+      e.y = g4.y;
+      e.z = g4.zz;
+      e.t = g4.zzz;
+      bool inf;
+      ed28_to_xyzz28<C>(w, inf, e);
+      XYZZ<FpField<C>> r4;
+      xyzz28_to<C>(r4, w, inf);
+      const unsigned q = threadIdx.x & 3u;
+      Fp<C> r, t2;
+      fp_select<C>(t2, q == 0, r4.x, r4.y);
+      fp_select<C>(r, q >= 2, r4.zz, t2);
+      fp_select<C>(r, q == 3, r4.zzz, r);
+      quad_store<C>(out, blockIdx.x, r);
+    } else {
+      // (an empty sum is ZZ = 0 limbs, which converts to the boundary form's ZZ = 0)
+      Fp<C> r;
+      fp28_to_fp<C>(r, acc);
+      quad_store<C>(out, blockIdx.x, r);
+    }
   }
 }
 

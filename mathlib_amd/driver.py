@@ -476,6 +476,10 @@ class Bases:
         check(load().mlhip_bases_msm(self._h, c._scalars(scalars), 1 if c.scalars_mont else 0, len(scalars), out))
         return G1(out.raw, c)
 
+    def CheckedSubgroup(self) -> bool:
+        """every point of the table was verified on the device to lie in G1 (BLS12-377: Edwards bucket sums)"""
+        return load().mlhip_bases_checked_subgroup(self._h) == 1
+
     def Close(self) -> None:
         if self._h:
             load().mlhip_bases_destroy(self._h)

@@ -496,7 +496,7 @@ struct Ops {
                 if (co[k]->l[l] < 0 || co[k]->l[l] >= (1 << 28)) return -3;
           }
         }
-      } else {
+      } else if (mode == 1) {
         for (int i = 0; i < n; i++) {
           A1 q = p[i];
           if (neg[i]) fp_neg<C>(q.y, q.y);
@@ -504,6 +504,41 @@ struct Ops {
           ed28_from_affine<C>(e, q);
           ed28_add<C>(acc, e);
         }
+      } else {  // the quad-lane schedule of the reduction (ed_quad28_add) through the host emulation of the permutes;
+                // mode 3 also adds every partial sum to itself once (equal operands) and takes that back out
+        typedef QuadHost28<C> B;
+        typename B::V qa;
+        qa.v[0] = acc.x;
+        qa.v[1] = acc.y;
+        qa.v[2] = acc.z;
+        qa.v[3] = acc.t;
+        for (int i = 0; i < n; i++) {
+          A1 q = p[i];
+          if (neg[i]) fp_neg<C>(q.y, q.y);
+          EdExt28<C> e;
+          ed28_from_affine<C>(e, q);
+          typename B::V qb;
+          qb.v[0] = e.x;
+          qb.v[1] = e.y;
+          qb.v[2] = e.z;
+          qb.v[3] = e.t;
+          ed_quad28_add<C, B>(qa, qb);
+          if (mode == 3) {
+            typename B::V dbl = qa, neg1 = qa;
+            ed_quad28_add<C, B>(dbl, qa);  // 2 S
+            fp28_neg<C>(neg1.v[0], qa.v[0]);  // -S: (-X : Y : Z : -T)
+            fp28_neg<C>(neg1.v[3], qa.v[3]);
+            ed_quad28_add<C, B>(dbl, neg1);  // 2 S - S
+            qa = dbl;
+          }
+          for (int k = 0; k < 4; k++)
+            for (int l = 0; l < C::N28 - 1; l++)
+              if (qa.v[k].l[l] < 0 || qa.v[k].l[l] >= (1 << 28)) return -3;
+        }
+        acc.x = qa.v[0];
+        acc.y = qa.v[1];
+        acc.z = qa.v[2];
+        acc.t = qa.v[3];
       }
       XYZZ28<C> w;
       bool inf;

@@ -300,6 +300,10 @@ def test_resident_bases_match_multiscalarmul(curve, segments, monkeypatch):
     g = c.GenG1()
     pts = [g.Mul(c.NewRandomZr(c._rng)) for _ in range(40)]
     bases = c.NewBases(pts)
+    from mathlib_amd import _lib
+
+    # the table is checked on the device where a curve has the twisted Edwards model that needs it (BLS12-377)
+    assert bases.CheckedSubgroup() == (c.id == _lib.CURVE_BLS12_377)
     for n in (40, 17, 1, 40):
         sc = [c.NewRandomZr(c._rng) for _ in range(n)]
         assert bases.MultiScalarMul(sc).Equals(c.MultiScalarMul(pts[:n], sc))

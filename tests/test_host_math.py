@@ -507,7 +507,7 @@ def test_ed28_twisted_edwards_g1_accumulation(hostmath):
         want = None
         for q, s in seq:
             want = R.g1_add(cp, want, R.g1_neg(cp, q) if s else q)
-        for mode in (0, 1):
+        for mode in (0, 1, 2, 3):  # mixed additions, full additions, the quad-lane schedule, that with doublings
             out = ctypes.create_string_buffer(2 * n)
             assert L.hm_ed28_chain(cid, pts, neg, len(seq), mode, out) == 0
             assert out.raw == R.g1_to_mont_bytes(cp, want), (mode, len(seq))
