@@ -220,6 +220,19 @@ def test_msm_other_config_shapes(mlhip, curve_name, group, log_n):
     threads = max(1, min(64, len(os.sched_getaffinity(0))))
     ss = s.cpu().numpy().view(np.uint64).reshape(n, 4)
     assert cref.msm(cid, group, pts.cpu().numpy(), ss, n, False, 16, threads) == full
+    if curve_name == "BLS12-377" and group == 1:
+        # BASELINE configs[4] over a fixed SRS: the same 2^22 pairs with the caller's promise -- bucket sums and reduction
+        # in twisted Edwards coordinates, tiles of 2^20 points, then a second launch on the kept conversion, and a prefix
+        plan.set_profiling(True)
+        plan.assume_srs(True)
+        assert plan.run(pts.data_ptr(), s.data_ptr(), n, False, st) == full
+        t = plan.timings()
+        assert t["edwards"] == 1.0 and t["tiles"] == (n >> 20 if n >= 1 << 21 else 1), t
+        assert plan.run(pts.data_ptr(), s.data_ptr(), n, False, st) == full
+        assert plan.run(pts.data_ptr(), s.data_ptr(), h, False, st) == a
+        plan.assume_srs(False)
+        assert plan.run(pts.data_ptr(), s.data_ptr(), n, False, st) == full
+        assert plan.timings()["edwards"] == 0.0
     plan.close()
 
 

@@ -28,6 +28,8 @@ def main():
         for kind in ("fetch", "write"):
             for f in glob.glob(os.path.join(src, "pmc_%s_c%s" % (kind, c), "**", "*counter_collection.csv"), recursive=True):
                 pmc_args.append("%s:%s" % (c, f))
+    for f in glob.glob(os.path.join(src, "stats_ed", "**", "*kernel_stats.csv"), recursive=True):
+        cp(f, "%s_edwards_kernel_stats.csv" % prefix)
     if pmc_args:
         sh = open(os.path.join(src, "source_hash.txt")).read().strip()
         commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()

@@ -28,6 +28,11 @@ for c in $configs; do
     echo "config $c bench line done"
   fi
 done
+# BLS12-377 over a fixed SRS (twisted Edwards bucket sums): kernel stats of the A/B tool
+rocprofv3 --kernel-trace --stats -d "$out/stats_ed" -o e --output-format csv -- python3 tools/perf_edwards.py 22 > "$out/perf_edwards_under_rocprof.txt" 2> "$out/stats_ed.err" || true
+python3 tools/perf_edwards.py 22 > "$out/perf_edwards22.txt" 2>&1 || true
+python3 tools/perf_edwards.py 20 > "$out/perf_edwards20.txt" 2>&1 || true
+echo "edwards profiled"
 # the traces themselves are large: keep the stats and the counter tables only
 find "$out" -name "*kernel_trace.csv" -size +20M -delete
 find "$out" -name "*stats*.csv"

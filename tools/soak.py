@@ -72,8 +72,21 @@ while time.time() - t0 < budget:
             ds = torch.frombuffer(bytearray(sc.tobytes()), dtype=torch.uint8).to(dev)
             cc = c if c else 12
             plan = _lib.MsmPlan(cid, group, n, cc)
-            if rnd.random() < 0.5:
+            # BLS12-377 G1: half of the plans carry the SRS promise (the points are multiples of the generator): bucket sums
+            # and reduction in twisted Edwards coordinates when the bucket set is large enough, twice through the same
+            # plan so that the second launch runs on the kept conversion
+            srs = name == "BLS12-377" and group == 1 and rnd.random() < 0.5
+            if srs:
+                plan.assume_srs(True)
+                plan.set_profiling(True)
+            if srs or rnd.random() < 0.5:
                 got = plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st)
+                if srs:
+                    if plan.timings().get("edwards") == 1.0:
+                        done["edwards"] = done.get("edwards", 0) + 1
+                    if plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st) != got:
+                        print("MISMATCH second launch on the kept Edwards conversion", n, cc, bits, "tile", tile, "seed", seed, flush=True)
+                        sys.exit(1)
             else:  # the G1 and the G2 MSM of the same scalars, sorted once
                 og = 3 - group
                 osz = g1b if og == 1 else g2b
@@ -101,6 +114,19 @@ while time.time() - t0 < budget:
             devs = (ctypes.c_int * nd)(*([0] * nd))
             _lib.check(lib.mlhip_msm_multi(cid, group, devs, nd, pts, sc.tobytes(), 0, n, c, out))
             done["multi"] = done.get("multi", 0) + 1
+        elif mode < 0.42 and group == 1:  # a resident table (BLS12-377: checked on the device, then Edwards bucket sums)
+            h = ctypes.c_void_p()
+            _lib.check(lib.mlhip_bases_create(cid, 1, pts, n, c, ctypes.byref(h)))
+            k = rnd.randrange(1, n + 1)
+            _lib.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, k, out))
+            if k != n and out.raw != cref.msm(cid, 1, pts, sc, k, False, 0, 16):
+                print("MISMATCH bases prefix", name, n, k, c, bits, "seed", seed, flush=True)
+                sys.exit(1)
+            _lib.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, n, out))
+            if name == "BLS12-377":
+                done["tables_checked"] = done.get("tables_checked", 0) + lib.mlhip_bases_checked_subgroup(h)
+            _lib.check(lib.mlhip_bases_destroy(h))
+            done["bases"] = done.get("bases", 0) + 1
         else:
             _lib.check(fn(cid, pts, sc.tobytes(), 0, n, c, out))
         if out.raw != exp:
