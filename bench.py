@@ -464,7 +464,7 @@ def main() -> None:
             # are fixed at their address and lie in the prime-order subgroup -- true of this shard, P_i = [k_i]G): bucket
             # sums in twisted Edwards coordinates, the converted copy of the points kept between launches.  Never `value`:
             # the reference's MultiScalarMul takes any curve points in fresh slices, and `value` is measured that way.
-            if CURVE == _lib.CURVE_BLS12_377 and groups == [G1]:
+            if CURVE == _lib.CURVE_BLS12_377 and tuple(groups) == (G1,):
                 pl = plans[(0, G1)]
                 pl.assume_srs(True)
                 ts, ed_ph = [], {}
