@@ -383,7 +383,7 @@ def main() -> None:
             "bound": "hbm", "kernel": acc_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": acc_ms / tiles,
             "algorithmic_bytes_per_launch": bytes_unit * n // tiles, "launches_per_msm": tiles,
-            "phase_ms": {("g1_" if g == G1 else "g2_") + k_: v for (g, k_), v in sorted(phase_avg.items()) if k_ != "tiles"},
+            "phase_ms": {("g1_" if g == G1 else "g2_") + k_: v for (g, k_), v in sorted(phase_avg.items()) if k_ not in ("tiles", "edwards")},
         }
         roofline["traffic"], roofline["traffic_note"] = _pmc(args.config, acc_kernel.split("<")[0] + "<" + cname)
         if reduced:
