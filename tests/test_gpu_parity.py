@@ -894,6 +894,23 @@ def test_msm_edwards_trusted_plan(lib, mlhip, monkeypatch):
             assert plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st) == want
             assert plan.timings()["edwards"] == 0.0
             plan.close()
+    # the G1 half of a shared-scalar launch (mlhip_msm_launch_shared) carries the promise: Edwards bucket sums for G1, the G2
+    # plan reads the same entry lists -- one pass and tiles
+    _, _, g2b, _ = mlhip.sizes(cid)
+    p2 = cref.gen_points(cid, 2, 779, 33, n)
+    d2 = torch.frombuffer(bytearray(p2), dtype=torch.uint8).to(dev)
+    ds = torch.frombuffer(bytearray(skew.tobytes()), dtype=torch.uint8).to(dev)
+    want1, want2 = cref.msm(cid, 1, pts, skew, n, False, 0, 8), cref.msm(cid, 2, p2, skew, n, False, 0, 8)
+    a, b = mlhip.MsmPlan(cid, 1, n, 13), mlhip.MsmPlan(cid, 2, n, 13)
+    a.set_profiling(True)
+    a.assume_srs(True)
+    for tile in ("0", "11"):
+        monkeypatch.setenv("MLHIP_TILE_LOG2", tile)
+        a.launch_shared(b, dp.data_ptr(), d2.data_ptr(), ds.data_ptr(), n, False, st)
+        assert a.finish() == want1 and b.finish() == want2, tile
+        assert a.timings()["edwards"] == 1.0
+    a.close()
+    b.close()
     monkeypatch.setenv("MLHIP_TILE_LOG2", "0")
     ds = torch.frombuffer(bytearray(uniform.tobytes()), dtype=torch.uint8).to(dev)
     small = mlhip.MsmPlan(cid, 1, n, 8)  # 32 x 128 buckets: one bucket per quad of lanes, on XYZZ
