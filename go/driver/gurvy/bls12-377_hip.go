@@ -117,3 +117,62 @@ func (c *Bls12_377Hip) PairingBatch(g2s []driver.G2, g1s []driver.G1) []driver.G
 	}
 	return out
 }
+
+// Bls12_377Bases is a G1 point table kept on the device: NewBases uploads it once, MultiScalarMul then moves only the
+// scalars per call -- the shape of a prover with a fixed SRS, and on this curve the fast path: when the table is made
+// the library checks every point on the device (on the curve and in the prime-order subgroup, gnark's IsInSubGroup
+// test), and a table that passes has its buckets summed and reduced in twisted Edwards coordinates (7 field products
+// per addition instead of 10: 2^22 points 11.1 -> 9.1 ms on one MI355X).  A table with a point outside G1 keeps the
+// Weierstrass kernels and gnark's result for that input; CheckedSubgroup tells which.
+type Bls12_377Bases struct {
+	h *C.mlhip_bases
+	n int
+}
+
+func (c *Bls12_377Hip) NewBases(points []driver.G1) *Bls12_377Bases {
+	n := len(points)
+	if n == 0 {
+		panic("hip: NewBases needs at least one point")
+	}
+	aff := make([]bls12377.G1Affine, n)
+	for i := range points {
+		aff[i] = points[i].(*bls12377G1).G1Affine
+	}
+	b := &Bls12_377Bases{n: n}
+	hipCheck(func() C.int {
+		return C.mlhip_bases_create(C.MLHIP_CURVE_BLS12_377, C.MLHIP_GROUP_G1, unsafe.Pointer(&aff[0]), C.size_t(n),
+			C.int(c.WindowC), &b.h)
+	})
+	return b
+}
+
+// MultiScalarMul returns sum_i [scalars[i]] bases[i] over the first len(scalars) bases.
+func (b *Bls12_377Bases) MultiScalarMul(scalars []driver.Zr) driver.G1 {
+	var result bls12377.G1Affine
+	if len(scalars) == 0 {
+		return &bls12377G1{result}
+	}
+	if len(scalars) > b.n {
+		panic("hip: more scalars than resident bases")
+	}
+	sc := make([]fr.Element, len(scalars))
+	for i := range scalars {
+		sc[i].SetBigInt(&scalars[i].(*common.BaseZr).Int)
+	}
+	hipCheck(func() C.int {
+		return C.mlhip_bases_msm(b.h, unsafe.Pointer(&sc[0]), 1, C.size_t(len(sc)), unsafe.Pointer(&result))
+	})
+	return &bls12377G1{result}
+}
+
+// CheckedSubgroup: every point of the table was verified to lie in G1 (the table takes the twisted Edwards kernels).
+func (b *Bls12_377Bases) CheckedSubgroup() bool {
+	return b.h != nil && C.mlhip_bases_checked_subgroup(b.h) == 1
+}
+
+func (b *Bls12_377Bases) Close() {
+	if b.h != nil {
+		C.mlhip_bases_destroy(b.h)
+		b.h = nil
+	}
+}
