@@ -20,8 +20,8 @@
 // The weights do not depend on the data (the formulas are straight-line), so the budget is verified once and for all on
 // the CPU: Fp2H28 below is the host model of one lane pair (both components + the weight), every operation checks its
 // precondition, and tests/test_host_math.py runs the whole pairing through it against the oracle.
-// Only u^2 = -1 and xi = 1 + u (BLS12-381) are implemented; BN254's 10-limb form gains nothing on the multiplier and
-// BLS12-377's u^2 = -5 does not fit the dual product's weight budget -- both stay on fp2_lanes.h.
+// u^2 = -1 with xi = 1 + u (BLS12-381) and u^2 = -5 with xi = u (BLS12-377: every product operand carry-propagated first, see
+// lp28_mul) are implemented; BN254's 10-limb form gains nothing on the multiplier and stays on fp2_lanes.h.
 #pragma once
 #include "fp28.h"
 #include "fp2_lanes.h"
@@ -256,13 +256,31 @@ MLHIP_HD void lp28_halve(E& r, const E& a) {
   r.set_vb(v);
 }
 
-// (a0 + a1 u)(b0 + b1 u), u^2 = -1: one fused dual product per lane
-//   lane c0: a0 b0 + a1 (-b1)        lane c1: a1 b0 + a0 b1
+// k x for the small positive k = -BETA of u^2 = BETA (5 for BLS12-377): shifts and adds, the weight grows k-fold
+template <class C>
+MLHIP_HD void fp28_times_k(Fp28<C>& r, const Fp28<C>& a) {
+  constexpr int K = -C::BETA;
+  static_assert(K == 1 || K == 5, "u^2 = -1 or -5");
+#pragma unroll
+  for (int i = 0; i < C::N28; i++) r.l[i] = K == 5 ? (int32_t)(((uint32_t)a.l[i] << 2) + (uint32_t)a.l[i]) : a.l[i];
+}
+
+// (a0 + a1 u)(b0 + b1 u), u^2 = BETA = -k: one fused dual product per lane
+//   lane c0: a0 b0 + a1 (-k b1)        lane c1: a1 b0 + a0 b1
+// k = 1 (BN254, BLS12-381): operands of weight w_a w_b <= 4.  k = 5 (BLS12-377): the c0 lane's product has weight
+// (1 + k) w_a w_b, so both operands are carry-propagated first, whatever they were -- the weights are not known on the
+// device, and a propagation is ~40 full-rate instructions beside a 616-instruction product.
 template <class C, class E>
-MLHIP_HD void lp28_mul(E& r, const E& a, const E& b) {
-  static_assert(C::BETA == -1, "carry-free lane pairs: u^2 = -1 only");
-  E::require(2 * a.w() * b.w() <= 8, "fp2_mul", a.w(), b.w());
-  E::require(2 * a.vb() * b.vb() <= LP28_MAXU, "fp2_mul (value bound)", a.vb(), b.vb());
+MLHIP_HD void lp28_mul(E& r, const E& a_in, const E& b_in) {
+  constexpr int K = -C::BETA;
+  E a = a_in, b = b_in;
+  if constexpr (K != 1) {
+    E::require(a.w() <= LP28_MAXW && b.w() <= LP28_MAXW, "fp2_mul", a.w(), b.w());
+    lp28_norm<C>(a);
+    lp28_norm<C>(b);
+  }
+  E::require((1 + K) * a.w() * b.w() <= 8, "fp2_mul", a.w(), b.w());
+  E::require((1 + K) * a.vb() * b.vb() <= LP28_MAXU, "fp2_mul (value bound)", a.vb(), b.vb());
   //   both lanes: own a * b0 + partner's a * (+-b1) -- b0 arrives by one broadcast (no select), the sign of b1 by one
   //   negation of the exchanged value and one select
   E ax, bx, b0, o;
@@ -270,8 +288,9 @@ MLHIP_HD void lp28_mul(E& r, const E& a, const E& b) {
   lp28_partner<C>(bx, b);
   lp28_real_on_both<C>(b0, b);
   for (int i = 0; i < E::LANES; i++) {
-    Fp28<C> nb, y2;
-    fp28_neg<C>(nb, bx.at(i));
+    Fp28<C> kb, nb, y2;
+    fp28_times_k<C>(kb, bx.at(i));
+    fp28_neg<C>(nb, kb);
     fp28_select<C>(y2, E::hi(i), b.at(i), nb);
     fp28_mul2<C>(o.at(i), a.at(i), b0.at(i), ax.at(i), y2);
   }
@@ -279,26 +298,66 @@ MLHIP_HD void lp28_mul(E& r, const E& a, const E& b) {
   o.set_vb(1);
   r = o;
 }
-// c0 = (a0 + a1)(a0 - a1), c1 = (2 a1) a0: one single product per lane; the operands have twice the weight of a
+// u^2 = -1: c0 = (a0 + a1)(a0 - a1), c1 = (2 a1) a0 -- one single product per lane; the operands have twice the weight of a.
+// u^2 = -k: c0 = (a0 + a1)(a0 - k a1) + (k - 1) a0 a1, c1 = 2 a0 a1 -- still one single product per lane (the c1 lane's
+// a0 a1 crosses to the c0 lane afterwards); both factors and the result are carry-propagated.
 template <class C, class E>
-MLHIP_HD void lp28_sqr(E& r, const E& a) {
-  static_assert(C::BETA == -1, "carry-free lane pairs: u^2 = -1 only");
-  E::require(4 * a.w() * a.w() <= 8, "fp2_sqr", a.w(), a.w());
-  E::require(4 * a.vb() * a.vb() <= LP28_MAXU, "fp2_sqr (value bound)", a.vb(), a.vb());
-  E ax, o;
-  lp28_partner<C>(ax, a);
-  for (int i = 0; i < E::LANES; i++) {
-    const bool hi = E::hi(i);
-    Fp28<C> t, d, x, y;
-    fp28_select<C>(t, hi, a.at(i), ax.at(i));
-    fp28_add<C>(x, a.at(i), t);  // a0 + a1 | 2 a1
-    fp28_sub<C>(d, a.at(i), ax.at(i));
-    fp28_select<C>(y, hi, ax.at(i), d);  // a0 - a1 | a0
-    fp28_mul<C>(o.at(i), x, y);
+MLHIP_HD void lp28_sqr(E& r, const E& a_in) {
+  constexpr int K = -C::BETA;
+  if constexpr (K == 1) {
+    const E& a = a_in;
+    E::require(4 * a.w() * a.w() <= 8, "fp2_sqr", a.w(), a.w());
+    E::require(4 * a.vb() * a.vb() <= LP28_MAXU, "fp2_sqr (value bound)", a.vb(), a.vb());
+    E ax, o;
+    lp28_partner<C>(ax, a);
+    for (int i = 0; i < E::LANES; i++) {
+      const bool hi = E::hi(i);
+      Fp28<C> t, d, x, y;
+      fp28_select<C>(t, hi, a.at(i), ax.at(i));
+      fp28_add<C>(x, a.at(i), t);  // a0 + a1 | 2 a1
+      fp28_sub<C>(d, a.at(i), ax.at(i));
+      fp28_select<C>(y, hi, ax.at(i), d);  // a0 - a1 | a0
+      fp28_mul<C>(o.at(i), x, y);
+    }
+    o.set_w(1);
+    o.set_vb(1);
+    r = o;
+  } else {
+    E a = a_in;
+    E::require(a.w() <= LP28_MAXW, "fp2_sqr", a.w(), a.w());
+    lp28_reduce<C>(a);  // (a0 + a1)(a0 - k a1): 2 (1 + k) vb^2 -- the operand is brought below p, not just carry-propagated
+    E::require(2 * (1 + K) * a.vb() * a.vb() <= LP28_MAXU, "fp2_sqr (value bound)", a.vb(), a.vb());
+    E ax, o, ox;
+    lp28_partner<C>(ax, a);
+    for (int i = 0; i < E::LANES; i++) {
+      const bool hi = E::hi(i);
+      Fp28<C> kp, s, d, x, y;
+      fp28_times_k<C>(kp, ax.at(i));
+      fp28_add<C>(s, a.at(i), ax.at(i));  // a0 + a1 (c0 lane)
+      fp28_sub<C>(d, a.at(i), kp);        // a0 - k a1 (c0 lane)
+      fp28_normalize<C>(s, s);
+      fp28_normalize<C>(d, d);
+      fp28_select<C>(x, hi, a.at(i), s);   // a0 + a1 | a1
+      fp28_select<C>(y, hi, ax.at(i), d);  // a0 - k a1 | a0
+      fp28_mul<C>(o.at(i), x, y);          // t | a0 a1
+    }
+    o.set_w(1);
+    o.set_vb(1);
+    lp28_partner<C>(ox, o);
+    for (int i = 0; i < E::LANES; i++) {
+      const bool hi = E::hi(i);
+      Fp28<C> v4, c0, c1;
+#pragma unroll
+      for (int j = 0; j < C::N28; j++) v4.l[j] = ox.at(i).l[j] * (K - 1);  // (k - 1) a0 a1 on the c0 lane
+      fp28_add<C>(c0, o.at(i), v4);
+      fp28_add<C>(c1, o.at(i), o.at(i));
+      fp28_select<C>(o.at(i), hi, c1, c0);
+      fp28_reduce<C>(o.at(i), o.at(i));  // |c0| <= t + (k - 1) |a0 a1|, k products: back below p like every other product
+    }
+    o.set_w(1);
+    o.set_vb(1);
+    r = o;
   }
-  o.set_w(1);
-  o.set_vb(1);
-  r = o;
 }
 // a * k, k in Fp (normalized carry-free form)
 template <class C, class E>
@@ -309,21 +368,40 @@ MLHIP_HD void lp28_mul_fp(E& r, const E& a, const Fp28<C>& k) {
   r.set_w(1);
   r.set_vb(1);
 }
-// xi a, xi = 1 + u: c0 = a0 - a1, c1 = a0 + a1
+// xi a.  xi = 1 + u, u^2 = -1 (BLS12-381): c0 = a0 - a1, c1 = a0 + a1.  xi = u, u^2 = -k (BLS12-377): c0 = -k a1, c1 = a0
 template <class C, class E>
 MLHIP_HD void lp28_mul_xi(E& r, const E& a) {
-  static_assert(C::XI0 == 1 && C::XI1 == 1 && C::BETA == -1, "carry-free lane pairs: xi = 1 + u only");
-  E::require(2 * a.w() <= LP28_MAXW, "fp2_mul_xi", a.w(), 0);
+  constexpr int K = -C::BETA;
+  static_assert((C::XI0 == 1 && C::XI1 == 1 && K == 1) || (C::XI0 == 0 && C::XI1 == 1), "carry-free lane pairs: xi = 1 + u (u^2 = -1) or xi = u");
   E ax, o;
-  lp28_partner<C>(ax, a);
-  for (int i = 0; i < E::LANES; i++) {
-    Fp28<C> n, t;
-    fp28_neg<C>(n, ax.at(i));
-    fp28_select<C>(t, E::hi(i), ax.at(i), n);
-    fp28_add<C>(o.at(i), a.at(i), t);
+  if constexpr (C::XI0 == 1) {
+    lp28_partner<C>(ax, a);
+    E::require(2 * a.w() <= LP28_MAXW, "fp2_mul_xi", a.w(), 0);
+    for (int i = 0; i < E::LANES; i++) {
+      Fp28<C> n, t;
+      fp28_neg<C>(n, ax.at(i));
+      fp28_select<C>(t, E::hi(i), ax.at(i), n);
+      fp28_add<C>(o.at(i), a.at(i), t);
+    }
+    o.set_w(2 * a.w());
+    o.set_vb(2 * a.vb());
+  } else {
+    E an = a;  // the c0 lane's -k a1 multiplies the weight by k: carry-propagated first, whatever it was
+    E::require(an.w() <= LP28_MAXW, "fp2_mul_xi", an.w(), 0);
+    lp28_norm<C>(an);
+    lp28_partner<C>(ax, an);
+    for (int i = 0; i < E::LANES; i++) {
+      Fp28<C> kp, n;
+      fp28_times_k<C>(kp, ax.at(i));
+      fp28_neg<C>(n, kp);
+      fp28_select<C>(o.at(i), E::hi(i), ax.at(i), n);
+    }
+    o.set_w(K);
+    o.set_vb(K * an.vb());
+    // ... and reduced mod p afterwards: xi-multiples are added to products all over the towers, and a k-fold value bound
+    // would run their sums out of the product budget (sum vb_x vb_y <= 280 with the factor 1 + k on the c0 lane)
+    lp28_reduce<C>(o);
   }
-  o.set_w(2 * a.w());
-  o.set_vb(2 * a.vb());
   r = o;
 }
 // both components congruent to 0 mod p (exact, any weight <= 8)
@@ -354,9 +432,10 @@ MLHIP_HD void lp28_mul_by_real_const(E& r, const E& a, const uint32_t (&k)[2][C:
   fp28_from_fp<C>(k28, kr);
   lp28_mul_fp<C>(r, a, k28);
 }
-// 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2): the norm goes through the boundary form for the divsteps inversion
+// 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + k a1^2), u^2 = -k: the norm goes through the boundary form for the divsteps inversion
 template <class C, class E>
 MLHIP_HD void lp28_inv(E& r, const E& a) {
+  constexpr int K = -C::BETA;
   E::require(a.w() * a.w() <= 8, "fp2_inv", a.w(), a.w());
   E::require(a.vb() * a.vb() <= LP28_MAXU, "fp2_inv (value bound)", a.vb(), a.vb());
   E sq, sqx, o;
@@ -365,8 +444,12 @@ MLHIP_HD void lp28_inv(E& r, const E& a) {
   sq.set_vb(1);
   lp28_partner<C>(sqx, sq);
   for (int i = 0; i < E::LANES; i++) {
-    Fp28<C> n, ni28, t, nt;
-    fp28_add<C>(n, sq.at(i), sqx.at(i));  // a0^2 + a1^2 on both lanes
+    Fp28<C> n, ni28, t, nt, k0, k1, im;
+    fp28_times_k<C>(k0, sq.at(i));
+    fp28_times_k<C>(k1, sqx.at(i));
+    fp28_select<C>(im, E::hi(i), k0, k1);                         // k a1^2 on both lanes
+    fp28_select<C>(n, E::hi(i), sqx.at(i), sq.at(i));             // a0^2 on both lanes
+    fp28_add<C>(n, n, im);                                        // a0^2 + k a1^2, weight 1 + k
     Fp<C> n32, ni32;
     fp28_to_fp<C>(n32, n);
     fp_inv<C>(ni32, n32);

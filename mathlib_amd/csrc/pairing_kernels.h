@@ -173,7 +173,7 @@ template <class C>
 __device__ __forceinline__ void miller_loop_lp28_lds(Fp12<C, Fp2L28<C>>& f, const Fp28<C>& px, const Fp28<C>& py,
                                                      const Fp2L28<C>& qx, const Fp2L28<C>& qy, bool live,
                                                      const MillerLds<C>& lds) {
-  static_assert(!C::IS_BN && C::MTWIST, "BLS12 loop with the M-twist line (BLS12-381)");
+  static_assert(!C::IS_BN, "BLS12 loop (M-twist line: BLS12-381, D-twist line: BLS12-377)");
   typedef Fp2L28<C> E2;
   fp12_one<C>(f);
   if (!live) return;
@@ -211,10 +211,17 @@ __device__ __forceinline__ void miller_loop_lp28_lds(Fp12<C, Fp2L28<C>>& f, cons
       fp2_mul_fp<C>(a, l.r0, y);
       fp2_mul_fp<C>(b, l.r1, x);
       fp2_norm<C>(c);
-      if (first)
-        fp12_mul_by_014<C>(f, c, b, a);
-      else
-        fp12_sqr_mul_by_014<C>(f, c, b, a);
+      if constexpr (C::MTWIST) {
+        if (first)
+          fp12_mul_by_014<C>(f, c, b, a);
+        else
+          fp12_sqr_mul_by_014<C>(f, c, b, a);
+      } else {
+        if (first)
+          fp12_mul_by_034<C>(f, a, b, c);
+        else
+          fp12_sqr_mul_by_034<C>(f, a, b, c);
+      }
       first = false;
     }
     if (bit) {
@@ -354,10 +361,11 @@ __global__ void __launch_bounds__(256) k_fp_mul(const Fp<C>* __restrict__ a, con
   out[i] = r;
 }
 
-// carry-free lane pairs: BLS12-381 unless MLHIP_PAIRING_SAT=1 (read per batch so a test can switch paths)
+// carry-free lane pairs: BLS12-381 and BLS12-377 (u^2 = -5: fp2_lanes28.h carry-propagates every product operand first)
+// unless MLHIP_PAIRING_SAT=1 (read per batch so a test can switch paths)
 template <class C>
 bool lp28_enabled() {
-  if (C::ID != 1) return false;
+  if (C::ID != 1 && C::ID != 2) return false;
   const char* e = getenv("MLHIP_PAIRING_SAT");
   return !(e && e[0] == '1');
 }
@@ -411,6 +419,8 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
         HIPCHK(hipGetLastError());
         return 0;
       }
+    }
+    if constexpr (C::ID == 1 || C::ID == 2) {
       switch (what) {
         case 0:
           if (ppp == 1)
@@ -628,6 +638,9 @@ int gt_exp_device(const void* d_in, const void* d_scalars, int mont, size_t n, v
       else
         k_gt_exp_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in,
                                                                                 (const uint32_t*)d_scalars, mont, n, (Fp12<C>*)d_out);
+    } else if constexpr (C::ID == 2) {
+      k_gt_exp_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,
+                                                                              mont, n, (Fp12<C>*)d_out);
     }
   } else
     k_gt_exp_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,

@@ -477,6 +477,10 @@ MLHIP_HD_NOINLINE void fp12_inv(Fp12<C, E2>& r, const Fp12<C, E2>& a) {
   fp6_mul<C>(r.c0, a.c0, t0);
   fp6_mul<C>(t1, a.c1, t0);
   fp6_neg<C>(r.c1, t1);
+  if constexpr (C::BETA != -1) {  // u^2 = -5: the c0 lane's products weigh 1 + 5, so un-reduced Fp6 products may not travel on
+    fp6_reduce<C>(r.c0);
+    fp6_reduce<C>(r.c1);
+  }
 }
 
 // Frobenius f -> f^(p^K), K = 1, 2, 3.  Coefficient of w^i gets multiplied by GAMMAK[i]

@@ -575,8 +575,9 @@ struct Ops {
 
 // ---- the carry-free lane-pair element (fp2_lanes28.h) through its host model Fp2H28: same tower / pairing templates
 // as the kernels, every operation checking its weight budget (aborts with a message when one is exceeded)
-struct Lp28 {
-  typedef Bls381 C;
+template <class CC>
+struct Lp28T {
+  typedef CC C;
   typedef Fp2H28<C> E;
   typedef Fp12<C, E> F12h;
   static void to_h(E& r, const Fp2<C>& a) {
@@ -673,6 +674,8 @@ struct Lp28 {
     return max_w(f);
   }
 };
+
+typedef Lp28T<Bls381> Lp28;
 
 // the quad-lane pairing (pairing_quad.h) through its host model Fp2Q28H: pair A / pair B of a quad
 struct Q28 {
@@ -828,6 +831,17 @@ int hm_g2_decode(int curve, const uint8_t* w, int compressed, int subgroup, void
 int hm_g2_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g2enc(pt, compressed, w)) }
 int hm_lp28_fp12_op(int op, const void* a, const void* b, void* out) { return Lp28::fp12_op(op, a, b, out); }
 int hm_lp28_pairing(const void* g1s, const void* g2s, int n_pairs, int with_fexp, void* out) { return Lp28::pairing(g1s, g2s, n_pairs, with_fexp, out); }
+// the same for a curve id: BLS12-381 (1) or BLS12-377 (2: u^2 = -5, xi = u, D-twist)
+int hm_lp28c_fp12_op(int curve, int op, const void* a, const void* b, void* out) {
+  if (curve == 1) return Lp28T<Bls381>::fp12_op(op, a, b, out);
+  if (curve == 2) return Lp28T<Bls377>::fp12_op(op, a, b, out);
+  return -2;
+}
+int hm_lp28c_pairing(int curve, const void* g1s, const void* g2s, int n_pairs, int with_fexp, void* out) {
+  if (curve == 1) return Lp28T<Bls381>::pairing(g1s, g2s, n_pairs, with_fexp, out);
+  if (curve == 2) return Lp28T<Bls377>::pairing(g1s, g2s, n_pairs, with_fexp, out);
+  return -2;
+}
 int hm_q28_fp12_op(int op, const void* a, const void* b, void* out) { return Q28::fp12_op(op, a, b, out); }
 int hm_q28_pairing(const void* g1, const void* g2, int n_pairs, int with_fexp, void* out) { return Q28::pairing(g1, g2, n_pairs, with_fexp, out); }
 int hm_fp28_reduce(int curve, const int32_t* in, int32_t* out) {
