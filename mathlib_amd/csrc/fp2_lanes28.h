@@ -372,9 +372,33 @@ MLHIP_HD void lp28_mul_fp(E& r, const E& a, const Fp28<C>& k) {
 template <class C, class E>
 MLHIP_HD void lp28_mul_xi(E& r, const E& a) {
   constexpr int K = -C::BETA;
-  static_assert((C::XI0 == 1 && C::XI1 == 1 && K == 1) || (C::XI0 == 0 && C::XI1 == 1), "carry-free lane pairs: xi = 1 + u (u^2 = -1) or xi = u");
+  static_assert((C::XI0 >= 1 && C::XI1 == 1 && K == 1) || (C::XI0 == 0 && C::XI1 == 1),
+                "carry-free lane pairs: xi = m + u (u^2 = -1) or xi = u");
   E ax, o;
-  if constexpr (C::XI0 == 1) {
+  if constexpr (C::XI0 > 1) {
+    // xi = m + u (BN254: m = 9): c0 = m a0 - a1, c1 = m a1 + a0 -- multiplied and carry-propagated in one pass (64-bit
+    // intermediates), then reduced mod p like the other xi-multiples
+    E an = a;
+    E::require(an.w() <= LP28_MAXW, "fp2_mul_xi", an.w(), 0);
+    lp28_norm<C>(an);
+    lp28_partner<C>(ax, an);
+    for (int i = 0; i < E::LANES; i++) {
+      Fp28<C> n, t;
+      fp28_neg<C>(n, ax.at(i));
+      fp28_select<C>(t, E::hi(i), ax.at(i), n);
+      int64_t c = 0;
+#pragma unroll
+      for (int j = 0; j < C::N28 - 1; j++) {
+        const int64_t v = (int64_t)an.at(i).l[j] * C::XI0 + t.l[j] + c;
+        o.at(i).l[j] = (int32_t)((uint32_t)v & MASK28);
+        c = v >> 28;
+      }
+      o.at(i).l[C::N28 - 1] = (int32_t)((int64_t)an.at(i).l[C::N28 - 1] * C::XI0 + t.l[C::N28 - 1] + c);
+    }
+    o.set_w(1);
+    o.set_vb((C::XI0 + 1) * an.vb());
+    lp28_reduce<C>(o);
+  } else if constexpr (C::XI0 == 1) {
     lp28_partner<C>(ax, a);
     E::require(2 * a.w() <= LP28_MAXW, "fp2_mul_xi", a.w(), 0);
     for (int i = 0; i < E::LANES; i++) {

@@ -173,7 +173,7 @@ template <class C>
 __device__ __forceinline__ void miller_loop_lp28_lds(Fp12<C, Fp2L28<C>>& f, const Fp28<C>& px, const Fp28<C>& py,
                                                      const Fp2L28<C>& qx, const Fp2L28<C>& qy, bool live,
                                                      const MillerLds<C>& lds) {
-  static_assert(!C::IS_BN, "BLS12 loop (M-twist line: BLS12-381, D-twist line: BLS12-377)");
+  // (M-twist line: BLS12-381; D-twist line: BLS12-377, BN254 -- the latter with its two Frobenius lines after the loop)
   typedef Fp2L28<C> E2;
   fp12_one<C>(f);
   if (!live) return;
@@ -240,6 +240,31 @@ __device__ __forceinline__ void miller_loop_lp28_lds(Fp12<C, Fp2L28<C>>& f, cons
       mul_by_line<C>(f, l, x, y);
     }
   }
+  if constexpr (C::IS_BN) {
+    // lines through pi(Q) and -pi^2(Q) (miller_loop_core's tail)
+    E2 x1, y1, x2, y2, g;
+    fp2_conj<C>(x1, qx);
+    fp2_from_const<C>(g, C::GAMMA1[2]);
+    fp2_mul<C>(x1, x1, g);
+    fp2_conj<C>(y1, qy);
+    fp2_from_const<C>(g, C::GAMMA1[3]);
+    fp2_mul<C>(y1, y1, g);
+    fp2_mul_by_real_const<C>(x2, qx, C::GAMMA2[2]);
+    fp2_mul_by_real_const<C>(y2, qy, C::GAMMA2[3]);
+    fp2_neg<C>(y2, y2);
+    G2Proj<C, E2> T;
+    Line<C, E2> l;
+    lds.get(T.x.v, 0);
+    lds.get(T.y.v, 1);
+    lds.get(T.z.v, 2);
+    Fp28<C> x, y;
+    lds.get(x, 3);
+    lds.get(y, 4);
+    g2_add_step<C>(T, x1, y1, l);
+    mul_by_line<C>(f, l, x, y);
+    g2_add_step<C>(T, x2, y2, l);
+    mul_by_line<C>(f, l, x, y);
+  }
   if (C::X_NEG) fp12_conj<C>(f, f);
 }
 
@@ -273,7 +298,7 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_pairing_lp28(const Affine<F
       fp28_from_fp<C>(qx[k].v, qxc);
       fp28_from_fp<C>(qy[k].v, qyc);
     }
-    if constexpr (MAXP == 1 && !C::IS_BN) {
+    if constexpr (MAXP == 1) {
       __shared__ int32_t t_slots[64 * MillerLds<C>::STRIDE];
       const MillerLds<C> lds{t_slots + threadIdx.x * MillerLds<C>::STRIDE};
       miller_loop_lp28_lds<C>(f, px[0], py[0], qx[0], qy[0], live[0], lds);
@@ -361,11 +386,11 @@ __global__ void __launch_bounds__(256) k_fp_mul(const Fp<C>* __restrict__ a, con
   out[i] = r;
 }
 
-// carry-free lane pairs: BLS12-381 and BLS12-377 (u^2 = -5: fp2_lanes28.h carry-propagates every product operand first)
-// unless MLHIP_PAIRING_SAT=1 (read per batch so a test can switch paths)
+// carry-free lane pairs on every curve (BLS12-377's u^2 = -5: fp2_lanes28.h carry-propagates every product operand first;
+// BN254: 10 limbs, xi = 9 + u) unless MLHIP_PAIRING_SAT=1 (read per batch so a test can switch paths)
 template <class C>
 bool lp28_enabled() {
-  if (C::ID != 1 && C::ID != 2) return false;
+  (void)C::ID;  // all three curves
   const char* e = getenv("MLHIP_PAIRING_SAT");
   return !(e && e[0] == '1');
 }
@@ -393,8 +418,10 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
         k_pairing<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, (Fp12<C>*)d_out);
         break;
     }
-  } else if (lp28_enabled<C>()) {
-    // BLS12-381: lane pairs in the carry-free form (MLHIP_PAIRING_SAT=1 selects the saturated lane-pair kernels below)
+  } else if (lp28_enabled<C>() && !(C::IS_BN && what == 0)) {
+    // lane pairs in the carry-free form (MLHIP_PAIRING_SAT=1 selects the saturated lane-pair kernels below; BN254's Miller
+    // loop alone stays on them: 7.3 against 7.45 ms per 65 536 -- its 10-limb products gain nothing, the final exponentiation's
+    // additions and squarings do: 8.6 -> 7.3 ms, the fused pairing 15.9 -> 14.1 ms)
     unsigned blocks = (unsigned)((2 * n + 63) / 64);
     if constexpr (C::ID == 1) {
       // One pairing per QUAD of lanes (pairing_quad.h) while the batch leaves the chip under-filled: up to 2^14 elements
@@ -420,7 +447,7 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
         return 0;
       }
     }
-    if constexpr (C::ID == 1 || C::ID == 2) {
+    {
       switch (what) {
         case 0:
           if (ppp == 1)
@@ -638,7 +665,7 @@ int gt_exp_device(const void* d_in, const void* d_scalars, int mont, size_t n, v
       else
         k_gt_exp_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in,
                                                                                 (const uint32_t*)d_scalars, mont, n, (Fp12<C>*)d_out);
-    } else if constexpr (C::ID == 2) {
+    } else {
       k_gt_exp_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,
                                                                               mont, n, (Fp12<C>*)d_out);
     }

@@ -835,11 +835,13 @@ int hm_lp28_pairing(const void* g1s, const void* g2s, int n_pairs, int with_fexp
 int hm_lp28c_fp12_op(int curve, int op, const void* a, const void* b, void* out) {
   if (curve == 1) return Lp28T<Bls381>::fp12_op(op, a, b, out);
   if (curve == 2) return Lp28T<Bls377>::fp12_op(op, a, b, out);
+  if (curve == 0) return Lp28T<Bn254>::fp12_op(op, a, b, out);
   return -2;
 }
 int hm_lp28c_pairing(int curve, const void* g1s, const void* g2s, int n_pairs, int with_fexp, void* out) {
   if (curve == 1) return Lp28T<Bls381>::pairing(g1s, g2s, n_pairs, with_fexp, out);
   if (curve == 2) return Lp28T<Bls377>::pairing(g1s, g2s, n_pairs, with_fexp, out);
+  if (curve == 0) return Lp28T<Bn254>::pairing(g1s, g2s, n_pairs, with_fexp, out);
   return -2;
 }
 int hm_q28_fp12_op(int op, const void* a, const void* b, void* out) { return Q28::fp12_op(op, a, b, out); }

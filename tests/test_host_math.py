@@ -718,29 +718,32 @@ def test_fp28_reduce_range(hostmath):
         assert all(0 <= int(out[i]) < (1 << 28) for i in range(13))
 
 
-def test_lp28_bls12_377_tower_and_pairing(hostmath):
-    """The carry-free lane-pair element on BLS12-377 (u^2 = -5, xi = u, D-twist): every Fp12-level operation, the compressed
-    squaring chains, the final exponentiation and whole pairings (one pair, two pairs, Miller loop alone, infinity) through
-    the host model -- which aborts on any weight or value-bound violation -- against the oracle.  With u^2 = -5 the c0 lane's
-    dual product weighs (1 + 5) w_a w_b: fp2_mul carry-propagates both operands, fp2_sqr is the two-term form."""
-    cp = R.CURVES["BLS12-377"]
+@pytest.mark.parametrize("name", ["BLS12-377", "BN254"])
+def test_lp28_other_curves_tower_and_pairing(hostmath, name):
+    """The carry-free lane-pair element on BLS12-377 (u^2 = -5, xi = u, D-twist) and BN254 (10 limbs, xi = 9 + u, the BN
+    loop and final exponentiation): every Fp12-level operation, the compressed squaring chains, the final exponentiation and
+    whole pairings (one pair, two pairs, Miller loop alone, infinity) through the host model -- which aborts on any weight or
+    value-bound violation -- against the oracle.  With u^2 = -5 the c0 lane's dual product weighs (1 + 5) w_a w_b: fp2_mul
+    carry-propagates both operands, fp2_sqr is the two-term form."""
+    cp = R.CURVES[name]
     T = R.tower(cp)
     L, cid = hostmath, cp.curve_id
-    d = R.Drbg("hm/lp28/377")
+    d = R.Drbg("hm/lp28/" + name)
     rf = lambda: tuple((d.below(cp.p), d.below(cp.p)) for _ in range(6))  # noqa: E731
     gb = lambda f: R.gt_to_mont_bytes(cp, f)  # noqa: E731
-    out = ctypes.create_string_buffer(576)
+    nb, g1n, g2n = 12 * cp.fp_bytes, 2 * cp.fp_bytes, 4 * cp.fp_bytes
+    out = ctypes.create_string_buffer(nb)
     f, g = rf(), rf()
     c = T.f12_mul(T.f12_conj(f), T.f12_inv(f))
     c = T.f12_mul(T.f12_frob(c, 2), c)  # cyclotomic subgroup element
     cases = [(0, f, T.f12_mul(f, g)), (1, f, T.f12_sqr(f)), (10, f, T.f12_mul(f, g)), (11, f, T.f12_sqr(f)), (2, f, T.f12_inv(f)),
              (3, f, T.f12_frob(f, 1)), (4, f, T.f12_frob(f, 2)), (5, f, T.f12_frob(f, 3)), (7, f, T.f12_conj(f)),
-             (6, c, T.f12_sqr(c)), (8, c, T.f12_pow(c, cp.x)), (9, f, R.final_exp(cp, f))]
+             (6, c, T.f12_sqr(c)), (8, c, T.f12_pow(c, abs(cp.x))), (9, f, R.final_exp(cp, f))]
     for op, a, exp in cases:
         assert L.hm_lp28c_fp12_op(cid, op, gb(a), gb(g), out) == 1, op
         assert R.gt_from_mont_bytes(cp, out.raw) == exp, op
     for n in (1, 2, 17, 63):  # chains of compressed cyclotomic squarings
-        assert L.hm_lp28c_fp12_op(cid, 12, gb(c), bytes([n]) + bytes(575), out) == 1
+        assert L.hm_lp28c_fp12_op(cid, 12, gb(c), bytes([n]) + bytes(nb - 1), out) == 1
         exp = c
         for _ in range(n):
             exp = T.f12_sqr(exp)
@@ -756,9 +759,9 @@ def test_lp28_bls12_377_tower_and_pairing(hostmath):
     assert L.hm_lp28c_pairing(cid, g1, g2, 1, 0, out) == 1
     assert R.final_exp(cp, R.gt_from_mont_bytes(cp, out.raw)) == R.pairing(cp, P, Q)
     one = tuple([(1, 0)] + [(0, 0)] * 5)
-    assert L.hm_lp28c_pairing(cid, bytes(96), R.g2_to_mont_bytes(cp, Q), 1, 1, out) == 1
+    assert L.hm_lp28c_pairing(cid, bytes(g1n), R.g2_to_mont_bytes(cp, Q), 1, 1, out) == 1
     assert R.gt_from_mont_bytes(cp, out.raw) == one
-    assert L.hm_lp28c_pairing(cid, R.g1_to_mont_bytes(cp, P), bytes(192), 1, 1, out) == 1
+    assert L.hm_lp28c_pairing(cid, R.g1_to_mont_bytes(cp, P), bytes(g2n), 1, 1, out) == 1
     assert R.gt_from_mont_bytes(cp, out.raw) == one
 
 
