@@ -1,5 +1,5 @@
 // fp2_lanes28.h -- Fp2 elements over lane pairs in the CARRY-FREE form (fp28.h): the element type of the batched
-// pairing kernels for BLS12-381 (pairing_kernels.h: k_pairing_lp28).
+// pairing kernels (pairing_kernels.h: k_pairing_lp28; BLS12-381 first, BLS12-377 and BN254 since round 3).
 //
 // Same layout as fp2_lanes.h -- lane 2i owns c0 and lane 2i+1 owns c1 of every Fp2 value, one pairing per lane pair --
 // but each component is an Fp28 (14 signed 28-bit limbs, Montgomery R28 = 2^392) instead of 12 saturated 32-bit limbs:
@@ -20,8 +20,8 @@
 // The weights do not depend on the data (the formulas are straight-line), so the budget is verified once and for all on
 // the CPU: Fp2H28 below is the host model of one lane pair (both components + the weight), every operation checks its
 // precondition, and tests/test_host_math.py runs the whole pairing through it against the oracle.
-// u^2 = -1 with xi = 1 + u (BLS12-381) and u^2 = -5 with xi = u (BLS12-377: every product operand carry-propagated first, see
-// lp28_mul) are implemented; BN254's 10-limb form gains nothing on the multiplier and stays on fp2_lanes.h.
+// u^2 = -1 with xi = m + u (BLS12-381: m = 1; BN254: m = 9, 10 limbs) and u^2 = -5 with xi = u (BLS12-377: every product operand
+// carry-propagated first, see lp28_mul) are implemented.
 #pragma once
 #include "fp28.h"
 #include "fp2_lanes.h"
