@@ -535,6 +535,27 @@ def main() -> None:
                 "bound": "hbm", "achieved": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
             }
+            # the north star names BN254 beside BLS12-381: the same batch on that curve (P_i = [k_i]G1, Q_i = [k_i]G2 made on the
+            # device), rank 0 only, never part of `value`
+            if rank == 0:
+                bn = _lib.CURVE_BN254
+                _, bg1, bg2, bgt = _lib.sizes(bn)
+                with open(os.path.join(ROOT, "tests", "golden", "bn254.json")) as fbn:
+                    gbn = json.load(fbn)
+                bp, bq = torch.empty(npair * bg1, dtype=torch.uint8, device=dev), torch.empty(npair * bg2, dtype=torch.uint8, device=dev)
+                for grp, key, dst in ((G1, "g1_gen", bp), (G2, "g2_gen", bq)):
+                    base = torch.frombuffer(bytearray(bytes.fromhex(gbn[key])), dtype=torch.uint8).to(dev)
+                    _lib.check(lib.mlhip_scalar_mul_device(bn, grp, base.data_ptr(), 0, scalars[:npair].contiguous().data_ptr(), 0, npair, dst.data_ptr(), stream))
+                bgt_out = torch.empty(npair * bgt, dtype=torch.uint8, device=dev)
+                tb = []
+                for _ in range(4):
+                    ev0.record()
+                    _lib.check(lib.mlhip_pairing_batch_device(bn, bp.data_ptr(), bq.data_ptr(), npair, bgt_out.data_ptr(), stream))
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    tb.append(ev0.elapsed_time(ev1))
+                extra["pairings_per_s_bn254"] = npair / (statistics.median(tb[1:]) * 1e-3)
+                del bp, bq, bgt_out
 
     steps_n = max(args.steps, 1)
     value = units_per_step * args.steps / elapsed
