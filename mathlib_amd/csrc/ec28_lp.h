@@ -1,11 +1,12 @@
 // ec28_lp.h -- G2 bucket accumulation in the carry-free form (fp28.h) over lane pairs.
 //
 // Same idea as ec28.h for G1, combined with the lane-pair layout of fp2_lanes.h: lane 2i holds the real part
-// and lane 2i+1 the imaginary part of every Fp2 coordinate, each as an Fp28.  Only curves with u^2 = -1
-// (BN254, BLS12-381) take this path: there an Fp2 product is ONE fused dual product per lane,
-//     c0 = a0 b0 + (-a1) b1        c1 = a1 b0 + a0 b1
-// (for u^2 = -5 the factor 5 would exceed the weight budget of a column; BLS12-377 G2 keeps the boundary form),
-// and an Fp2 square is one single product per lane: c0 = (a0 + a1)(a0 - a1), c1 = (2 a1) a0.
+// and lane 2i+1 the imaginary part of every Fp2 coordinate, each as an Fp28.  An Fp2 product is ONE fused dual
+// product per lane,
+//     c0 = a0 b0 + (-k a1) b1        c1 = a1 b0 + a0 b1        (u^2 = -k)
+// and an Fp2 square is one single product per lane: c0 = (a0 + a1)(a0 - a1), c1 = (2 a1) a0 for k = 1.  For k = 5
+// (BLS12-377, round 3) the c0 lane's product weighs (1 + 5) w_a w_b: every product operand is normalized, the differences
+// that feed products are reduced mod p rather than carry-propagated (lp28_settle), and the square is the two-term form.
 // Weight rules (fp28.h): a dual product needs w_a w_b <= 4, the single-product square needs w_a = 1 -- so P and
 // R are carry-propagated right after the subtraction, X3 and Y3 before they are stored: four propagations and
 // 8 dual + 2 single products per mixed addition.  (Fusing Y3 = R (Q - X3) - Y1 PPP into one four-product reduction
@@ -111,7 +112,7 @@ struct PairDevice {
 #endif
 
 // lane-wise helpers over a backend value
-#define MLHIP_LP28_EACH(B, body) B::each([&](int li_) { body; })
+#define MLHIP_LP28_EACH(B, ...) B::each([&](int li_) { __VA_ARGS__; })
 
 template <class C, class B>
 MLHIP_HD void lp28_sub(typename B::V& r, const typename B::V& a, const typename B::V& b) {
@@ -144,30 +145,77 @@ MLHIP_HD bool lp28_is_zero_exact(const typename B::V& a) {
   return B::both(z);
 }
 
-// r = a b in Fp2 (u^2 = -1): one dual product per lane; needs w_a w_b <= 4
+// k x for k = -BETA (u^2 = BETA): 1, or 5 for BLS12-377
+template <class C>
+MLHIP_HD void fp28_times_beta_k(Fp28<C>& r, const Fp28<C>& a) {
+  constexpr int K = -C::BETA;
+  static_assert(K == 1 || K == 5, "u^2 = -1 or -5");
+#pragma unroll
+  for (int i = 0; i < C::N28; i++) r.l[i] = K == 5 ? (int32_t)(((uint32_t)a.l[i] << 2) + (uint32_t)a.l[i]) : a.l[i];
+}
+template <class C, class B>
+MLHIP_HD void lp28_reduce_p(typename B::V& r, const typename B::V& a) {
+  MLHIP_LP28_EACH(B, fp28_reduce<C>(B::at(r, li_), B::at(a, li_)));
+}
+// the carry propagation of a difference that feeds products: u^2 = -1 keeps the value (fp28_normalize); u^2 = -5, whose c0
+// lane weighs a product (1 + 5)-fold, also brings it back below p (fp28_reduce: ~1.7 x the instructions)
+template <class C, class B>
+MLHIP_HD void lp28_settle(typename B::V& r, const typename B::V& a) {
+  if constexpr (C::BETA == -1)
+    lp28_normalize<C, B>(r, a);
+  else
+    lp28_reduce_p<C, B>(r, a);
+}
+
+// r = a b in Fp2 (u^2 = -k): one dual product per lane, c0 = a0 b0 + a1 (-k b1), c1 = a1 b0 + a0 b1.
+// k = 1 needs w_a w_b <= 4; k = 5 (BLS12-377) needs normalized operands with |values| such that 6 vb_a vb_b <= 280
 template <class C, class B>
 MLHIP_HD void lp28_mul(typename B::V& r, const typename B::V& a, const typename B::V& b) {
-  static_assert(C::BETA == -1, "lane-pair carry-free products assume u^2 = -1");
-  // both lanes: own a * b0 + partner's a * (+-b1): b0 by one broadcast, the sign of b1 by one negation and one select
-  typename B::V ax, bx, b0, nbx, y2;
+  // both lanes: own a * b0 + partner's a * (+-k b1): b0 by one broadcast, the sign of b1 by one negation and one select
+  typename B::V ax, bx, b0, kbx, nbx, y2;
   B::xchg(ax, a);
   B::xchg(bx, b);
   B::real_on_both(b0, b);
-  lp28_neg<C, B>(nbx, bx);
-  B::sel_hi(y2, b, nbx);  // c0: -b1 | c1: b1 (own)
+  MLHIP_LP28_EACH(B, fp28_times_beta_k<C>(B::at(kbx, li_), B::at(bx, li_)));
+  lp28_neg<C, B>(nbx, kbx);
+  B::sel_hi(y2, b, nbx);  // c0: -k b1 | c1: b1 (own)
   MLHIP_LP28_EACH(B, fp28_mul2<C>(B::at(r, li_), B::at(a, li_), B::at(b0, li_), B::at(ax, li_), B::at(y2, li_)));
 }
 
-// r = a^2, a normalized (weight 1): one single product per lane
+// r = a^2, a normalized (weight 1): one single product per lane.  u^2 = -1: c0 = (a0 + a1)(a0 - a1), c1 = (2 a1) a0.
+// u^2 = -k: c0 = (a0 + a1)(a0 - k a1) + (k - 1) a0 a1, c1 = 2 a0 a1 -- the c1 lane's a0 a1 crosses to the c0 lane afterwards;
+// `a` must be reduced (|value| < p), the result is reduced again.
 template <class C, class B>
 MLHIP_HD void lp28_sqr(typename B::V& r, const typename B::V& a) {
-  typename B::V ax, t, d, x, y;
-  B::xchg(ax, a);
-  B::sel_hi(t, a, ax);
-  MLHIP_LP28_EACH(B, fp28_add<C>(B::at(x, li_), B::at(a, li_), B::at(t, li_)));    // a0 + a1 | 2 a1
-  MLHIP_LP28_EACH(B, fp28_sub<C>(B::at(d, li_), B::at(a, li_), B::at(ax, li_)));   // c0 lane: a0 - a1
-  B::sel_hi(y, ax, d);
-  MLHIP_LP28_EACH(B, fp28_mul<C>(B::at(r, li_), B::at(x, li_), B::at(y, li_)));
+  constexpr int K = -C::BETA;
+  if constexpr (K == 1) {
+    typename B::V ax, t, d, x, y;
+    B::xchg(ax, a);
+    B::sel_hi(t, a, ax);
+    MLHIP_LP28_EACH(B, fp28_add<C>(B::at(x, li_), B::at(a, li_), B::at(t, li_)));    // a0 + a1 | 2 a1
+    MLHIP_LP28_EACH(B, fp28_sub<C>(B::at(d, li_), B::at(a, li_), B::at(ax, li_)));   // c0 lane: a0 - a1
+    B::sel_hi(y, ax, d);
+    MLHIP_LP28_EACH(B, fp28_mul<C>(B::at(r, li_), B::at(x, li_), B::at(y, li_)));
+  } else {
+    typename B::V ax, kax, s, d, x, y, o, ox, v4, c0, c1;
+    B::xchg(ax, a);
+    MLHIP_LP28_EACH(B, fp28_times_beta_k<C>(B::at(kax, li_), B::at(ax, li_)));
+    MLHIP_LP28_EACH(B, fp28_add<C>(B::at(s, li_), B::at(a, li_), B::at(ax, li_)));   // c0 lane: a0 + a1
+    MLHIP_LP28_EACH(B, fp28_sub<C>(B::at(d, li_), B::at(a, li_), B::at(kax, li_)));  // c0 lane: a0 - k a1
+    lp28_normalize<C, B>(s, s);
+    lp28_normalize<C, B>(d, d);
+    B::sel_hi(x, a, s);   // a0 + a1 | a1
+    B::sel_hi(y, ax, d);  // a0 - k a1 | a0
+    MLHIP_LP28_EACH(B, fp28_mul<C>(B::at(o, li_), B::at(x, li_), B::at(y, li_)));  // t | a0 a1
+    B::xchg(ox, o);
+    MLHIP_LP28_EACH(B, {
+      for (int j = 0; j < C::N28; j++) B::at(v4, li_).l[j] = B::at(ox, li_).l[j] * (K - 1);
+    });
+    MLHIP_LP28_EACH(B, fp28_add<C>(B::at(c0, li_), B::at(o, li_), B::at(v4, li_)));
+    MLHIP_LP28_EACH(B, fp28_add<C>(B::at(c1, li_), B::at(o, li_), B::at(o, li_)));
+    B::sel_hi(o, c1, c0);
+    lp28_reduce_p<C, B>(r, o);
+  }
 }
 
 template <class V>
@@ -241,9 +289,9 @@ MLHIP_HD void xyzz28_lp_madd(XYZZ28L<typename B::V>& acc, bool& inf, const Affin
   lp28_mul<C, B>(U2, q.x, acc.zz);
   lp28_mul<C, B>(S2, q.y, acc.zzz);
   lp28_sub<C, B>(t, U2, acc.x);
-  lp28_normalize<C, B>(P, t);
+  lp28_settle<C, B>(P, t);
   lp28_sub<C, B>(t, S2, acc.y);
-  lp28_normalize<C, B>(R, t);
+  lp28_settle<C, B>(R, t);
   if (lp28_is_zero_exact<C, B>(P)) {
     XYZZ28L<V> ta = acc;  // cold-path copies: keep the caller's accumulator in registers
     Affine28L<V> tq = q;
@@ -260,12 +308,13 @@ MLHIP_HD void xyzz28_lp_madd(XYZZ28L<typename B::V>& acc, bool& inf, const Affin
   lp28_sub<C, B>(t, t, PPP);
   lp28_sub<C, B>(t, t, Q);
   lp28_sub<C, B>(t, t, Q);
-  lp28_normalize<C, B>(X3, t);
+  lp28_settle<C, B>(X3, t);
   lp28_sub<C, B>(e, Q, X3);                      // weight 2
+  if constexpr (C::BETA != -1) lp28_normalize<C, B>(e, e);  // (the c0 lane's product leaves room for weight 1 only)
   lp28_mul<C, B>(Vv, R, e);            // 1 x 2
   lp28_mul<C, B>(T, acc.y, PPP);       // 1 x 1
   lp28_sub<C, B>(t, Vv, T);
-  lp28_normalize<C, B>(acc.y, t);
+  lp28_settle<C, B>(acc.y, t);
   acc.x = X3;
   lp28_mul<C, B>(t, acc.zz, PP);
   acc.zz = t;
@@ -324,9 +373,9 @@ MLHIP_HD void xyzz28_lp_add(XYZZ28L<typename B::V>& acc, bool& inf, const XYZZ28
   lp28_mul<C, B>(S1, acc.y, q.zzz);
   lp28_mul<C, B>(S2, q.y, acc.zzz);
   lp28_sub<C, B>(t, U2, U1);
-  lp28_normalize<C, B>(P, t);
+  lp28_settle<C, B>(P, t);
   lp28_sub<C, B>(t, S2, S1);
-  lp28_normalize<C, B>(R, t);
+  lp28_settle<C, B>(R, t);
   if (lp28_is_zero_exact<C, B>(P)) {
     XYZZ28L<V> ta = acc, tq = q;  // cold-path copies: keep the caller's values in registers
     bool ti = inf;
@@ -342,12 +391,13 @@ MLHIP_HD void xyzz28_lp_add(XYZZ28L<typename B::V>& acc, bool& inf, const XYZZ28
   lp28_sub<C, B>(t, t, PPP);
   lp28_sub<C, B>(t, t, Q);
   lp28_sub<C, B>(t, t, Q);
-  lp28_normalize<C, B>(X3, t);
+  lp28_settle<C, B>(X3, t);
   lp28_sub<C, B>(e, Q, X3);       // weight 2
+  if constexpr (C::BETA != -1) lp28_normalize<C, B>(e, e);
   lp28_mul<C, B>(Vv, R, e);       // 1 x 2
   lp28_mul<C, B>(T, S1, PPP);     // 1 x 1
   lp28_sub<C, B>(t, Vv, T);
-  lp28_normalize<C, B>(acc.y, t);
+  lp28_settle<C, B>(acc.y, t);
   acc.x = X3;
   lp28_mul<C, B>(t, acc.zz, q.zz);
   lp28_mul<C, B>(acc.zz, t, PP);

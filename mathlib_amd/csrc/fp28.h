@@ -81,6 +81,24 @@ MLHIP_HD void fp28_normalize(Fp28<C>& r, const Fp28<C>& a) {
   r.l[C::N28 - 1] = a.l[C::N28 - 1] + c;
 }
 
+// value -> value - round(value / p) p, carry-propagated: limbs normalized, |result| < 0.6 p.  The quotient comes from
+// the top limb (value / 2^364 up to the weight) in single precision: exact to well within +-0.01.
+template <class C>
+MLHIP_HD void fp28_reduce(Fp28<C>& r, const Fp28<C>& a) {
+  constexpr int L = C::N28;
+  constexpr float inv_ptop = 1.0f / ((float)C::P28[L - 1] + (float)C::P28[L - 2] * (1.0f / 268435456.0f));
+  const float qf = (float)a.l[L - 1] * inv_ptop;
+  const int32_t q = (int32_t)(qf + (qf >= 0.0f ? 0.5f : -0.5f));
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < L - 1; i++) {
+    const int64_t v = (int64_t)a.l[i] - (int64_t)q * C::P28[i] + c;
+    r.l[i] = (int32_t)((uint32_t)v & MASK28);
+    c = v >> 28;
+  }
+  r.l[L - 1] = (int32_t)((int64_t)a.l[L - 1] - (int64_t)q * C::P28[L - 1] + c);
+}
+
 // r = (a b + c d) / R28 mod p in one reduction; DUAL = false drops the second product.  SQR: b is ignored and
 // the product a a is formed from the N28 (N28+1)/2 distinct limb products.
 template <class C, bool DUAL, bool SQR>

@@ -122,24 +122,6 @@ inline bool lp28_both(const Fp2H28<C>&, const bool (&b)[2]) {
 constexpr int LP28_MAXW = 8;    // |limb| < w 2^28 must fit an int32
 constexpr int LP28_MAXU = 280;  // sum of vb_x vb_y over the products of one reduction: the result is then within 1.2 p
 
-// value -> value - round(value / p) p, carry-propagated: limbs normalized, |result| < 0.6 p.  The quotient comes from
-// the top limb (value / 2^364 up to the weight) in single precision: exact to well within +-0.01.
-template <class C>
-MLHIP_HD void fp28_reduce(Fp28<C>& r, const Fp28<C>& a) {
-  constexpr int L = C::N28;
-  constexpr float inv_ptop = 1.0f / ((float)C::P28[L - 1] + (float)C::P28[L - 2] * (1.0f / 268435456.0f));
-  const float qf = (float)a.l[L - 1] * inv_ptop;
-  const int32_t q = (int32_t)(qf + (qf >= 0.0f ? 0.5f : -0.5f));
-  int64_t c = 0;
-#pragma unroll
-  for (int i = 0; i < L - 1; i++) {
-    const int64_t v = (int64_t)a.l[i] - (int64_t)q * C::P28[i] + c;
-    r.l[i] = (int32_t)((uint32_t)v & MASK28);
-    c = v >> 28;
-  }
-  r.l[L - 1] = (int32_t)((int64_t)a.l[L - 1] - (int64_t)q * C::P28[L - 1] + c);
-}
-
 // ---- generic bodies over either element -------------------------------------------------------------------------
 template <class C, class E>
 MLHIP_HD void lp28_zero(E& r) {

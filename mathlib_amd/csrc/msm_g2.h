@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) k_accumulate_lp(const Affine<Fp2Field<C>>
   lp_store_xyzz<C>(buckets, g, acc, hi);
 }
 
-// ---- segmented G2 accumulation in the boundary form (curves without the carry-free G2 kernel: BN254, BLS12-377) -----
+// ---- segmented G2 accumulation in the boundary form (the curve without the carry-free G2 kernel: BN254) -----
 // Same scheme as k_accumulate28_lp_seg, but the kept state of a bucket is simply its boundary-form sum in `buckets`:
 // segment s > 0 starts from it and stores it back; nothing to convert at the end.
 template <class C>

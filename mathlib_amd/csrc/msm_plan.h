@@ -122,9 +122,10 @@ int plan_alloc(mlhip_msm_plan* p) {
     p->reduce28 = want28 && !p->reduce_one_lane && !(red32 && red32[0] == '1');
     if (p->reduce28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * sizeof(XYZZ28<typename F::Curve>)));
   }
-  if constexpr (std::is_same<F, Fp2Field<typename F::Curve>>::value && F::Curve::BETA == -1 && F::Curve::N28 == 14) {
-    // G2 in the carry-free form: BLS12-381 only (-14 % accumulation time); u^2 = -5 does not fit the weight budget
-    // (BLS12-377) and the 10-limb BN254 form gains nothing over its 8 saturated limbs on lane pairs
+  if constexpr (std::is_same<F, Fp2Field<typename F::Curve>>::value && F::Curve::N28 == 14) {
+    // G2 in the carry-free form: the 14-limb curves (BLS12-381: -14 % accumulation time; BLS12-377 since round 3, with the
+    // differences reduced instead of carry-propagated for u^2 = -5, ec28_lp.h); the 10-limb BN254 form gains nothing over
+    // its 8 saturated limbs on lane pairs
     const char* acc32 = getenv("MLHIP_ACC32");
     if (!(acc32 && acc32[0] == '1')) {
       HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(AffineG2_28<typename F::Curve>)));
@@ -312,7 +313,7 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
     size_t n_chunks = (size_t)p->W * p->T;
     if constexpr (kLanePairs) {
       bool done28 = false;
-      if constexpr (C::BETA == -1 && C::N28 == 14) {
+      if constexpr (C::N28 == 14) {
         if (p->reduce28) {
           typedef XYZZ28L<Fp28<C>> X28;
           k_chunks_lp28<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>(
@@ -380,7 +381,7 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
 template <class C, class F>
 int resident_tiles(const mlhip_msm_plan* p, size_t n) {
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
-  constexpr bool kBoundary = kG2 && !(C::BETA == -1 && C::N28 == 14);
+  constexpr bool kBoundary = kG2 && !(C::N28 == 14);
   if (!p->aux || (!kBoundary && !p->d_points28)) return 1;
   int lg = kG2 ? 20 : 21;
   size_t from = (size_t)1 << (kG2 ? 23 : 22);
@@ -448,7 +449,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
         p->upload_src = nullptr;
       }
       if constexpr (std::is_same<F, Fp2Field<C>>::value) {
-        if constexpr (C::BETA == -1)
+        if constexpr (C::N28 == 14)
           k_points_to28_g2<C><<<dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, p->aux>>>(
               (const A*)d_points, n, (AffineG2_28<C>*)p->d_points28);
       } else {
@@ -473,18 +474,23 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     constexpr bool kLanePairs = std::is_same<F, Fp2Field<C>>::value;  // G2: two lanes per bucket
     if constexpr (kLanePairs) {
       bool done28 = false;
-      if constexpr (C::BETA == -1) {
+      if constexpr (C::N28 == 14) {
         if (p->d_points28) {
           HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
           if constexpr (C::N28 == 14) {
             if (p->reduce28) {  // one segment that is first and last, leaving the raw accumulators for k_chunks_lp28
               const dim3 grid((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), block(p->acc_block);
-              if (g2_split_by_coordinate())
-                k_accumulate28_kc_seg<C><<<grid, block, 0, st>>>(
-                    (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
-                    big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28,
-                    MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
-              else
+              bool kc = false;
+              if constexpr (C::BETA == -1) {
+                if (g2_split_by_coordinate()) {
+                  k_accumulate28_kc_seg<C><<<grid, block, 0, st>>>(
+                      (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+                      big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28,
+                      MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
+                  kc = true;
+                }
+              }
+              if (!kc)
                 k_accumulate28_lp_seg<C><<<grid, block, 0, st>>>(
                     (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
                     big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28,
@@ -549,7 +555,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
               MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
           folded = true;
         }
-      } else if constexpr (C::BETA == -1 && C::N28 == 14) {
+      } else if constexpr (C::N28 == 14) {
         if (p->reduce28 && p->d_points28) {
           k_accumulate_big_seg_g2<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
               p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28L<Fp28<C>>*)p->d_state28,
@@ -602,7 +608,7 @@ template <class C, class F>
 int stream_begin(mlhip_msm_plan* p, StreamCtx& cx, hipStream_t st, int min_K) {
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
   // G2 on the curves without the carry-free lane-pair kernel keeps its bucket state in the boundary form
-  constexpr bool kBoundary = kG2 && !(C::BETA == -1 && C::N28 == 14);
+  constexpr bool kBoundary = kG2 && !(C::N28 == 14);
   if (!p->aux || (!kBoundary && !p->d_points28))
     return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM needs the auxiliary stream (and, for G1, the carry-free path)");
   constexpr size_t kStateBytes = kG2 ? 2 * sizeof(XYZZ28L<Fp28<C>>) : sizeof(XYZZ28<C>);
@@ -640,7 +646,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   typedef Affine<F> A;
   typedef XYZZ<F> X;
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
-  constexpr bool kBoundary = kG2 && !(C::BETA == -1 && C::N28 == 14);
+  constexpr bool kBoundary = kG2 && !(C::N28 == 14);
   const size_t nbuckets = (size_t)p->W * p->M;
   const size_t off = (size_t)s * cx.seg;
   const size_t len = std::min(cx.seg, cx.n - off);
@@ -698,11 +704,16 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
                                                                            (const X*)p->d_bigpart, flags, (X*)p->d_buckets);
   } else if constexpr (kG2) {
     const dim3 grid((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), block(p->acc_block);
-    if (g2_split_by_coordinate())
-      k_accumulate28_kc_seg<C><<<grid, block, 0, st>>>(
-          (const AffineG2_28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
-          big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
-    else
+    bool kc = false;
+    if constexpr (C::BETA == -1) {
+      if (g2_split_by_coordinate()) {
+        k_accumulate28_kc_seg<C><<<grid, block, 0, st>>>(
+            (const AffineG2_28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+            big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
+        kc = true;
+      }
+    }
+    if (!kc)
       k_accumulate28_lp_seg<C><<<grid, block, 0, st>>>(
           (const AffineG2_28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
           big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
@@ -743,7 +754,7 @@ template <class C, class F>
 int stream_end(mlhip_msm_plan* p, const StreamCtx& cx, hipStream_t st) {
   typedef XYZZ<F> X;
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
-  constexpr bool kBoundary = kG2 && !(C::BETA == -1 && C::N28 == 14);
+  constexpr bool kBoundary = kG2 && !(C::N28 == 14);
   if (cx.resident && !cx.conv_cached && p->points_static && !kBoundary) {  // every tile was converted: the copy is whole again
     p->conv_src = cx.d_points;
     p->conv_n = cx.n;

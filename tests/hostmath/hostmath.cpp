@@ -319,7 +319,7 @@ struct Ops {
   // G2 full additions in the carry-free lane-pair form (ec28_lp.h: xyzz28_lp_add): fold XYZZ points given as affine
   // inputs scaled by per-point z in Fp2 (so that ZZ != 1)
   static int add28_lp_chain(const void* pts, const void* zs, int n, void* out) {
-    if constexpr (C::BETA == -1) {
+    if constexpr (C::N28 > 0) {  // every curve: u^2 = -1 and, since round 3, u^2 = -5
       typedef PairHost<C> B;
       typedef Fp2Field<C> F2;
       const A2* p = (const A2*)pts;
@@ -375,7 +375,7 @@ struct Ops {
   }
   // G2 bucket accumulation in the carry-free lane-pair form (ec28_lp.h) through the host emulation backend
   static int madd28_lp_chain(const void* pts, const uint8_t* neg, int n, void* out) {
-    if constexpr (C::BETA == -1) {
+    if constexpr (C::N28 > 0) {  // every curve: u^2 = -1 and, since round 3, u^2 = -5
       typedef PairHost<C> B;
       const A2* p = (const A2*)pts;
       XYZZ28L<typename B::V> acc;

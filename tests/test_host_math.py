@@ -432,7 +432,7 @@ def test_quad_lane_xyzz_add(hostmath, name):
         assert out.raw == R.g1_to_mont_bytes(cp, want)
 
 
-@pytest.mark.parametrize("name", ["BN254", "BLS12-381"])
+@pytest.mark.parametrize("name", ["BN254", "BLS12-381", "BLS12-377"])
 def test_madd28_lane_pair_g2_accumulation(hostmath, name):
     """ec28_lp.h (G2, u^2 = -1 curves): bucket sums in the carry-free lane-pair form, host emulation of the pair
     exchange, against the oracle -- including doubling, cancellation, infinity inputs."""
@@ -461,9 +461,10 @@ def test_madd28_lane_pair_g2_accumulation(hostmath, name):
         assert out.raw == R.g2_to_mont_bytes(cp, want)
         # ec28_kc.h: the pair split by coordinate, one-lane Karatsuba Fp2 products; also checks (inside) that the
         # bucket state equals the component split's bit for bit after every addition
-        out = ctypes.create_string_buffer(4 * n)
-        assert L.hm_madd28_kc_chain(cid, pts, neg, len(seq), out) == 0
-        assert out.raw == R.g2_to_mont_bytes(cp, want)
+        if cp.beta == -1:
+            out = ctypes.create_string_buffer(4 * n)
+            assert L.hm_madd28_kc_chain(cid, pts, neg, len(seq), out) == 0
+            assert out.raw == R.g2_to_mont_bytes(cp, want)
     # the full addition of the carry-free G2 reduction (xyzz28_lp_add): operands with random Z, doubling, cancellation
     for seq in cases:
         pts = b"".join(R.g2_to_mont_bytes(cp, R.g2_neg(cp, q) if s else q) for q, s in seq)

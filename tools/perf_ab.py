@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B on one box: the same 2^20-point G1 MSM through two plans created under different environment settings
-(e.g. MLHIP_ACC32=1 vs default), alternating, phases printed.  Usage: perf_ab.py [curve] [log2 n] [ENVVAR]"""
+"""A/B on one box: the same 2^20-point MSM (G1; MLHIP_PERF_GROUP=2: G2) through two plans created under different
+environment settings (e.g. MLHIP_ACC32=1 vs default), alternating, phases printed.  Usage: perf_ab.py [curve] [log2 n] [ENVVAR]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ from mathlib_amd import _lib  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "BLS12-381"
 n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
 var = sys.argv[3] if len(sys.argv) > 3 else "MLHIP_ACC32"
+group = int(os.environ.get("MLHIP_PERF_GROUP", "1"))
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
@@ -30,16 +31,16 @@ def rnd(k):
     return torch.randint(-(1 << 63), (1 << 63) - 1, (k, 4), dtype=torch.int64, generator=gen, device=dev).view(torch.uint8).reshape(k, 32).contiguous()
 
 
-base = torch.frombuffer(bytearray(bytes.fromhex(g["g1_gen"])), dtype=torch.uint8).to(dev)
-P = torch.empty(n * g1b, dtype=torch.uint8, device=dev)
-_lib.check(lib.mlhip_scalar_mul_device(cid, 1, base.data_ptr(), 0, rnd(n).data_ptr(), 0, n, P.data_ptr(), st))
+base = torch.frombuffer(bytearray(bytes.fromhex(g["g1_gen" if group == 1 else "g2_gen"])), dtype=torch.uint8).to(dev)
+P = torch.empty(n * (g1b if group == 1 else g2b), dtype=torch.uint8, device=dev)
+_lib.check(lib.mlhip_scalar_mul_device(cid, group, base.data_ptr(), 0, rnd(n).data_ptr(), 0, n, P.data_ptr(), st))
 S = rnd(n)
 torch.cuda.synchronize()
 plans = {}
 os.environ[var] = "1"
-plans[var + "=1"] = _lib.MsmPlan(cid, 1, n, 16)
+plans[var + "=1"] = _lib.MsmPlan(cid, group, n, 16)
 del os.environ[var]
-plans["default"] = _lib.MsmPlan(cid, 1, n, 16)
+plans["default"] = _lib.MsmPlan(cid, group, n, 16)
 res = {}
 for k, pl in plans.items():
     pl.set_profiling(True)
