@@ -427,11 +427,10 @@ void pool_release(PoolEntry* e, bool failed) {
 // Number of segments a host-buffer MSM is streamed in (1 = one upload, one pass).  Measured on MI355X / PCIe gen5
 // (tools/perf_hostapi.py): from 2^19 points the transfer is worth hiding; MLHIP_STREAM_SEGMENTS overrides (0/1 = off).
 int stream_segments(int group, size_t n, const mlhip_msm_plan* plan) {
-  // G1 and the G2 of the BLS12 curves stream through the carry-free kernels (always there unless MLHIP_ACC32=1); G2 on BN254
-  // curves keeps its bucket state in the boundary form and needs nothing beyond the auxiliary stream -- the same
-  // condition plan_stream checks (kBoundary)
-  const bool carry_free_state = group == MLHIP_GROUP_G1 || plan->curve != MLHIP_CURVE_BN254;
-  if (!plan->aux || (carry_free_state && !plan->d_points28)) return 1;
+  // G1 and G2 stream through the carry-free kernels and their bucket state (always there unless MLHIP_ACC32=1, which runs
+  // one pass) -- the condition stream_begin checks
+  (void)group;
+  if (!plan->aux || !plan->d_points28) return 1;
   if (const char* e = getenv("MLHIP_STREAM_SEGMENTS")) {
     int v = atoi(e);
     if (v < 2) return 1;
@@ -777,8 +776,8 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
   // halves the second level), 8 for G2 on the boundary-form curves and for tiny windows
   // (and for small bucket sets, where the chunk pass is a dependent chain rather than work: 2^12 points, c = 13:
   // reduction 0.25 -> 0.22 ms)
-  // G2 of the BLS12 curves (carry-free lane-pair reduction): 16 as well -- BLS12-381: reduction 1.43 -> 1.31 ms at c = 16
-  const bool chunks16 = group == MLHIP_GROUP_G1 || curve != MLHIP_CURVE_BN254;
+  // G2 (carry-free lane-pair reduction): 16 as well -- BLS12-381: reduction 1.43 -> 1.31 ms at c = 16
+  const bool chunks16 = true;
   p->lgL = (chunks16 && p->M >= 256 && (size_t)p->W * p->M >= ((size_t)1 << 17)) ? 4 : 3;
   if (const char* e = getenv("MLHIP_CHUNK_LOG2")) {
     int v = atoi(e);
@@ -860,8 +859,7 @@ int mlhip_msm_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scal
 
 // can this plan run the segment train (plan_stream / plan_stream_shared)?  The condition stream_begin checks.
 static bool plan_can_stream(const mlhip_msm_plan* p) {
-  const bool carry_free_state = p->group == MLHIP_GROUP_G1 || p->curve != MLHIP_CURVE_BN254;
-  return p->aux && !(carry_free_state && !p->d_points28);
+  return p->aux && p->d_points28;
 }
 
 // the shared-scalar train on two plans; h_* = nullptr: everything is already at the d_* pointers

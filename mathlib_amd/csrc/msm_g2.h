@@ -99,80 +99,6 @@ __global__ void __launch_bounds__(256) k_accumulate_lp(const Affine<Fp2Field<C>>
   lp_store_xyzz<C>(buckets, g, acc, hi);
 }
 
-// ---- segmented G2 accumulation in the boundary form (the curve without the carry-free G2 kernel: BN254) -----
-// Same scheme as k_accumulate28_lp_seg, but the kept state of a bucket is simply its boundary-form sum in `buckets`:
-// segment s > 0 starts from it and stores it back; nothing to convert at the end.
-template <class C>
-__global__ void __launch_bounds__(256) k_accumulate_lp_seg(const Affine<Fp2Field<C>>* __restrict__ points,
-                                                           const uint32_t* __restrict__ sorted,
-                                                           const uint32_t* __restrict__ offsets,
-                                                           const uint32_t* __restrict__ counts, size_t n_buckets,
-                                                           const uint32_t* __restrict__ order, uint32_t big_threshold,
-                                                           uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
-                                                           int flags, XYZZ<Fp2Field<C>>* __restrict__ buckets) {
-  typedef Fp2LField<C> FL;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t pair = t >> 1;  // both lanes of a pair share the bucket: every branch below is pair-uniform
-  if (pair >= n_buckets) return;
-  const int hi = lane_is_hi() ? 1 : 0;
-  const size_t g = order[pair];
-  const uint32_t cnt = counts[g];
-  const bool first = (flags & MLHIP_SEG_FIRST) != 0;
-  if (cnt > big_threshold) {  // k_accumulate_big_fold adds this segment's entries to the bucket
-    if (!hi) {
-      uint32_t pos = atomicAdd(big_count, 1u);
-      big_list[pos] = (uint32_t)g;
-    }
-    return;
-  }
-  if (cnt == 0 && !first) return;
-  XYZZ<FL> acc;
-  if (first)
-    xyzz_set_inf<FL>(acc);
-  else
-    lp_load_xyzz<C>(acc, buckets, g, hi);
-  const size_t begin = offsets[g], end = begin + cnt;
-  if (begin < end) {
-    uint32_t e = sorted[begin];
-    Affine<FL> p;
-    lp_load_affine<C>(p, points, e & 0x7fffffffu, hi);
-    for (size_t k = begin; k < end; k++) {
-      uint32_t en = e;
-      Affine<FL> pn = p;
-      if (k + 1 < end) {
-        en = sorted[k + 1];
-        lp_load_affine<C>(pn, points, en & 0x7fffffffu, hi);
-      }
-      xyzz_madd<FL>(acc, p, (e >> 31) != 0);
-      e = en;
-      p = pn;
-    }
-  }
-  lp_store_xyzz<C>(buckets, g, acc, hi);
-}
-
-// long buckets of such a segment: bucket <- (bucket, unless this is the first segment) + total of the slice sums
-template <class F, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_accumulate_big_fold(const uint32_t* __restrict__ big_list,
-                                                               const uint32_t* __restrict__ big_count,
-                                                               const uint32_t* __restrict__ prefix,
-                                                               const XYZZ<F>* __restrict__ partials, int flags,
-                                                               XYZZ<F>* __restrict__ buckets) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
-  const uint32_t nbig = *big_count;
-  const bool first = (flags & MLHIP_SEG_FIRST) != 0;
-  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
-    const uint32_t g = big_list[bi];
-    XYZZ<F> sum;
-    big_bucket_total<F, BLOCK>(sum, sh, partials, prefix, bi);
-    if (threadIdx.x == 0) {
-      if (!first) xyzz_add_ool<F>(sum, buckets[g]);
-      buckets[g] = sum;
-    }
-  }
-}
-
 // ---- slice sums of long G2 buckets over lane pairs (k_big_slices is the one-lane form: ~340 live words per lane) ------
 // BLOCK / 2 pairs stride over the slice's entries with the lane-pair mixed addition, then an LDS tree of lane-pair
 // additions; slice bookkeeping as in k_big_slices (msm_accumulate.h).

@@ -5,6 +5,12 @@
 
 namespace mlhip {
 
+// G2 runs in the carry-free lane-pair form (ec28_lp.h: bucket loop, segment / tile state, lane-pair reduction) on every curve
+// since round 3 -- BLS12-381 first (-14 % accumulation), then BLS12-377 (u^2 = -5: 2^20 points 12.35 -> 9.45 ms) and BN254
+// (10 limbs: 5.25 -> 4.95 ms); MLHIP_ACC32=1 keeps the boundary-form kernels as the second implementation
+template <class C>
+constexpr bool g2_carry_free_v = true;
+
 // G2 bucket accumulation (carry-free form): lane pairs split by component with dual products (k_accumulate28_lp_seg, default)
 // or by coordinate with one-lane Karatsuba Fp2 products (k_accumulate28_kc_seg, MLHIP_G2_KC=1: 16 % fewer multiplier
 // instructions per addition, but three 64-bit column combinations per product column and 130 spilled registers instead of
@@ -122,10 +128,8 @@ int plan_alloc(mlhip_msm_plan* p) {
     p->reduce28 = want28 && !p->reduce_one_lane && !(red32 && red32[0] == '1');
     if (p->reduce28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * sizeof(XYZZ28<typename F::Curve>)));
   }
-  if constexpr (std::is_same<F, Fp2Field<typename F::Curve>>::value && F::Curve::N28 == 14) {
-    // G2 in the carry-free form: the 14-limb curves (BLS12-381: -14 % accumulation time; BLS12-377 since round 3, with the
-    // differences reduced instead of carry-propagated for u^2 = -5, ec28_lp.h); the 10-limb BN254 form gains nothing over
-    // its 8 saturated limbs on lane pairs
+  if constexpr (std::is_same<F, Fp2Field<typename F::Curve>>::value && g2_carry_free_v<typename F::Curve>) {
+    // G2 in the carry-free form (g2_carry_free_v above)
     const char* acc32 = getenv("MLHIP_ACC32");
     if (!(acc32 && acc32[0] == '1')) {
       HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(AffineG2_28<typename F::Curve>)));
@@ -313,7 +317,7 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
     size_t n_chunks = (size_t)p->W * p->T;
     if constexpr (kLanePairs) {
       bool done28 = false;
-      if constexpr (C::N28 == 14) {
+      if constexpr (g2_carry_free_v<C>) {
         if (p->reduce28) {
           typedef XYZZ28L<Fp28<C>> X28;
           k_chunks_lp28<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>(
@@ -381,8 +385,7 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
 template <class C, class F>
 int resident_tiles(const mlhip_msm_plan* p, size_t n) {
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
-  constexpr bool kBoundary = kG2 && !(C::N28 == 14);
-  if (!p->aux || (!kBoundary && !p->d_points28)) return 1;
+  if (!p->aux || !p->d_points28) return 1;
   int lg = kG2 ? 20 : 21;
   size_t from = (size_t)1 << (kG2 ? 23 : 22);
   if (plan_use_edwards<C, F>(p)) {  // 168-byte Niels triples: 2^20 of them are what 2^21 Weierstrass points weigh
@@ -449,7 +452,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
         p->upload_src = nullptr;
       }
       if constexpr (std::is_same<F, Fp2Field<C>>::value) {
-        if constexpr (C::N28 == 14)
+        if constexpr (g2_carry_free_v<C>)
           k_points_to28_g2<C><<<dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, p->aux>>>(
               (const A*)d_points, n, (AffineG2_28<C>*)p->d_points28);
       } else {
@@ -474,10 +477,10 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     constexpr bool kLanePairs = std::is_same<F, Fp2Field<C>>::value;  // G2: two lanes per bucket
     if constexpr (kLanePairs) {
       bool done28 = false;
-      if constexpr (C::N28 == 14) {
+      if constexpr (g2_carry_free_v<C>) {
         if (p->d_points28) {
           HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
-          if constexpr (C::N28 == 14) {
+          if constexpr (g2_carry_free_v<C>) {
             if (p->reduce28) {  // one segment that is first and last, leaving the raw accumulators for k_chunks_lp28
               const dim3 grid((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), block(p->acc_block);
               bool kc = false;
@@ -555,7 +558,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
               MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28, (X*)p->d_buckets);
           folded = true;
         }
-      } else if constexpr (C::N28 == 14) {
+      } else if constexpr (g2_carry_free_v<C>) {
         if (p->reduce28 && p->d_points28) {
           k_accumulate_big_seg_g2<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
               p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28L<Fp28<C>>*)p->d_state28,
@@ -607,14 +610,12 @@ struct StreamCtx {
 template <class C, class F>
 int stream_begin(mlhip_msm_plan* p, StreamCtx& cx, hipStream_t st, int min_K) {
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
-  // G2 on the curves without the carry-free lane-pair kernel keeps its bucket state in the boundary form
-  constexpr bool kBoundary = kG2 && !(C::N28 == 14);
-  if (!p->aux || (!kBoundary && !p->d_points28))
-    return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM needs the auxiliary stream (and, for G1, the carry-free path)");
+  if (!p->aux || !p->d_points28)
+    return mlhip_rt::fail(MLHIP_EINVAL, "streamed MSM needs the auxiliary stream and the carry-free path");
   constexpr size_t kStateBytes = kG2 ? 2 * sizeof(XYZZ28L<Fp28<C>>) : sizeof(XYZZ28<C>);
   if (cx.n == 0 || cx.K < min_K || cx.K > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "bad segment count");
   const size_t nbuckets = (size_t)p->W * p->M;
-  if (!kBoundary && !p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * kStateBytes));
+  if (!p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * kStateBytes));
   for (int s = 0; s < cx.K; s++)
     if (!p->ev_seg[s]) HIPCHK(hipEventCreateWithFlags(&p->ev_seg[s], hipEventDisableTiming));
   // resident points (h_points == nullptr): only the scalars travel (or nothing: h_scalars == nullptr); their carry-free
@@ -646,12 +647,11 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   typedef Affine<F> A;
   typedef XYZZ<F> X;
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
-  constexpr bool kBoundary = kG2 && !(C::N28 == 14);
   const size_t nbuckets = (size_t)p->W * p->M;
   const size_t off = (size_t)s * cx.seg;
   const size_t len = std::min(cx.seg, cx.n - off);
   const bool first = off == 0, last = off + len >= cx.n;
-  const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0) | (!kBoundary && p->reduce28 ? MLHIP_SEG_KEEP28 : 0);
+  const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0) | (p->reduce28 ? MLHIP_SEG_KEEP28 : 0);
   const char* hp = (const char*)cx.h_points;
   const char* hs = (const char*)cx.h_scalars;
   char* dsc = (char*)cx.d_scalars + off * 32;
@@ -660,9 +660,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   if (hs) HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
   if (!cx.conv_cached) {
     if (!cx.resident) HIPCHK(hipMemcpyAsync(dpt, hp + off * sizeof(A), len * sizeof(A), hipMemcpyHostToDevice, p->aux));
-    if constexpr (kBoundary) {
-      // the boundary-form kernel reads the uploaded points as they are
-    } else if constexpr (kG2)
+    if constexpr (kG2)
       k_points_to28_g2<C><<<dim3((unsigned)((4 * len + 255) / 256)), dim3(256), 0, p->aux>>>(
           dpt, len, (AffineG2_28<C>*)p->d_points28 + off);
     else {
@@ -694,15 +692,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   const mlhip_msm_plan* sv = sorter ? sorter : p;  // whose entry lists the kernels read
   uint32_t big_threshold = (uint32_t)std::min<size_t>((len >> (p->c - 1)) * 8, 1u << 30);
   if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
-  if constexpr (kBoundary) {
-    k_accumulate_lp_seg<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-        dpt, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order, big_threshold, p->d_biglist, p->d_bigcount, flags,
-        (X*)p->d_buckets);
-    constexpr int BB = 128;
-    launch_big_slices<F, BB>(p, dpt, st, sv);
-    k_accumulate_big_fold<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
-                                                                           (const X*)p->d_bigpart, flags, (X*)p->d_buckets);
-  } else if constexpr (kG2) {
+  if constexpr (kG2) {
     const dim3 grid((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), block(p->acc_block);
     bool kc = false;
     if constexpr (C::BETA == -1) {
@@ -753,9 +743,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
 template <class C, class F>
 int stream_end(mlhip_msm_plan* p, const StreamCtx& cx, hipStream_t st) {
   typedef XYZZ<F> X;
-  constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
-  constexpr bool kBoundary = kG2 && !(C::N28 == 14);
-  if (cx.resident && !cx.conv_cached && p->points_static && !kBoundary) {  // every tile was converted: the copy is whole again
+  if (cx.resident && !cx.conv_cached && p->points_static) {  // every tile was converted: the copy is whole again
     p->conv_src = cx.d_points;
     p->conv_n = cx.n;
     p->conv_ed = cx.ed;
