@@ -241,6 +241,49 @@ __global__ void __launch_bounds__(64) k_fixed_base_lp(const Affine<Fp2Field<C>>*
   o[2 + hi] = r.y.v;
 }
 
+// the same on the carry-free lane-pair form (ec28_lp.h, every curve since round 3): the table converted once by
+// k_points_to28_g2, <= 32 carry-free mixed additions per scalar, one conversion back per result
+template <class C>
+__global__ void __launch_bounds__(64) k_fixed_base_lp28(const AffineG2_28<C>* __restrict__ table,
+                                                        const uint32_t* __restrict__ scalars, int mont, size_t n,
+                                                        Affine<Fp2Field<C>>* __restrict__ out) {
+  typedef Fp2LField<C> FL;
+  typedef PairDevice<C> B;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = t >> 1;
+  if (i >= n) return;
+  const int hi = (int)(threadIdx.x & 1u);
+  uint32_t s[8];
+  fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  XYZZ28L<Fp28<C>> acc;
+  bool inf = true;
+#pragma unroll 1
+  for (int j = 0; j < FB_WINDOWS; j++) {
+    const uint32_t d = (s[j >> 2] >> ((j & 3) * 8)) & 255u;
+    if (d) {  // pair-uniform: both lanes hold the same scalar
+      const AffineG2_28<C>* e = table + ((size_t)j * FB_ROW + d - 1);
+      Affine28L<Fp28<C>> q;
+      q.x = e->c[hi];
+      q.y = e->c[2 + hi];
+      xyzz28_lp_madd<C, B>(acc, inf, q, false);
+    }
+  }
+  XYZZ<FL> r;
+  if (inf) {
+    xyzz_set_inf<FL>(r);
+  } else {
+    fp28_to_fp<C>(r.x.v, acc.x);
+    fp28_to_fp<C>(r.y.v, acc.y);
+    fp28_to_fp<C>(r.zz.v, acc.zz);
+    fp28_to_fp<C>(r.zzz.v, acc.zzz);
+  }
+  Affine<FL> a;
+  xyzz_to_affine<FL>(a, r);
+  Fp<C>* o = reinterpret_cast<Fp<C>*>(out + i);
+  o[hi] = a.x.v;
+  o[2 + hi] = a.y.v;
+}
+
 template <class C, class F>
 int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_scalars, int mont, size_t n, void* d_out,
                       hipStream_t st) {
@@ -260,7 +303,7 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
     // Calls on different streams reuse it in the order they take the lock: each waits for the event the previous
     // one recorded after its last kernel.  (hipMallocAsync here gave intermittently wrong results on this runtime.)
     const size_t tab_bytes = kEntries * sizeof(Affine<F>), sc_bytes = kEntries * 32;
-    const size_t t28_bytes = kG1 ? kEntries * sizeof(Affine28<C>) : 0;
+    const size_t t28_bytes = kG1 ? kEntries * sizeof(Affine28<C>) : kEntries * sizeof(AffineG2_28<C>);
     const size_t need = tab_bytes + sc_bytes + t28_bytes;
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
@@ -298,7 +341,13 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
       k_fixed_base_g1<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(t28, (const uint32_t*)d_scalars, mont, n,
                                                                              (Affine<F>*)d_out);
     } else {
-      if (!one_lane)
+      const char* a32 = getenv("MLHIP_ACC32");  // =1: the boundary-form lane-pair kernel (second implementation)
+      if (!one_lane && !(a32 && a32[0] == '1')) {
+        AffineG2_28<C>* t28 = (AffineG2_28<C>*)(scratch + tab_bytes + sc_bytes);
+        k_points_to28_g2<C><<<dim3((unsigned)((4 * kEntries + 255) / 256)), dim3(256), 0, st>>>(table, kEntries, t28);
+        k_fixed_base_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>(t28, (const uint32_t*)d_scalars, mont, n,
+                                                                                    (Affine<F>*)d_out);
+      } else if (!one_lane)
         k_fixed_base_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
                                                                                   (Affine<F>*)d_out);
       else

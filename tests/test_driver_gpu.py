@@ -180,6 +180,13 @@ def test_fixed_base_table_path(curve, mlhip, monkeypatch):
         assert outs["1"] == outs["0"]
         for i in (0, 3, n - 6, n - 5, n - 4, n - 3, n - 2, n - 1):
             assert outs["1"][i * size : (i + 1) * size] == cref.point_mul(c.id, group, base, ks[i])
+        if group == 2:  # the table path on the boundary-form lane-pair kernel (round 1; the default is carry-free since round 3)
+            monkeypatch.setenv("MLHIP_FIXED_BASE_MIN", "1")
+            monkeypatch.setenv("MLHIP_ACC32", "1")
+            out = ctypes.create_string_buffer(size * n)
+            mlhip.check(lib.mlhip_scalar_mul(c.id, group, base, 0, sc, 0, n, out))
+            monkeypatch.delenv("MLHIP_ACC32")
+            assert out.raw == outs["1"]
     # a curve point outside G1 (cofactor > 1 on the BLS curves): x = 1, 2, ... until x^3 + b is a square
     cp = next(v for v in R.CURVES.values() if v.curve_id == c.id)
     if cp.family == "BLS12":
