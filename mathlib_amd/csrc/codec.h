@@ -11,7 +11,9 @@
 // largest, 0x40 infinity, 0x00 uncompressed).
 // status: 0 ok | 1 malformed encoding | 2 not on the curve | 3 not in the subgroup.
 #pragma once
+#include "fp28.h"
 #include "ec.h"
+#include "ec28.h"
 #include "pairing.h"  // fp_halve
 
 namespace mlhip {
@@ -20,25 +22,28 @@ enum { CODEC_OK = 0, CODEC_MALFORMED = 1, CODEC_NOT_ON_CURVE = 2, CODEC_NOT_IN_S
 
 // r = a^e, e given as N little-endian 32-bit words: fixed 4-bit windows (15 table entries), so a 381-bit
 // exponent costs 380 squarings + <= 95 + 14 multiplications instead of ~190 with the binary ladder
+// Since round 3 the chain runs in the carry-free form (fp28.h): a squaring is 105 + 196 v_mad_i64_i32 instead of the
+// boundary form's 288 v_mad_u64_u32 + 288 v_addc, one conversion in and one out (every value of the chain is a product
+// output, i.e. normalized).
 template <class C>
-MLHIP_HD void fp_pow_words(Fp<C>& r, const Fp<C>& a, const uint32_t (&e)[C::N]) {
-  Fp<C> tab[15];  // a^1 .. a^15
+MLHIP_HD void fp28_pow_words(Fp28<C>& r, const Fp28<C>& a, const uint32_t (&e)[C::N]) {
+  Fp28<C> tab[15];  // a^1 .. a^15
   tab[0] = a;
-  for (int i = 1; i < 15; i++) fp_mul<C>(tab[i], tab[i - 1], a);
-  Fp<C> acc;
-  fp_one<C>(acc);
+  for (int i = 1; i < 15; i++) fp28_mul<C>(tab[i], tab[i - 1], tab[0]);
+  Fp28<C> acc;
+  fp28_from_const<C>(acc, C::ONE28);
   bool started = false;
   for (int i = C::N * 8 - 1; i >= 0; i--) {  // nibbles, most significant first
     if (started) {
-      fp_sqr<C>(acc, acc);
-      fp_sqr<C>(acc, acc);
-      fp_sqr<C>(acc, acc);
-      fp_sqr<C>(acc, acc);
+      fp28_sqr<C>(acc, acc);
+      fp28_sqr<C>(acc, acc);
+      fp28_sqr<C>(acc, acc);
+      fp28_sqr<C>(acc, acc);
     }
     const uint32_t nib = (e[i >> 3] >> ((i & 7) * 4)) & 15u;
     if (nib) {
       if (started)
-        fp_mul<C>(acc, acc, tab[nib - 1]);
+        fp28_mul<C>(acc, acc, tab[nib - 1]);
       else {
         acc = tab[nib - 1];
         started = true;
@@ -46,6 +51,20 @@ MLHIP_HD void fp_pow_words(Fp<C>& r, const Fp<C>& a, const uint32_t (&e)[C::N]) 
     }
   }
   r = acc;
+}
+template <class C>
+MLHIP_HD void fp_pow_words(Fp<C>& r, const Fp<C>& a, const uint32_t (&e)[C::N]) {
+  Fp28<C> a28, r28;
+  fp28_from_fp<C>(a28, a);
+  fp28_pow_words<C>(r28, a28, e);
+  fp28_to_fp<C>(r, r28);
+}
+// x = y mod p for normalized carry-free values (exact)
+template <class C>
+MLHIP_HD bool fp28_eq(const Fp28<C>& x, const Fp28<C>& y) {
+  Fp28<C> d;
+  fp28_sub<C>(d, x, y);
+  return fp28_maybe_zero<C>(d) && fp28_is_zero_exact<C>(d);
 }
 
 // square root in Fp; false when a is a non-residue.  p = 3 mod 4: a^((p+1)/4); else Tonelli-Shanks.
@@ -55,42 +74,48 @@ MLHIP_HD bool fp_sqrt(Fp<C>& r, const Fp<C>& a) {
     fp_zero<C>(r);
     return true;
   }
-  Fp<C> one;
-  fp_one<C>(one);
+  // the whole computation in the carry-free form (every value a product output): one conversion in, one out
+  Fp28<C> a28, one;
+  fp28_from_fp<C>(a28, a);
+  fp28_from_const<C>(one, C::ONE28);
   if (C::SQRT_S == 1) {
-    Fp<C> y, y2;
-    fp_pow_words<C>(y, a, C::SQRT_EXP);
-    fp_sqr<C>(y2, y);
-    if (!fp_eq<C>(y2, a)) return false;
-    r = y;
+    Fp28<C> y, y2;
+    fp28_pow_words<C>(y, a28, C::SQRT_EXP);
+    fp28_sqr<C>(y2, y);
+    if (!fp28_eq<C>(y2, a28)) return false;
+    fp28_to_fp<C>(r, y);
     return true;
   }
   // p - 1 = 2^S q:  w = a^((q-1)/2), x = a w, b = x w = a^q
-  Fp<C> w, x, b, z, t;
-  fp_pow_words<C>(w, a, C::SQRT_EXP);
-  fp_mul<C>(x, a, w);
-  fp_mul<C>(b, x, w);
-  fp_from_const<C>(z, C::SQRT_Z);
+  Fp28<C> w, x, b, z, t;
+  fp28_pow_words<C>(w, a28, C::SQRT_EXP);
+  fp28_mul<C>(x, a28, w);
+  fp28_mul<C>(b, x, w);
+  {
+    Fp<C> z32;
+    fp_from_const<C>(z32, C::SQRT_Z);
+    fp28_from_fp<C>(z, z32);
+  }
   int rr = C::SQRT_S;
   // a is a residue iff b^(2^(S-1)) = 1
   t = b;
-  for (int i = 0; i < C::SQRT_S - 1; i++) fp_sqr<C>(t, t);
-  if (!fp_eq<C>(t, one)) return false;
-  while (!fp_eq<C>(b, one)) {
+  for (int i = 0; i < C::SQRT_S - 1; i++) fp28_sqr<C>(t, t);
+  if (!fp28_eq<C>(t, one)) return false;
+  while (!fp28_eq<C>(b, one)) {
     int m = 0;
     t = b;
-    while (!fp_eq<C>(t, one)) {
-      fp_sqr<C>(t, t);
+    while (!fp28_eq<C>(t, one)) {
+      fp28_sqr<C>(t, t);
       m++;
     }
     t = z;
-    for (int i = 0; i < rr - m - 1; i++) fp_sqr<C>(t, t);
-    fp_sqr<C>(z, t);
-    fp_mul<C>(b, b, z);
-    fp_mul<C>(x, x, t);
+    for (int i = 0; i < rr - m - 1; i++) fp28_sqr<C>(t, t);
+    fp28_sqr<C>(z, t);
+    fp28_mul<C>(b, b, z);
+    fp28_mul<C>(x, x, t);
     rr = m;
   }
-  r = x;
+  fp28_to_fp<C>(r, x);
   return true;
 }
 
@@ -157,33 +182,49 @@ MLHIP_HD bool g1_in_subgroup_ladder(const Affine<FpField<C>>& P) {
 // holds on the whole curve, so phi(P) = [-x^2]P forces [x^4 - x^2 + 1]P = [r]P = O; complete because phi acts as
 // the scalar -x^2 on the r-torsion for this beta (tools/gen_constants.py picks it).  Two 64-bit ladders (2 x 63
 // doublings + a dozen additions) instead of a 255-bit one.
+// (since round 3 the two ladders run in the carry-free form, ec28.h: xyzz28_dbl / xyzz28_madd / xyzz28_add)
 template <class C>
 MLHIP_HD bool g1_in_subgroup_endo(const Affine<FpField<C>>& P) {
-  typedef FpField<C> F;
   int top = 63;
   while (!((C::X_ABS >> top) & 1)) top--;
-  XYZZ<F> R, S, d;
-  xyzz_from_affine<F>(R, P);  // [|x|] P
+  Affine28<C> p28;
+  affine28_from<C>(p28, P);
+  XYZZ28<C> R, S, d;
+  bool r_inf = false, s_inf;
+  R.x = p28.x;  // [|x|] P
+  R.y = p28.y;
+  fp28_from_const<C>(R.zz, C::ONE28);
+  fp28_from_const<C>(R.zzz, C::ONE28);
   for (int i = top - 1; i >= 0; i--) {
-    xyzz_dbl<F>(d, R);
-    R = d;
-    if ((C::X_ABS >> i) & 1) xyzz_madd<F>(R, P, false);
+    if (!r_inf) {
+      xyzz28_dbl<C>(d, R);
+      R = d;
+      r_inf = fp28_all_zero<C>(R.zz);
+    }
+    if ((C::X_ABS >> i) & 1) xyzz28_madd<C>(R, r_inf, p28, false);
   }
   S = R;  // [|x|] R = [x^2] P
+  s_inf = r_inf;
   for (int i = top - 1; i >= 0; i--) {
-    xyzz_dbl<F>(d, S);
-    S = d;
-    if ((C::X_ABS >> i) & 1) xyzz_add<F>(S, R);
+    if (!s_inf) {
+      xyzz28_dbl<C>(d, S);
+      S = d;
+      s_inf = fp28_all_zero<C>(S.zz);
+    }
+    if ((C::X_ABS >> i) & 1) xyzz28_add<C>(S, s_inf, R, r_inf);
   }
-  if (xyzz_is_inf<F>(S)) return false;  // the order of P divides x^2: not in G1 (P is finite here)
+  if (s_inf) return false;  // the order of P divides x^2: not in G1 (P is finite here)
   // S == -phi(P) = (beta Px, -Py) ?   i.e.  S.X = beta Px S.ZZ  and  S.Y = -Py S.ZZZ
-  Fp<C> beta, t, u;
+  Fp<C> beta;
   fp_from_const<C>(beta, C::ENDO_BETA);
-  fp_mul<C>(t, P.x, beta);
-  fp_mul<C>(t, t, S.zz);
-  fp_mul<C>(u, P.y, S.zzz);
-  fp_neg<C>(u, u);
-  return fp_eq<C>(t, S.x) & fp_eq<C>(u, S.y);
+  Fp28<C> b28, t, u, dx, dy;
+  fp28_from_fp<C>(b28, beta);
+  fp28_mul<C>(t, p28.x, b28);
+  fp28_mul<C>(t, t, S.zz);
+  fp28_mul<C>(u, p28.y, S.zzz);
+  fp28_sub<C>(dx, t, S.x);
+  fp28_add<C>(dy, u, S.y);
+  return (fp28_maybe_zero<C>(dx) && fp28_is_zero_exact<C>(dx)) & (fp28_maybe_zero<C>(dy) && fp28_is_zero_exact<C>(dy));
 }
 
 // mode 1: the fastest exact test available for the curve; mode 2: always the plain [r]P ladder

@@ -138,4 +138,51 @@ MLHIP_HD void xyzz28_dbl(XYZZ28<C>& r, const XYZZ28<C>& p) {
   r.x = X3;
 }
 
+// acc += q, both XYZZ28 with normalized coordinates and their own infinity flags (add-2008-s), one lane: 12 products + 2
+// squares, Y3 = R (Q - X3) - S1 PPP one fused dual product.  Same point: doubled (xyzz28_dbl); opposite points: infinity.
+// For the chains of the subgroup test (codec.h); the bucket reduction runs the quad-lane schedule (ec_quad28.h).
+template <class C>
+MLHIP_HD void xyzz28_add(XYZZ28<C>& acc, bool& inf, const XYZZ28<C>& q, bool q_inf) {
+  if (q_inf) return;
+  if (inf) {
+    acc = q;
+    inf = false;
+    return;
+  }
+  Fp28<C> U1, U2, S1, S2, P, R, PP, PPP, Q, X3, t, n;
+  fp28_mul<C>(U1, acc.x, q.zz);
+  fp28_mul<C>(U2, q.x, acc.zz);
+  fp28_mul<C>(S1, acc.y, q.zzz);
+  fp28_mul<C>(S2, q.y, acc.zzz);
+  fp28_sub<C>(P, U2, U1);  // weight 2
+  fp28_sub<C>(R, S2, S1);
+  if (fp28_maybe_zero<C>(P) && fp28_is_zero_exact<C>(P)) {
+    if (fp28_maybe_zero<C>(R) && fp28_is_zero_exact<C>(R)) {
+      XYZZ28<C> d;
+      xyzz28_dbl<C>(d, q);
+      acc = d;
+      inf = fp28_all_zero<C>(d.zz);  // a point of order two doubles to infinity (canonical zeros)
+    } else {
+      inf = true;
+    }
+    return;
+  }
+  fp28_sqr<C>(PP, P);
+  fp28_mul<C>(PPP, P, PP);  // 2 x 1
+  fp28_mul<C>(Q, U1, PP);
+  fp28_sqr<C>(t, R);
+  fp28_sub<C>(t, t, PPP);
+  fp28_sub<C>(t, t, Q);
+  fp28_sub<C>(t, t, Q);  // weight 4
+  fp28_normalize<C>(X3, t);
+  fp28_sub<C>(Q, Q, X3);  // weight 2
+  fp28_neg<C>(n, S1);
+  fp28_mul2<C>(acc.y, R, Q, n, PPP);  // 2 x 2 + 1 x 1
+  acc.x = X3;
+  fp28_mul<C>(t, acc.zz, q.zz);
+  fp28_mul<C>(acc.zz, t, PP);
+  fp28_mul<C>(t, acc.zzz, q.zzz);
+  fp28_mul<C>(acc.zzz, t, PPP);
+}
+
 }  // namespace mlhip
