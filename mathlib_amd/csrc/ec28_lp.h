@@ -145,14 +145,6 @@ MLHIP_HD bool lp28_is_zero_exact(const typename B::V& a) {
   return B::both(z);
 }
 
-// k x for k = -BETA (u^2 = BETA): 1, or 5 for BLS12-377
-template <class C>
-MLHIP_HD void fp28_times_beta_k(Fp28<C>& r, const Fp28<C>& a) {
-  constexpr int K = -C::BETA;
-  static_assert(K == 1 || K == 5, "u^2 = -1 or -5");
-#pragma unroll
-  for (int i = 0; i < C::N28; i++) r.l[i] = K == 5 ? (int32_t)(((uint32_t)a.l[i] << 2) + (uint32_t)a.l[i]) : a.l[i];
-}
 template <class C, class B>
 MLHIP_HD void lp28_reduce_p(typename B::V& r, const typename B::V& a) {
   MLHIP_LP28_EACH(B, fp28_reduce<C>(B::at(r, li_), B::at(a, li_)));
@@ -176,7 +168,7 @@ MLHIP_HD void lp28_mul(typename B::V& r, const typename B::V& a, const typename 
   B::xchg(ax, a);
   B::xchg(bx, b);
   B::real_on_both(b0, b);
-  MLHIP_LP28_EACH(B, fp28_times_beta_k<C>(B::at(kbx, li_), B::at(bx, li_)));
+  MLHIP_LP28_EACH(B, fp28_times_k<C>(B::at(kbx, li_), B::at(bx, li_)));
   lp28_neg<C, B>(nbx, kbx);
   B::sel_hi(y2, b, nbx);  // c0: -k b1 | c1: b1 (own)
   MLHIP_LP28_EACH(B, fp28_mul2<C>(B::at(r, li_), B::at(a, li_), B::at(b0, li_), B::at(ax, li_), B::at(y2, li_)));
@@ -199,7 +191,7 @@ MLHIP_HD void lp28_sqr(typename B::V& r, const typename B::V& a) {
   } else {
     typename B::V ax, kax, s, d, x, y, o, ox, v4, c0, c1;
     B::xchg(ax, a);
-    MLHIP_LP28_EACH(B, fp28_times_beta_k<C>(B::at(kax, li_), B::at(ax, li_)));
+    MLHIP_LP28_EACH(B, fp28_times_k<C>(B::at(kax, li_), B::at(ax, li_)));
     MLHIP_LP28_EACH(B, fp28_add<C>(B::at(s, li_), B::at(a, li_), B::at(ax, li_)));   // c0 lane: a0 + a1
     MLHIP_LP28_EACH(B, fp28_sub<C>(B::at(d, li_), B::at(a, li_), B::at(kax, li_)));  // c0 lane: a0 - k a1
     lp28_normalize<C, B>(s, s);

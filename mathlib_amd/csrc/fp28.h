@@ -81,6 +81,15 @@ MLHIP_HD void fp28_normalize(Fp28<C>& r, const Fp28<C>& a) {
   r.l[C::N28 - 1] = a.l[C::N28 - 1] + c;
 }
 
+// k x for the small positive k = -BETA of u^2 = BETA (5 for BLS12-377): shifts and adds, the weight grows k-fold
+template <class C>
+MLHIP_HD void fp28_times_k(Fp28<C>& r, const Fp28<C>& a) {
+  constexpr int K = -C::BETA;
+  static_assert(K == 1 || K == 5, "u^2 = -1 or -5");
+#pragma unroll
+  for (int i = 0; i < C::N28; i++) r.l[i] = K == 5 ? (int32_t)(((uint32_t)a.l[i] << 2) + (uint32_t)a.l[i]) : a.l[i];
+}
+
 // value -> value - round(value / p) p, carry-propagated: limbs normalized, |result| < 0.6 p.  The quotient comes from
 // the top limb (value / 2^364 up to the weight) in single precision: exact to well within +-0.01.
 template <class C>

@@ -238,15 +238,6 @@ MLHIP_HD void lp28_halve(E& r, const E& a) {
   r.set_vb(v);
 }
 
-// k x for the small positive k = -BETA of u^2 = BETA (5 for BLS12-377): shifts and adds, the weight grows k-fold
-template <class C>
-MLHIP_HD void fp28_times_k(Fp28<C>& r, const Fp28<C>& a) {
-  constexpr int K = -C::BETA;
-  static_assert(K == 1 || K == 5, "u^2 = -1 or -5");
-#pragma unroll
-  for (int i = 0; i < C::N28; i++) r.l[i] = K == 5 ? (int32_t)(((uint32_t)a.l[i] << 2) + (uint32_t)a.l[i]) : a.l[i];
-}
-
 // (a0 + a1 u)(b0 + b1 u), u^2 = BETA = -k: one fused dual product per lane
 //   lane c0: a0 b0 + a1 (-k b1)        lane c1: a1 b0 + a0 b1
 // k = 1 (BN254, BLS12-381): operands of weight w_a w_b <= 4.  k = 5 (BLS12-377): the c0 lane's product has weight
