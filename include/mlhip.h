@@ -186,9 +186,11 @@ int mlhip_gt_exp_device(int curve, const void* d_in_gt, const void* d_scalars, i
 
 /* out[i] = [scalars[i]] points[i * point_stride]: batched single-scalar multiplication (G1.Mul / G2.Mul,
  * driver/gurvy/bls12381/bls12-381.go:238-247, :342-351).  point_stride = 0 multiplies one base point by
- * every scalar (how the synthetic benchmark inputs [k_i]G are produced); from 2^16 scalars on that case builds a table
- * of [d 2^(8j)]P on the device and spends <= 32 mixed additions per scalar instead of 256 doublings + 64 additions
- * (MLHIP_FIXED_BASE_MIN=n moves the threshold, 0 = never).  Device pointers. */
+ * every scalar (how the synthetic benchmark inputs [k_i]G are produced); from 2^12 scalars on that case builds a table
+ * of [m 2^(wj)]P on the device (w = 12; MLHIP_FB_WINDOW overrides) and spends ceil(256 / w) mixed
+ * additions per scalar instead of 256 doublings + 64 additions (MLHIP_FIXED_BASE_MIN=n moves the threshold, 0 = never).
+ * The table stays on the device: the next call with the same curve, group and base point skips the build (the comparison
+ * runs on the device, the call stays asynchronous; MLHIP_FB_CACHE=0 builds it every time).  Device pointers. */
 int mlhip_scalar_mul_device(int curve, int group, const void* d_points, size_t point_stride, const void* d_scalars,
                             int scalars_mont, size_t n, void* d_out_affine, void* stream);
 /* host-buffer form */

@@ -30,9 +30,10 @@ __device__ __forceinline__ int signed_window4_digit(const uint32_t t[9], int w) 
 template <class C, class F>
 __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__ points, size_t point_stride,
                                                    const uint32_t* __restrict__ scalars, int mont, size_t n,
-                                                   Affine<F>* __restrict__ out) {
+                                                   Affine<F>* __restrict__ out, const uint32_t* __restrict__ skip = nullptr) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (skip && *skip) return;  // the fixed-base table of this base is still in `out` (k_fb_check)
   uint32_t s[8];
   if (mont < 0) {  // plain 256-bit integers, not reduced mod r (the fixed-base table: [d 2^(8j)]P for ANY P on the curve)
 #pragma unroll
@@ -85,11 +86,21 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
 }
 
 // ---- one base, many scalars (point_stride = 0: [s_i]G for generators, Pedersen bases ...) ------------------------
-// From FIXED_BASE_MIN scalars on, the table T[j][d-1] = [d 2^(8j)]P (32 windows x 255 affine points, built by
-// k_scalar_mul itself from 8160 plain-integer scalars) turns every product into <= 32 mixed additions and no doubling:
-// 2^20 G1 products in 10 ms instead of 70 ms, G2 in 26 ms instead of 209 ms (profiles/r01_perf_scalar_mul.txt).  G1 runs the additions in the carry-free form (ec28.h).
-constexpr int FB_WINDOWS = 32, FB_ROW = 255;
-constexpr size_t FIXED_BASE_MIN = (size_t)1 << 16;  // the table costs one double-and-add wave time (G1 ~4 ms, G2 ~7 ms)
+// From FIXED_BASE_MIN scalars on, a table T[j][m-1] = [m 2^(wj)]P, m = 1 .. 2^(w-1), turns every product into
+// ceil(256 / w) mixed additions of +-T[j][|d_j|] (signed w-bit digits, msm_window_digit) and no doubling.  The table is built
+// by k_scalar_mul itself from plain-integer scalars -- one double-and-add wave time whatever its size, as long as its entries
+// fit one wave per SIMD -- so w = 12 (22 windows x 2 048 points) instead of round 1's 32 unsigned bytes.  The table stays in
+// the device's scratch buffer with its base as the key: a call with the same curve, group, width and base (k_fb_check
+// compares on the device, the build kernels return at once) skips the build -- generators and Pedersen bases come back call
+// after call.  2^20 products of one base, BLS12-381 (profiles/r03_perf_scalar_mul.txt): G1 10.2 -> 8.3 ms with the table built
+// in the call, 4.1 ms with the table of an earlier call (double-and-add: 63 ms); G2 22.8 -> 19.6 / 13.2 ms (190 ms).
+// MLHIP_FB_WINDOW = w (4 .. 14) overrides the width, MLHIP_FB_CACHE = 0 rebuilds the table in every call.
+// The threshold: a first call costs what the double-and-add kernel costs (both are one wave time, ~4 ms G1 / ~6 ms G2), every
+// later one a tenth of it.
+constexpr size_t FIXED_BASE_MIN = (size_t)1 << 12;
+constexpr int FB_W_G1 = 12, FB_W_G2 = 12, FB_W_MIN = 4, FB_W_MAX = 14;
+constexpr size_t FB_HEADER = 512;  // bytes in front of the table: [flag | tag | base point (<= 192 bytes)]
+MLHIP_HD int fb_windows(int w) { return (256 + w - 1) / w; }
 
 struct FixedBaseScratch {
   char* buf = nullptr;
@@ -99,19 +110,51 @@ struct FixedBaseScratch {
 static std::mutex g_fb_mu;
 static FixedBaseScratch g_fb[64];  // per device
 
-static __global__ void __launch_bounds__(256) k_fb_scalars(uint32_t* __restrict__ out) {
+// header[0] = 1 iff the buffer holds the table of this (tag, base) already; otherwise the new key is stored and header[0] = 0
+static __global__ void __launch_bounds__(64) k_fb_check(uint32_t* __restrict__ header, const uint32_t* __restrict__ base,
+                                                        uint32_t nwords, uint32_t tag, int use_cache) {
+  const uint32_t lane = threadIdx.x;
+  bool same = header[1] == tag;
+  if (lane < nwords) same = same && header[2 + lane] == base[lane];
+  const bool all = __all(same) != 0 && use_cache != 0;
+  if (!all) {
+    if (lane < nwords) header[2 + lane] = base[lane];
+    if (lane == 0) header[1] = tag;
+  }
+  if (lane == 0) header[0] = all ? 1u : 0u;
+}
+
+// the table's scalars: entry t = j * row + (m - 1) is the plain integer m 2^(wj); where that does not fit 256 bits (the
+// upper part of the top window's row, which no scalar below 2^255 reaches) the entry is 0 = the point at infinity
+static __global__ void __launch_bounds__(256) k_fb_scalars(uint32_t* __restrict__ out, int w, uint32_t entries,
+                                                           const uint32_t* __restrict__ skip) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= FB_WINDOWS * FB_ROW) return;
-  const uint32_t j = t / FB_ROW, d = t % FB_ROW + 1;
+  if (t >= entries || *skip) return;
+  const uint32_t row = 1u << (w - 1);
+  const uint32_t j = t / row, m = t % row + 1;
+  const uint32_t off = j * (uint32_t)w, word = off >> 5, sh = off & 31u;
+  const uint64_t v = (uint64_t)m << sh;
+  uint32_t o[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) out[8 * t + k] = 0;
-  out[8 * t + (j >> 2)] = d << ((j & 3) * 8);
+  for (int k = 0; k < 8; k++) o[k] = 0;
+  bool fits = word < 8;
+  if (fits) {
+    o[word] = (uint32_t)v;
+    if ((uint32_t)(v >> 32)) {
+      if (word + 1 < 8)
+        o[word + 1] = (uint32_t)(v >> 32);
+      else
+        fits = false;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) out[8 * t + k] = fits ? o[k] : 0u;
 }
 
 template <class C>
 __global__ void __launch_bounds__(64) k_fixed_base_g1(const Affine28<C>* __restrict__ table,
                                                       const uint32_t* __restrict__ scalars, int mont, size_t n,
-                                                      Affine<FpField<C>>* __restrict__ out) {
+                                                      Affine<FpField<C>>* __restrict__ out, int w) {
   typedef FpField<C> F;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -119,12 +162,14 @@ __global__ void __launch_bounds__(64) k_fixed_base_g1(const Affine28<C>* __restr
   fr_canonical<C>(s, scalars + 8 * i, mont != 0);
   XYZZ28<C> acc;
   bool inf = true;
+  const int nw = fb_windows(w);
+  uint32_t carry = 0, neg = 0;
 #pragma unroll 1
-  for (int j = 0; j < FB_WINDOWS; j++) {
-    const uint32_t d = (s[j >> 2] >> ((j & 3) * 8)) & 255u;
-    if (d) {
-      const Affine28<C> q = table[j * FB_ROW + d - 1];
-      xyzz28_madd<C>(acc, inf, q, false);
+  for (int j = 0; j < nw; j++) {
+    const uint32_t m = msm_window_digit(s, j * w, w, carry, neg);
+    if (m) {
+      const Affine28<C> q = table[((size_t)j << (w - 1)) + m - 1];
+      xyzz28_madd<C>(acc, inf, q, neg != 0);
     }
   }
   XYZZ<F> r;
@@ -136,17 +181,25 @@ __global__ void __launch_bounds__(64) k_fixed_base_g1(const Affine28<C>* __restr
 
 template <class C, class F>
 __global__ void __launch_bounds__(64) k_fixed_base(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ scalars,
-                                                   int mont, size_t n, Affine<F>* __restrict__ out) {
+                                                   int mont, size_t n, Affine<F>* __restrict__ out, int w) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
   fr_canonical<C>(s, scalars + 8 * i, mont != 0);
   XYZZ<F> acc;
   xyzz_set_inf<F>(acc);
+  const int nw = fb_windows(w);
+  uint32_t carry = 0, neg = 0;
 #pragma unroll 1
-  for (int j = 0; j < FB_WINDOWS; j++) {
-    const uint32_t d = (s[j >> 2] >> ((j & 3) * 8)) & 255u;
-    if (d) xyzz_madd_ool<F>(acc, table[j * FB_ROW + d - 1]);
+  for (int j = 0; j < nw; j++) {
+    const uint32_t m = msm_window_digit(s, j * w, w, carry, neg);
+    if (m) {
+      Affine<F> q = table[((size_t)j << (w - 1)) + m - 1];
+      typename F::T ny;
+      F::neg(ny, q.y);
+      F::select(q.y, neg != 0, ny, q.y);
+      xyzz_madd_ool<F>(acc, q);
+    }
   }
   Affine<F> a;
   xyzz_to_affine<F>(a, acc);
@@ -158,11 +211,13 @@ __global__ void __launch_bounds__(64) k_fixed_base(const Affine<F>* __restrict__
 template <class C>
 __global__ void __launch_bounds__(64) k_scalar_mul_lp(const Affine<Fp2Field<C>>* __restrict__ points, size_t point_stride,
                                                       const uint32_t* __restrict__ scalars, int mont, size_t n,
-                                                      Affine<Fp2Field<C>>* __restrict__ out) {
+                                                      Affine<Fp2Field<C>>* __restrict__ out,
+                                                      const uint32_t* __restrict__ skip = nullptr) {
   typedef Fp2LField<C> FL;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = t >> 1;  // both lanes of a pair share i and the scalar: every branch below is pair-uniform
   if (i >= n) return;
+  if (skip && *skip) return;
   const int hi = (int)(threadIdx.x & 1u);
   uint32_t s[8];
   if (mont < 0) {
@@ -215,7 +270,7 @@ __global__ void __launch_bounds__(64) k_scalar_mul_lp(const Affine<Fp2Field<C>>*
 template <class C>
 __global__ void __launch_bounds__(64) k_fixed_base_lp(const Affine<Fp2Field<C>>* __restrict__ table,
                                                       const uint32_t* __restrict__ scalars, int mont, size_t n,
-                                                      Affine<Fp2Field<C>>* __restrict__ out) {
+                                                      Affine<Fp2Field<C>>* __restrict__ out, int w) {
   typedef Fp2LField<C> FL;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = t >> 1;
@@ -225,13 +280,15 @@ __global__ void __launch_bounds__(64) k_fixed_base_lp(const Affine<Fp2Field<C>>*
   fr_canonical<C>(s, scalars + 8 * i, mont != 0);
   XYZZ<FL> acc;
   xyzz_set_inf<FL>(acc);
+  const int nw = fb_windows(w);
+  uint32_t carry = 0, neg = 0;
 #pragma unroll 1
-  for (int j = 0; j < FB_WINDOWS; j++) {
-    const uint32_t d = (s[j >> 2] >> ((j & 3) * 8)) & 255u;
-    if (d) {
+  for (int j = 0; j < nw; j++) {
+    const uint32_t m = msm_window_digit(s, j * w, w, carry, neg);  // pair-uniform
+    if (m) {
       Affine<FL> q;
-      lp_load_affine<C>(q, table, (size_t)j * FB_ROW + d - 1, hi);
-      xyzz_madd<FL>(acc, q, false);
+      lp_load_affine<C>(q, table, ((size_t)j << (w - 1)) + m - 1, hi);
+      xyzz_madd<FL>(acc, q, neg != 0);
     }
   }
   Affine<FL> r;
@@ -242,11 +299,11 @@ __global__ void __launch_bounds__(64) k_fixed_base_lp(const Affine<Fp2Field<C>>*
 }
 
 // the same on the carry-free lane-pair form (ec28_lp.h, every curve since round 3): the table converted once by
-// k_points_to28_g2, <= 32 carry-free mixed additions per scalar, one conversion back per result
+// k_points_to28_g2, one carry-free mixed addition per window, one conversion back per result
 template <class C>
 __global__ void __launch_bounds__(64) k_fixed_base_lp28(const AffineG2_28<C>* __restrict__ table,
                                                         const uint32_t* __restrict__ scalars, int mont, size_t n,
-                                                        Affine<Fp2Field<C>>* __restrict__ out) {
+                                                        Affine<Fp2Field<C>>* __restrict__ out, int w) {
   typedef Fp2LField<C> FL;
   typedef PairDevice<C> B;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,15 +314,17 @@ __global__ void __launch_bounds__(64) k_fixed_base_lp28(const AffineG2_28<C>* __
   fr_canonical<C>(s, scalars + 8 * i, mont != 0);
   XYZZ28L<Fp28<C>> acc;
   bool inf = true;
+  const int nw = fb_windows(w);
+  uint32_t carry = 0, neg = 0;
 #pragma unroll 1
-  for (int j = 0; j < FB_WINDOWS; j++) {
-    const uint32_t d = (s[j >> 2] >> ((j & 3) * 8)) & 255u;
-    if (d) {  // pair-uniform: both lanes hold the same scalar
-      const AffineG2_28<C>* e = table + ((size_t)j * FB_ROW + d - 1);
+  for (int j = 0; j < nw; j++) {
+    const uint32_t m = msm_window_digit(s, j * w, w, carry, neg);
+    if (m) {  // pair-uniform: both lanes hold the same scalar
+      const AffineG2_28<C>* e = table + (((size_t)j << (w - 1)) + m - 1);
       Affine28L<Fp28<C>> q;
       q.x = e->c[hi];
       q.y = e->c[2 + hi];
-      xyzz28_lp_madd<C, B>(acc, inf, q, false);
+      xyzz28_lp_madd<C, B>(acc, inf, q, neg != 0);
     }
   }
   XYZZ<FL> r;
@@ -297,14 +356,22 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
     fb_min = v <= 0 ? SIZE_MAX : (size_t)v;
   }
   if (point_stride == 0 && n >= fb_min) {
-    constexpr size_t kEntries = (size_t)FB_WINDOWS * FB_ROW;
     constexpr bool kG1 = std::is_same<F, FpField<C>>::value;
-    // scratch: [table | its 8160 scalars | (G1) the table in the carry-free form] in one persistent buffer per device.
+    int w = kG1 ? FB_W_G1 : FB_W_G2;
+    if (const char* e = getenv("MLHIP_FB_WINDOW")) {
+      const int v = atoi(e);
+      if (v >= FB_W_MIN && v <= FB_W_MAX) w = v;
+    }
+    const char* ce = getenv("MLHIP_FB_CACHE");
+    const int use_cache = !(ce && ce[0] == '0');
+    const size_t entries = (size_t)fb_windows(w) << (w - 1);
+    // scratch: [header | table | its scalars | the table in the carry-free form] in one persistent buffer per device.
     // Calls on different streams reuse it in the order they take the lock: each waits for the event the previous
     // one recorded after its last kernel.  (hipMallocAsync here gave intermittently wrong results on this runtime.)
-    const size_t tab_bytes = kEntries * sizeof(Affine<F>), sc_bytes = kEntries * 32;
-    const size_t t28_bytes = kG1 ? kEntries * sizeof(Affine28<C>) : kEntries * sizeof(AffineG2_28<C>);
-    const size_t need = tab_bytes + sc_bytes + t28_bytes;
+    const size_t tab_bytes = entries * sizeof(Affine<F>), sc_bytes = entries * 32;
+    const size_t t28_bytes = kG1 ? entries * sizeof(Affine28<C>) : entries * sizeof(AffineG2_28<C>);
+    const size_t need = FB_HEADER + tab_bytes + sc_bytes + t28_bytes;
+    static_assert(8 + sizeof(Affine<F>) <= FB_HEADER && sizeof(Affine<F>) / 4 <= 64, "the key fits the header and one wave");
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_fb_mu);
@@ -315,44 +382,50 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
       fb.cap = 0;
       HIPCHK(hipMalloc((void**)&fb.buf, need));
       fb.cap = need;
+      HIPCHK(hipMemset(fb.buf, 0, FB_HEADER));  // tag 0: no table yet
     }
     if (!fb.last)
       HIPCHK(hipEventCreateWithFlags(&fb.last, hipEventDisableTiming));
     else
       HIPCHK(hipStreamWaitEvent(st, fb.last, 0));
-    char* scratch = fb.buf;
+    uint32_t* header = (uint32_t*)fb.buf;
+    char* scratch = fb.buf + FB_HEADER;
     Affine<F>* table = (Affine<F>*)scratch;
     uint32_t* tsc = (uint32_t*)(scratch + tab_bytes);
-    k_fb_scalars<<<dim3((unsigned)((kEntries + 255) / 256)), dim3(256), 0, st>>>(tsc);
+    // what the table depends on beside the base: curve, group, width, and which kernel built it (the one-lane G2 kernel
+    // and the lane-pair one give the same bytes; the bit only keeps an A/B honest)
+    const uint32_t tag = 0x80000000u | ((uint32_t)C::ID << 16) | ((kG1 ? 1u : 2u) << 8) | (uint32_t)w | (one_lane ? 0x4000u : 0u);
+    k_fb_check<<<dim3(1), dim3(64), 0, st>>>(header, (const uint32_t*)d_points, (uint32_t)(sizeof(Affine<F>) / 4), tag, use_cache);
+    k_fb_scalars<<<dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st>>>(tsc, w, (uint32_t)entries, header);
     if constexpr (!kG1) {
       if (!one_lane)
-        k_scalar_mul_lp<C><<<dim3((unsigned)((2 * kEntries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc,
-                                                                                         -1, kEntries, table);
+        k_scalar_mul_lp<C><<<dim3((unsigned)((2 * entries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc,
+                                                                                        -1, entries, table, header);
       else
-        k_scalar_mul<C, F><<<dim3((unsigned)((kEntries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
-                                                                                        kEntries, table);
+        k_scalar_mul<C, F><<<dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
+                                                                                       entries, table, header);
     } else {
-      k_scalar_mul<C, F><<<dim3((unsigned)((kEntries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
-                                                                                      kEntries, table);
+      k_scalar_mul<C, F><<<dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
+                                                                                     entries, table, header);
     }
     if constexpr (kG1) {
       Affine28<C>* t28 = (Affine28<C>*)(scratch + tab_bytes + sc_bytes);
-      k_points_to28<C><<<dim3((unsigned)((kEntries + 255) / 256)), dim3(256), 0, st>>>(table, kEntries, t28);
+      k_points_to28<C><<<dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st>>>(table, entries, t28);
       k_fixed_base_g1<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(t28, (const uint32_t*)d_scalars, mont, n,
-                                                                             (Affine<F>*)d_out);
+                                                                             (Affine<F>*)d_out, w);
     } else {
       const char* a32 = getenv("MLHIP_ACC32");  // =1: the boundary-form lane-pair kernel (second implementation)
       if (!one_lane && !(a32 && a32[0] == '1')) {
         AffineG2_28<C>* t28 = (AffineG2_28<C>*)(scratch + tab_bytes + sc_bytes);
-        k_points_to28_g2<C><<<dim3((unsigned)((4 * kEntries + 255) / 256)), dim3(256), 0, st>>>(table, kEntries, t28);
+        k_points_to28_g2<C><<<dim3((unsigned)((4 * entries + 255) / 256)), dim3(256), 0, st>>>(table, entries, t28);
         k_fixed_base_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>(t28, (const uint32_t*)d_scalars, mont, n,
-                                                                                    (Affine<F>*)d_out);
+                                                                                    (Affine<F>*)d_out, w);
       } else if (!one_lane)
         k_fixed_base_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
-                                                                                  (Affine<F>*)d_out);
+                                                                                  (Affine<F>*)d_out, w);
       else
         k_fixed_base<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
-                                                                             (Affine<F>*)d_out);
+                                                                             (Affine<F>*)d_out, w);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(fb.last, st));

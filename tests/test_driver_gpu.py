@@ -156,7 +156,7 @@ def test_scalar_mul_batch_kernel(curve, mlhip, one_lane, monkeypatch):
 
 
 def test_fixed_base_table_path(curve, mlhip, monkeypatch):
-    """One base, many scalars: the table path (normally from 2^17 scalars on) forced at n = 300, against the oracle and
+    """One base, many scalars: the table path (normally from 2^12 scalars on) forced at n = 300, against the oracle and
     the double-and-add kernel -- scalars with zero bytes, 0, 1, r - 1, a base outside the r-torsion subgroup of G1
     (the table must not reduce its multiples mod r) and the point at infinity as base."""
     import ctypes
@@ -207,6 +207,33 @@ def test_fixed_base_table_path(curve, mlhip, monkeypatch):
     out = ctypes.create_string_buffer(c.g1_bytes * n)
     mlhip.check(lib.mlhip_scalar_mul(c.id, 1, bytes(c.g1_bytes), 0, sc, 0, n, out))
     assert out.raw == bytes(c.g1_bytes * n)
+    # the table stays on the device with its base as the key: the same base again (no build), another base (rebuilt), the
+    # first one again, the other group in between; every window width; MLHIP_FB_CACHE=0 = a build per call
+    ks2 = ks + [(1 << 255) % c.r, c.r // 2, c.r // 2 + 1, (1 << 252) - 1] + [((1 << w) - 1) << (5 * w) for w in (8, 11, 12, 13)]
+    sc2 = b"".join(k.to_bytes(32, "little") for k in ks2)
+    n2 = len(ks2)
+    other = cref.point_mul(c.id, 1, c.GenG1().raw, 12345)
+    want = {}
+    monkeypatch.setenv("MLHIP_FIXED_BASE_MIN", "0")
+    for name, group, base, size in (("g", 1, c.GenG1().raw, c.g1_bytes), ("h", 1, other, c.g1_bytes), ("g2", 2, c._gen_g2.raw, c.g2_bytes)):
+        out = ctypes.create_string_buffer(size * n2)
+        mlhip.check(lib.mlhip_scalar_mul(c.id, group, base, 0, sc2, 0, n2, out))
+        want[name] = (group, base, size, out.raw)
+    for i in (n - 1, n2 - 8, n2 - 7, n2 - 6, n2 - 1):
+        assert want["g"][3][i * c.g1_bytes : (i + 1) * c.g1_bytes] == cref.point_mul(c.id, 1, c.GenG1().raw, ks2[i])
+    monkeypatch.setenv("MLHIP_FIXED_BASE_MIN", "1")
+    for width, cache in ((None, None), ("4", None), ("8", None), ("13", None), ("14", None), (None, "0")):
+        if width:
+            monkeypatch.setenv("MLHIP_FB_WINDOW", width)
+        if cache:
+            monkeypatch.setenv("MLHIP_FB_CACHE", cache)
+        for name in ("g", "g", "h", "g", "g2", "g2", "g", "h", "h"):
+            group, base, size, expect = want[name]
+            out = ctypes.create_string_buffer(size * n2)
+            mlhip.check(lib.mlhip_scalar_mul(c.id, group, base, 0, sc2, 0, n2, out))
+            assert out.raw == expect, (name, width, cache)
+        monkeypatch.delenv("MLHIP_FB_WINDOW", raising=False)
+        monkeypatch.delenv("MLHIP_FB_CACHE", raising=False)
 
 
 def test_runPowTest_gt_exp(curve):

@@ -39,7 +39,7 @@ for name in ("BLS12-381", "BN254", "BLS12-377"):
     g = load_golden(name)
     cid = g["curve_id"]
     fpb, g1b, g2b, gtb = _lib.sizes(cid)
-    for group, size, key, lgs in ((1, g1b, "g1_gen", (17, 20)), (2, g2b, "g2_gen", (17, 20))):
+    for group, size, key, lgs in ((1, g1b, "g1_gen", (12, 17, 20)), (2, g2b, "g2_gen", (12, 17, 20))):
         base = torch.frombuffer(bytearray(bytes.fromhex(g[key])), dtype=torch.uint8).to(dev)
         for lg in lgs:
             n = 1 << lg
@@ -47,9 +47,28 @@ for name in ("BLS12-381", "BN254", "BLS12-377"):
             P = torch.empty(n * size, dtype=torch.uint8, device=dev)
             Q = torch.empty(n * size, dtype=torch.uint8, device=dev)
             os.environ.pop("MLHIP_FIXED_BASE_MIN", None)
-            t_tab = timed(lambda: _lib.check(lib.mlhip_scalar_mul_device(cid, group, base.data_ptr(), 0, S.data_ptr(), 0, n, P.data_ptr(), st)))
+            run = lambda: _lib.check(lib.mlhip_scalar_mul_device(cid, group, base.data_ptr(), 0, S.data_ptr(), 0, n, P.data_ptr(), st))  # noqa: E731
+            os.environ["MLHIP_FB_CACHE"] = "0"
+            t_build = timed(run)
+            os.environ.pop("MLHIP_FB_CACHE", None)
+            run()
+            t_tab = timed(run)
             os.environ["MLHIP_FIXED_BASE_MIN"] = "0"
             t_dbl = timed(lambda: _lib.check(lib.mlhip_scalar_mul_device(cid, group, base.data_ptr(), 0, S.data_ptr(), 0, n, Q.data_ptr(), st)), reps=2)
-            print("%s G%d one base, 2^%d scalars: table path %.2f ms (%.3e /s) | double-and-add %.2f ms | same bytes: %s" % (
-                name, group, lg, t_tab * 1e3, n / t_tab, t_dbl * 1e3, bool(torch.equal(P, Q))), flush=True)
+            print("%s G%d one base, 2^%d scalars: table path %.2f ms with the table built in the call, %.2f ms (%.3e /s) with the table of an earlier call | double-and-add %.2f ms | same bytes: %s" % (
+                name, group, lg, t_build * 1e3, t_tab * 1e3, n / t_tab, t_dbl * 1e3, bool(torch.equal(P, Q))), flush=True)
+            os.environ.pop("MLHIP_FIXED_BASE_MIN", None)
+            if lg == 20 and name == "BLS12-381":  # the window width (MLHIP_FB_WINDOW; default 12)
+                line = []
+                for w in ((8, 10, 11, 12, 13) if group == 1 else (8, 10, 11, 12)):
+                    os.environ["MLHIP_FB_WINDOW"] = str(w)
+                    os.environ["MLHIP_FB_CACHE"] = "0"
+                    tb = timed(run)
+                    os.environ.pop("MLHIP_FB_CACHE", None)
+                    run()
+                    tc = timed(run)
+                    line.append("w=%d: %.2f / %.2f ms" % (w, tb * 1e3, tc * 1e3))
+                    assert torch.equal(P, Q)
+                os.environ.pop("MLHIP_FB_WINDOW", None)
+                print("    window widths (built in the call / kept): " + "   ".join(line), flush=True)
     os.environ.pop("MLHIP_FIXED_BASE_MIN", None)

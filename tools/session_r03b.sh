@@ -18,5 +18,6 @@ else
   python3 tools/perf_small_msm.py > gpurun_out/r03y/small_msm.txt 2>&1
   python3 tools/perf_pairing.py BLS12-381 > gpurun_out/r03y/pairing_phases.txt 2>&1
   python3 tools/perf_latency.py > gpurun_out/r03y/latency.txt 2>&1 || true
+  python3 tools/perf_scalar_mul.py > gpurun_out/r03y/scalar_mul.txt 2>&1 || true
 fi
 echo all-done
