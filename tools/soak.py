@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak against the C oracle: MSMs (all curves, G1 and G2, random n / window / scalar widths, duplicated
-and negated points, infinities) device-resident plans (one pass / tiles / the shared-scalar G1+G2 launch) and pairing batches, for a given number of
+and negated points, infinities), fixed-base batched Mul (random window width, kept / rebuilt tables), device-resident plans (one pass / tiles / the shared-scalar G1+G2 launch) and pairing batches, for a given number of
 seconds.  Prints a progress line every
 20 s; exits non-zero on the first mismatch."""
 import ctypes
@@ -31,7 +31,33 @@ while time.time() - t0 < budget:
     cid = g["curve_id"]
     fpb, g1b, g2b, gtb = _lib.sizes(cid)
     r_order = int(g["r"], 16)
-    if rnd.random() < 0.8:
+    if rnd.random() < 0.12:
+        # one base, many scalars (mlhip_scalar_mul, stride 0): the fixed-base table path with a random window width, the table
+        # of an earlier call kept or rebuilt, one of three bases per curve and group so that calls hit and miss the kept table
+        group = 2 if rnd.random() < 0.35 else 1
+        sz = g1b if group == 1 else g2b
+        gen = bytes.fromhex(g["g1_gen" if group == 1 else "g2_gen"])
+        base = gen if rnd.random() < 0.5 else cref.point_mul(cid, group, gen, rnd.choice([2, 0xABCDEF]))
+        n = rnd.choice([1, 2, 63, 64, 65, 300, 1000, 4097])
+        bits = rnd.choice([8, 64, 200, 253, 256])
+        vals = [rnd.getrandbits(bits) % r_order for _ in range(n)]
+        vals[rnd.randrange(n)] = rnd.choice([0, 1, r_order - 1, r_order // 2 + 1])
+        os.environ["MLHIP_FIXED_BASE_MIN"] = "1"
+        w = rnd.choice([None, None, 4, 7, 8, 10, 11, 13, 14])
+        if w:
+            os.environ["MLHIP_FB_WINDOW"] = str(w)
+        if rnd.random() < 0.25:
+            os.environ["MLHIP_FB_CACHE"] = "0"
+        out = ctypes.create_string_buffer(sz * n)
+        _lib.check(lib.mlhip_scalar_mul(cid, group, base, 0, b"".join(v.to_bytes(32, "little") for v in vals), 0, n, out))
+        for k in ("MLHIP_FIXED_BASE_MIN", "MLHIP_FB_WINDOW", "MLHIP_FB_CACHE"):
+            os.environ.pop(k, None)
+        for i in {0, n - 1, rnd.randrange(n), rnd.randrange(n)}:
+            if out.raw[i * sz : (i + 1) * sz] != cref.point_mul(cid, group, base, vals[i]):
+                print("MISMATCH fixed-base mul", name, group, n, i, "window", w, "seed", seed, flush=True)
+                sys.exit(1)
+        done["fixed_base"] = done.get("fixed_base", 0) + 1
+    elif rnd.random() < 0.8:
         group = 2 if rnd.random() < 0.25 else 1
         sz = g1b if group == 1 else g2b
         n = rnd.choice([1, 2, 5, 33, 100, 257, 1000, 1025, 3000, 5000, 20000, 70000, 300000]) if rnd.random() < 0.7 else rnd.randrange(1, 40000)
