@@ -266,6 +266,119 @@ func (c *Curve) PairingBatch(g2s []driver.G2, g1s []driver.G1) []driver.Gt {
 	return out
 }
 
+// MulBatchG1 returns a[i].Mul(b[i]) for every i with one kernel launch (the batched form of G1.Mul,
+// bls12-381.go:238-247; SURVEY.md 8f row 3).
+func (c *Curve) MulBatchG1(a []driver.G1, b []driver.Zr) []driver.G1 {
+	n := len(a)
+	if len(b) != n {
+		panic("hip: MulBatchG1 length mismatch")
+	}
+	if n == 0 {
+		return nil
+	}
+	points := make([]bls12381.G1Affine, n)
+	for i := range a {
+		points[i] = a[i].(*gurvy381.G1).G1Affine
+	}
+	return c.scalarMulG1(points, 1, b)
+}
+
+// BaseMulBatchG1 returns base.Mul(b[i]) for every i: one base (a generator, a Pedersen base), many scalars.  From 2^12
+// scalars on the library multiplies through a table of the base's multiples, which it keeps on the device: later calls
+// with the same base skip the table's construction.
+func (c *Curve) BaseMulBatchG1(base driver.G1, b []driver.Zr) []driver.G1 {
+	if len(b) == 0 {
+		return nil
+	}
+	return c.scalarMulG1([]bls12381.G1Affine{base.(*gurvy381.G1).G1Affine}, 0, b)
+}
+
+func (c *Curve) scalarMulG1(points []bls12381.G1Affine, stride int, b []driver.Zr) []driver.G1 {
+	n := len(b)
+	scalars := make([]fr.Element, n)
+	for i := range b {
+		scalars[i] = gurvy381.ZrValue(b[i])
+	}
+	res := make([]bls12381.G1Affine, n)
+	check(func() C.int {
+		return C.mlhip_scalar_mul(C.MLHIP_CURVE_BLS12_381, C.MLHIP_GROUP_G1,
+			unsafe.Pointer(&points[0]), C.size_t(stride), unsafe.Pointer(&scalars[0]), 1, C.size_t(n), unsafe.Pointer(&res[0]))
+	})
+	out := make([]driver.G1, n)
+	for i := range res {
+		out[i] = &gurvy381.G1{G1Affine: res[i]}
+	}
+	return out
+}
+
+// MulBatchG2 / BaseMulBatchG2: the same for G2 (bls12-381.go:342-351).
+func (c *Curve) MulBatchG2(a []driver.G2, b []driver.Zr) []driver.G2 {
+	n := len(a)
+	if len(b) != n {
+		panic("hip: MulBatchG2 length mismatch")
+	}
+	if n == 0 {
+		return nil
+	}
+	points := make([]bls12381.G2Affine, n)
+	for i := range a {
+		points[i] = a[i].(*gurvy381.G2).G2Affine
+	}
+	return c.scalarMulG2(points, 1, b)
+}
+
+func (c *Curve) BaseMulBatchG2(base driver.G2, b []driver.Zr) []driver.G2 {
+	if len(b) == 0 {
+		return nil
+	}
+	return c.scalarMulG2([]bls12381.G2Affine{base.(*gurvy381.G2).G2Affine}, 0, b)
+}
+
+func (c *Curve) scalarMulG2(points []bls12381.G2Affine, stride int, b []driver.Zr) []driver.G2 {
+	n := len(b)
+	scalars := make([]fr.Element, n)
+	for i := range b {
+		scalars[i] = gurvy381.ZrValue(b[i])
+	}
+	res := make([]bls12381.G2Affine, n)
+	check(func() C.int {
+		return C.mlhip_scalar_mul(C.MLHIP_CURVE_BLS12_381, C.MLHIP_GROUP_G2,
+			unsafe.Pointer(&points[0]), C.size_t(stride), unsafe.Pointer(&scalars[0]), 1, C.size_t(n), unsafe.Pointer(&res[0]))
+	})
+	out := make([]driver.G2, n)
+	for i := range res {
+		out[i] = &gurvy381.G2{G2Affine: res[i]}
+	}
+	return out
+}
+
+// ExpBatch returns gts[i].Exp(b[i]) for every i with one kernel launch (Gt.Exp, bls12-381.go:399-407; SURVEY.md 8f row 2).
+func (c *Curve) ExpBatch(gts []driver.Gt, b []driver.Zr) []driver.Gt {
+	n := len(gts)
+	if len(b) != n {
+		panic("hip: ExpBatch length mismatch")
+	}
+	if n == 0 {
+		return nil
+	}
+	in := make([]bls12381.GT, n)
+	scalars := make([]fr.Element, n)
+	for i := range gts {
+		in[i] = gts[i].(*gurvy381.Gt).GT
+		scalars[i] = gurvy381.ZrValue(b[i])
+	}
+	res := make([]bls12381.GT, n)
+	check(func() C.int {
+		return C.mlhip_gt_exp(C.MLHIP_CURVE_BLS12_381, unsafe.Pointer(&in[0]), unsafe.Pointer(&scalars[0]), 1, C.size_t(n),
+			unsafe.Pointer(&res[0]))
+	})
+	out := make([]driver.Gt, n)
+	for i := range res {
+		out[i] = &gurvy381.Gt{GT: res[i]}
+	}
+	return out
+}
+
 // NewG1sFromCompressed decodes n compressed G1 points (the wire form of G1.Compressed, bls12-381.go:292-296)
 // on the device: decompression, curve check and subgroup check per point.  It is the bulk form of
 // NewG1FromCompressed (bls12-381.go:551-559) and panics like it on the first invalid encoding, with gnark's

@@ -93,6 +93,21 @@ func TestHipDevicePaths(t *testing.T) {
 	assert.Equal(t, hip.Curve.MultiScalarMul(g1s, zrs).Bytes(), bases.MultiScalarMul(zrs).Bytes())
 	assert.Equal(t, hip.Curve.MultiScalarMul(g1s[:7], zrs[:7]).Bytes(), bases.MultiScalarMul(zrs[:7]).Bytes())
 
+	// batched Mul / Gt.Exp against the embedded driver's single calls (bls12-381.go:238-247, :342-351, :399-407)
+	m1 := hip.MulBatchG1(g1s, zrs)
+	m2 := hip.MulBatchG2(g2s, zrs)
+	b1 := hip.BaseMulBatchG1(g1s[3], zrs)
+	b2 := hip.BaseMulBatchG2(g2s[3], zrs)
+	ex := hip.ExpBatch(batch, zrs)
+	for i := 0; i < n; i++ {
+		assert.True(t, m1[i].Equals(g1s[i].Mul(zrs[i])))
+		assert.True(t, m2[i].Equals(g2s[i].Mul(zrs[i])))
+		assert.True(t, b1[i].Equals(g1s[3].Mul(zrs[i])))
+		assert.True(t, b2[i].Equals(g2s[3].Mul(zrs[i])))
+		assert.Equal(t, batch[i].Exp(zrs[i]).Bytes(), ex[i].Bytes())
+	}
+	assert.Equal(t, b1[5].Bytes(), hip.BaseMulBatchG1(g1s[3], zrs)[5].Bytes()) // the second call runs on the kept table
+
 	wire := hip.G1sCompressed(g1s)
 	for i := 0; i < n; i++ {
 		assert.Equal(t, g1s[i].Compressed(), wire[i*48:(i+1)*48])

@@ -16,7 +16,7 @@
 //   Curve::FExp(gt)                      driver/math.go:56-57                         -> mlhip_final_exp
 //   G1::Mul / Mul2 / Add / Sub / Neg     driver/math.go:249-288
 //   G2::Mul / Add, Gt::Mul / Exp / IsUnity, Zr::Plus / Minus / Mul / ...             driver/math.go:191-360
-//   additive: MultiScalarMulG2, MultiScalarMulG1G2, PairingBatch, PairingProduct
+//   additive: MultiScalarMulG2, MultiScalarMulG1G2, PairingBatch, PairingProduct, MulBatch, BaseMulBatch, ExpBatch
 #pragma once
 #include <array>
 #include <cstdint>
@@ -481,6 +481,36 @@ class Curve {
     }
     return out;
   }
+  // out[i] = points[i].Mul(scalars[i]), one launch (additive; SURVEY 8f row 3: G1.Mul / G2.Mul, bls12-381.go:238-247, :342-351)
+  std::vector<G1> MulBatch(const std::vector<G1>& points, const std::vector<Zr>& scalars) const {
+    return mul_batch<G1>(MLHIP_GROUP_G1, g1_bytes, points, 1, scalars);
+  }
+  std::vector<G2> MulBatch(const std::vector<G2>& points, const std::vector<Zr>& scalars) const {
+    return mul_batch<G2>(MLHIP_GROUP_G2, g2_bytes, points, 1, scalars);
+  }
+  // out[i] = base.Mul(scalars[i]): one base, many scalars -- from 2^12 scalars on through a table of the base's multiples that
+  // the library keeps on the device for later calls with the same base
+  std::vector<G1> BaseMulBatch(const G1& base, const std::vector<Zr>& scalars) const {
+    return mul_batch<G1>(MLHIP_GROUP_G1, g1_bytes, std::vector<G1>(1, base), 0, scalars);
+  }
+  std::vector<G2> BaseMulBatch(const G2& base, const std::vector<Zr>& scalars) const {
+    return mul_batch<G2>(MLHIP_GROUP_G2, g2_bytes, std::vector<G2>(1, base), 0, scalars);
+  }
+  // out[i] = gts[i].Exp(scalars[i]), one launch (additive; SURVEY 8f row 2: Gt.Exp, bls12-381.go:399-407)
+  std::vector<Gt> ExpBatch(const std::vector<Gt>& gts, const std::vector<Zr>& scalars) const {
+    if (gts.size() != scalars.size()) throw std::invalid_argument("ExpBatch: length mismatch");
+    std::vector<Gt> out;
+    if (gts.empty()) return out;
+    Bytes in, sc, o(gt_bytes * gts.size());
+    pack(gts, scalars, in, sc);
+    check(mlhip_gt_exp(id, in.data(), sc.data(), scalars_mont ? 1 : 0, gts.size(), o.data()));
+    for (size_t i = 0; i < gts.size(); i++) {
+      Gt g = new_gt();
+      memcpy(g.raw.data(), o.data() + i * gt_bytes, gt_bytes);
+      out.push_back(g);
+    }
+    return out;
+  }
   Gt PairingProduct(const std::vector<G2>& g2s, const std::vector<G1>& g1s) const {
     if (g2s.size() != g1s.size()) throw std::invalid_argument("PairingProduct: length mismatch");
     Bytes p, q;
@@ -498,6 +528,23 @@ class Curve {
   }
 
  private:
+  template <class P>
+  std::vector<P> mul_batch(int group, size_t size, const std::vector<P>& points, size_t stride, const std::vector<Zr>& scalars) const {
+    if (stride != 0 && points.size() != scalars.size()) throw std::invalid_argument("MulBatch: length mismatch");
+    std::vector<P> out;
+    const size_t n = scalars.size();
+    if (n == 0) return out;
+    Bytes pts, sc, o(size * n);
+    pack(points, scalars, pts, sc);
+    check(mlhip_scalar_mul(id, group, pts.data(), stride, sc.data(), scalars_mont ? 1 : 0, n, o.data()));
+    for (size_t i = 0; i < n; i++) {
+      P g;
+      g.curve = this;
+      g.raw.assign(o.begin() + i * size, o.begin() + (i + 1) * size);
+      out.push_back(g);
+    }
+    return out;
+  }
   template <class P>
   void pack(const std::vector<P>& a, const std::vector<Zr>& b, Bytes& pts, Bytes& sc) const {
     for (auto& x : a) pts.insert(pts.end(), x.raw.begin(), x.raw.end());

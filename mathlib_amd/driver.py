@@ -438,6 +438,45 @@ class Curve:
         return [Gt(out.raw[i * self.gt_bytes : (i + 1) * self.gt_bytes], self) for i in range(n)]
 
 
+    def MulBatch(self, points: Sequence, scalars: Sequence[Zr]) -> list:
+        """out[i] = points[i].Mul(scalars[i]) for G1 or G2 points, one launch (additive; SURVEY 8f row 3: the batched form of
+        G1.Mul / G2.Mul, bls12-381.go:238-247, :342-351)."""
+        if len(points) != len(scalars):
+            raise ValueError("MulBatch: length mismatch")
+        n = len(points)
+        if n == 0:
+            return []
+        cls = type(points[0])
+        group, size = (GROUP_G1, self.g1_bytes) if cls is G1 else (GROUP_G2, self.g2_bytes)
+        out = ctypes.create_string_buffer(size * n)
+        check(load().mlhip_scalar_mul(self.id, group, b"".join(p.raw for p in points), 1, self._scalars(scalars),
+                                      1 if self.scalars_mont else 0, n, out))
+        return [cls(out.raw[i * size : (i + 1) * size], self) for i in range(n)]
+
+    def BaseMulBatch(self, base, scalars: Sequence[Zr]) -> list:
+        """out[i] = base.Mul(scalars[i]): one base (a generator, a Pedersen base), many scalars.  From 2^12 scalars on the
+        library multiplies through a table of the base's multiples that it keeps on the device for later calls with the
+        same base (mlhip_scalar_mul, point_stride 0)."""
+        n = len(scalars)
+        if n == 0:
+            return []
+        cls = type(base)
+        group, size = (GROUP_G1, self.g1_bytes) if cls is G1 else (GROUP_G2, self.g2_bytes)
+        out = ctypes.create_string_buffer(size * n)
+        check(load().mlhip_scalar_mul(self.id, group, base.raw, 0, self._scalars(scalars), 1 if self.scalars_mont else 0, n, out))
+        return [cls(out.raw[i * size : (i + 1) * size], self) for i in range(n)]
+
+    def ExpBatch(self, gts: Sequence[Gt], scalars: Sequence[Zr]) -> List[Gt]:
+        """out[i] = gts[i].Exp(scalars[i]), one launch (additive; SURVEY 8f row 2: Gt.Exp, bls12-381.go:399-407)."""
+        if len(gts) != len(scalars):
+            raise ValueError("ExpBatch: length mismatch")
+        n = len(gts)
+        if n == 0:
+            return []
+        out = ctypes.create_string_buffer(self.gt_bytes * n)
+        check(load().mlhip_gt_exp(self.id, b"".join(g.raw for g in gts), self._scalars(scalars), 1 if self.scalars_mont else 0, n, out))
+        return [Gt(out.raw[i * self.gt_bytes : (i + 1) * self.gt_bytes], self) for i in range(n)]
+
     def PairingProduct(self, g2s: Sequence[G2], g1s: Sequence[G1]) -> Gt:
         """FExp(prod_i Pairing(g2s[i], g1s[i])) with one shared final exponentiation (additive API)."""
         if len(g2s) != len(g1s):

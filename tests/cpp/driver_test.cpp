@@ -168,6 +168,19 @@ static void runPairingTest(const Curve& c, const G2& g2, uint64_t& st) {
   G2 sum = g2.Mul(r1);
   sum.Add(g2.Mul(r2));
   EXPECT(c.MultiScalarMulG2({g2, g2}, {r1, r2}).Equals(sum));
+  {  // batched Mul / Gt.Exp: the single calls, element by element
+    std::vector<G1> m1 = c.MulBatch(ps, {r1, r2, c.GroupOrder});
+    EXPECT(m1.size() == 3 && m1[0].Equals(ps[0].Mul(r1)) && m1[1].Equals(ps[1].Mul(r2)) && m1[2].IsInfinity());
+    std::vector<G2> m2 = c.MulBatch(qs, {r2, r1, r1});
+    EXPECT(m2.size() == 3 && m2[0].Equals(qs[0].Mul(r2)) && m2[2].Equals(qs[2].Mul(r1)));
+    std::vector<G1> b1 = c.BaseMulBatch(g1, {r1, r2, r1});
+    EXPECT(b1.size() == 3 && b1[0].Equals(g1.Mul(r1)) && b1[1].Equals(g1.Mul(r2)) && b1[2].Equals(b1[0]));
+    std::vector<G2> b2 = c.BaseMulBatch(g2, {r2});
+    EXPECT(b2.size() == 1 && b2[0].Equals(g2.Mul(r2)));
+    std::vector<Gt> e = c.ExpBatch({gengt, gengt}, {r1, c.GroupOrder});
+    EXPECT(e.size() == 2 && e[0].Equals(gengt.Exp(r1)) && e[1].IsUnity());
+    EXPECT(c.MulBatch(std::vector<G1>(), {}).empty() && c.ExpBatch({}, {}).empty());
+  }
   {  // the shared-scalar call = the two reference-shaped calls; mismatched lengths give the identities
     G1 g1 = c.GenG1();
     auto both = c.MultiScalarMulG1G2({g1, g1.Mul(r2)}, {g2, g2.Mul(r1)}, {r1, r2});

@@ -236,6 +236,29 @@ def test_fixed_base_table_path(curve, mlhip, monkeypatch):
         monkeypatch.delenv("MLHIP_FB_CACHE", raising=False)
 
 
+def test_batched_mul_and_exp_mirrors(curve):
+    """The additive batch entry points of the host mirror (MulBatch, BaseMulBatch, ExpBatch: SURVEY 8f rows 2 and 3) agree
+    with the single calls of the reference interface they batch, element by element -- G1 and G2, infinity and r among them."""
+    c = curve
+    n = 9
+    zs = [c.NewRandomZr(c._rng) for _ in range(n - 2)] + [c.NewZrFromInt(0), c.NewZrFromInt(1)]
+    p1 = [c.GenG1().Mul(c.NewRandomZr(c._rng)) for _ in range(n - 1)] + [c.NewG1()]
+    p2 = [c.GenG2().Mul(c.NewRandomZr(c._rng)) for _ in range(n - 1)] + [c.NewG2()]
+    for pts in (p1, p2):
+        got = c.MulBatch(pts, zs)
+        assert len(got) == n and all(got[i].Equals(pts[i].Mul(zs[i])) for i in range(n))
+        fixed = c.BaseMulBatch(pts[2], zs)
+        assert len(fixed) == n and all(fixed[i].Equals(pts[2].Mul(zs[i])) for i in range(n))
+        assert [x.raw for x in c.BaseMulBatch(pts[2], zs)] == [x.raw for x in fixed]
+    gt = c.GenGt()
+    gts = [gt.Exp(z) for z in zs[:4]]
+    ex = c.ExpBatch(gts, zs[4:8])
+    assert all(ex[i].Equals(gts[i].Exp(zs[4 + i])) for i in range(4))
+    assert c.MulBatch([], []) == [] and c.BaseMulBatch(c.GenG1(), []) == [] and c.ExpBatch([], []) == []
+    with pytest.raises(ValueError):
+        c.MulBatch(p1, zs[:3])
+
+
 def test_runPowTest_gt_exp(curve):
     """math_test.go:390-421: e(g2, g1)^r == e(g2^r, g1) == e(g2, g1^r), through Gt.Exp"""
     c = curve
