@@ -110,18 +110,27 @@ struct FixedBaseScratch {
 static std::mutex g_fb_mu;
 static FixedBaseScratch g_fb[64];  // per device
 
-// header[0] = 1 iff the buffer holds the table of this (tag, base) already; otherwise the new key is stored and header[0] = 0
+// header[0] = 1 iff the buffer holds the table of this (tag, base) already; otherwise header[0] = 0 and the tag is cleared
+// until k_fb_commit, queued behind the kernels that build the table, stores the new key -- a call that fails between the
+// two leaves no key, so the next one builds again
 static __global__ void __launch_bounds__(64) k_fb_check(uint32_t* __restrict__ header, const uint32_t* __restrict__ base,
                                                         uint32_t nwords, uint32_t tag, int use_cache) {
   const uint32_t lane = threadIdx.x;
   bool same = header[1] == tag;
   if (lane < nwords) same = same && header[2 + lane] == base[lane];
   const bool all = __all(same) != 0 && use_cache != 0;
-  if (!all) {
-    if (lane < nwords) header[2 + lane] = base[lane];
-    if (lane == 0) header[1] = tag;
+  if (lane == 0) {
+    header[0] = all ? 1u : 0u;
+    if (!all) header[1] = 0u;
   }
-  if (lane == 0) header[0] = all ? 1u : 0u;
+}
+static __global__ void __launch_bounds__(64) k_fb_commit(uint32_t* __restrict__ header, const uint32_t* __restrict__ base,
+                                                         uint32_t nwords, uint32_t tag) {
+  if (header[0]) return;  // the table was there already
+  const uint32_t lane = threadIdx.x;
+  if (lane < nwords) header[2 + lane] = base[lane];
+  __syncthreads();
+  if (lane == 0) header[1] = tag;
 }
 
 // the table's scalars: entry t = j * row + (m - 1) is the plain integer m 2^(wj); where that does not fit 256 bits (the
@@ -408,6 +417,7 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
       k_scalar_mul<C, F><<<dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
                                                                                      entries, table, header);
     }
+    k_fb_commit<<<dim3(1), dim3(64), 0, st>>>(header, (const uint32_t*)d_points, (uint32_t)(sizeof(Affine<F>) / 4), tag);
     if constexpr (kG1) {
       Affine28<C>* t28 = (Affine28<C>*)(scratch + tab_bytes + sc_bytes);
       k_points_to28<C><<<dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st>>>(table, entries, t28);
