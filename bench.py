@@ -557,6 +557,33 @@ def main() -> None:
                 extra["pairings_per_s_bn254"] = npair / (statistics.median(tb[1:]) * 1e-3)
                 del bp, bq, bgt_out
 
+        # ---- batched G1.Mul beside the MSM headline (north_star's double-and-add kernel): one base per scalar
+        # (signed 4-bit windows, 2^17 products) and one base for all scalars (fixed-base table, 2^20 products, the table of the
+        # generator still on the device from the input generation or built by the first of these calls)
+        if args.config == 2 and rank == 0 and not args.no_pairing and not args.kernels_only:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nm = min(n, 1 << 17)
+            gen1 = torch.frombuffer(bytearray(curve.GenG1().raw), dtype=torch.uint8).to(dev)
+            dst = torch.empty(n * g1b, dtype=torch.uint8, device=dev)
+            times = {"per_point": [], "one_base": []}
+            for _ in range(3):
+                ev0.record()
+                _lib.check(lib.mlhip_scalar_mul_device(CURVE, G1, points[G1].data_ptr(), 1, scalars.data_ptr(), 0, nm, dst.data_ptr(), stream))
+                ev1.record()
+                torch.cuda.synchronize()
+                times["per_point"].append(ev0.elapsed_time(ev1))
+                ev0.record()
+                _lib.check(lib.mlhip_scalar_mul_device(CURVE, G1, gen1.data_ptr(), 0, scalars.data_ptr(), 0, n, dst.data_ptr(), stream))
+                ev1.record()
+                torch.cuda.synchronize()
+                times["one_base"].append(ev0.elapsed_time(ev1))
+            extra["batched_g1_mul"] = {
+                "per_point_bases_muls_per_s": nm / (min(times["per_point"][1:]) * 1e-3), "per_point_bases_n": nm,
+                "one_base_muls_per_s": n / (min(times["one_base"][1:]) * 1e-3), "one_base_n": n,
+                "one_base_ms": {"first_call": times["one_base"][0], "later_calls_min": min(times["one_base"][1:])},
+            }
+            del dst
+
     steps_n = max(args.steps, 1)
     value = units_per_step * args.steps / elapsed
     if step_ms:
