@@ -53,7 +53,8 @@ from mathlib_amd.driver import Curve  # noqa: E402
 G1, G2 = _lib.GROUP_G1, _lib.GROUP_G2
 WINDOW_C = 16
 N_PAIRINGS = 1 << 16
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_MEASURED_GBS = 6290.0  # the same guide's measured copy rate (BASELINE.md section 4 asks for both denominators)
 INT_MAC_PEAK = 3.19e13  # measured v_mad_u64_u32 lane-ops/s, profiles/r01_ubench_int.txt
 PAIRING_BYTES_PER_UNIT = 864  # 96 + 192 in, 576 out
 
@@ -217,6 +218,7 @@ def main() -> None:
     extra = {}
     phase = {}
     step_ms = []
+    exchange_ms = []  # per timed step: the all-gather of the partial sums + the local EC additions (N > 1 only)
     res = {}
 
     # =============================================================== config 3: the pairing batch is the step
@@ -256,6 +258,7 @@ def main() -> None:
         roofline = {
             "bound": "hbm", "kernel": "k_pairing_lp28<Bls381,2,1> (fused Miller loop + final exponentiation, one pairing per lane pair, carry-free 28-bit limbs)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "peak_measured": HBM_MEASURED_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,
             "traffic": None, "avg_kernel_ms": kernel_ms,
             "note": "864 algorithmic bytes per pairing; the kernel is integer-issue bound (DESIGN.md section 4)",
         }
@@ -302,7 +305,10 @@ def main() -> None:
                 if record:
                     for kname, v in plans[(slot, g)].timings().items():
                         phase[(g, kname)] = phase.get((g, kname), 0.0) + v
+            tx = time.perf_counter()
             totals = mdist.combine_many(CURVE, parts, dev)  # one all-gather (RCCL) + local EC adds; identity at N = 1
+            if record:
+                exchange_ms.append((time.perf_counter() - tx) * 1e3)
             return dict(zip(groups, totals))
 
         def run_sequential(k, record):
@@ -381,7 +387,8 @@ def main() -> None:
         achieved = bytes_unit * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         roofline = {
             "bound": "hbm", "kernel": acc_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": acc_ms / tiles,
+            "frac": achieved / HBM_PEAK_GBS, "peak_measured": HBM_MEASURED_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,
+            "traffic": None, "avg_kernel_ms": acc_ms / tiles,
             "algorithmic_bytes_per_launch": bytes_unit * n // tiles, "launches_per_msm": tiles,
             "phase_ms": {("g1_" if g == G1 else "g2_") + k_: v for (g, k_), v in sorted(phase_avg.items()) if k_ not in ("tiles", "edwards")},
         }
@@ -534,7 +541,10 @@ def main() -> None:
             extra["pairing_roofline"] = {
                 "bound": "hbm", "achieved": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "peak_measured": HBM_MEASURED_GBS, "frac_of_measured_peak": PAIRING_BYTES_PER_UNIT * npair / (best * 1e-3) / 1e9 / HBM_MEASURED_GBS,
+                "kernel": "k_pairing_lp28<Bls381,2,1>",
             }
+            extra["pairing_roofline"]["traffic"], extra["pairing_roofline"]["traffic_note"] = _pmc(3, "k_pairing_lp28<Bls381, 2")
             # the north star names BN254 beside BLS12-381: the same batch on that curve (P_i = [k_i]G1, Q_i = [k_i]G2 made on the
             # device), rank 0 only, never part of `value`
             if rank == 0:
@@ -556,6 +566,24 @@ def main() -> None:
                     tb.append(ev0.elapsed_time(ev1))
                 extra["pairings_per_s_bn254"] = npair / (statistics.median(tb[1:]) * 1e-3)
                 del bp, bq, bgt_out
+                # ... and the G1 MSM of this config's size on BN254 (driver/gurvy/bn254.go:232-245): 2^20 pairs, c = 16, inputs
+                # resident, one MSM in flight -- the protocol of `value`, never part of it
+                base = torch.frombuffer(bytearray(bytes.fromhex(gbn["g1_gen"])), dtype=torch.uint8).to(dev)
+                bpts = torch.empty(n * bg1, dtype=torch.uint8, device=dev)
+                _lib.check(lib.mlhip_scalar_mul_device(bn, G1, base.data_ptr(), 0, seeded_scalars(n_total, lo, hi, seed * 3 + 7, dev).data_ptr(), 0, n, bpts.data_ptr(), stream))
+                torch.cuda.synchronize()
+                bplan = _lib.MsmPlan(bn, G1, n, WINDOW_C)
+                tm = []
+                for _ in range(6):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    bplan.launch(bpts.data_ptr(), scalars.data_ptr(), n, False, stream)
+                    bplan.finish()
+                    tm.append((time.perf_counter() - t1) * 1e3)
+                bplan.close()
+                extra["bn254_g1_msm"] = {"pairs": n, "window_c": WINDOW_C, "ms_per_msm_median": statistics.median(tm[1:]), "ms_per_msm_min": min(tm[1:]),
+                                         "scalar_muls_per_s": n / (statistics.median(tm[1:]) * 1e-3), "algorithmic_bytes_per_scalar_mul": MSM_BYTES[(bn, G1)]}
+                del bpts
 
         # ---- batched G1.Mul beside the MSM headline (north_star's double-and-add kernel): one base per scalar
         # (signed 4-bit windows, 2^17 products) and one base for all scalars (fixed-base table, 2^20 products, the table of the
@@ -590,6 +618,28 @@ def main() -> None:
         extra["ms_per_step_median"] = statistics.median(step_ms)
         extra["ms_per_step_min"] = min(step_ms)
         extra["ms_per_step_max"] = max(step_ms)
+    if world > 1:
+        # where an N > 1 line's efficiency went: every rank's own median step and, within it, the exchange (all-gather of
+        # the 96 / 192-byte partial sums over RCCL + the local EC additions; it also absorbs the wait for the slowest rank)
+        # and the kernels' device time -- one all_gather_object after the timed region
+        import torch.distributed as dist
+
+        mine = {"rank": rank, "ms_per_step_median": statistics.median(step_ms) if step_ms else None,
+                "exchange_ms_median": statistics.median(exchange_ms) if exchange_ms else None,
+                "exchange_ms_max": max(exchange_ms) if exchange_ms else None,
+                "device_ms_per_step": sum(v for (g, k_), v in phase.items() if k_ == "device_total") / steps_n if phase else None}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        if rank == 0:
+            med = [r["ms_per_step_median"] for r in allr if r["ms_per_step_median"] is not None]
+            exm = [r["exchange_ms_median"] for r in allr if r["exchange_ms_median"] is not None]
+            exx = [r["exchange_ms_max"] for r in allr if r["exchange_ms_max"] is not None]
+            dvm = [r["device_ms_per_step"] for r in allr if r["device_ms_per_step"] is not None]
+            extra["per_rank_ms_per_step"] = {"min": min(med), "max": max(med), "all": med} if med else None
+            extra["exchange_ms"] = {"median": statistics.median(exm), "max": max(exx), "per_rank_median": exm,
+                                    "what": "perf_counter around mathlib_amd.dist.combine_many in every timed step: H2D of the partials, "
+                                            "ONE all-gather, D2H, the local EC additions on the host; includes waiting for the slowest rank"} if exm else None
+            extra["per_rank_device_ms_per_step"] = {"min": min(dvm), "max": max(dvm)} if dvm else None
 
     # ---- CPU baseline: the oracle's C restatement on a bounded sample of the same workload, host cores of this box
     cpu_baseline = None
@@ -690,7 +740,7 @@ def _pmc(config: int, kernel_prefix: str):
     when the kernels have changed since, the figure is withheld rather than quoted for code it was not measured on."""
     from mathlib_amd.build import source_hash
 
-    for name in ("r03_pmc_traffic.json",):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pm = json.load(f)

@@ -39,6 +39,10 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the functions declared here with MLHIP_API are its whole dynamic
+ * symbol table (tests/test_abi.py compares `nm -D --defined-only` with this header). */
+#define MLHIP_API __attribute__((visibility("default")))
+
 #define MLHIP_CURVE_BN254 0
 #define MLHIP_CURVE_BLS12_381 1
 #define MLHIP_CURVE_BLS12_377 2
@@ -53,14 +57,14 @@ extern "C" {
 #define MLHIP_GROUP_G2 2
 
 /* ---- library / device ---------------------------------------------------------------------- */
-int mlhip_version(void);
-const char* mlhip_last_error(void);
-int mlhip_device_count(int* count);
+MLHIP_API int mlhip_version(void);
+MLHIP_API const char* mlhip_last_error(void);
+MLHIP_API int mlhip_device_count(int* count);
 /* Pins the calling thread's subsequent calls to one device (-1 undoes it: the thread follows the process's device
  * list again, whose first entry -- device 0 when there is no list -- serves calls that are not spread).  Nothing
  * touches the GPU before the first compute call (the reference computes GenGt at package init, math.go:142-255:
  * importing the backend must not need a GPU). */
-int mlhip_set_device(int device);
+MLHIP_API int mlhip_set_device(int device);
 
 /* ---- several devices in one process (one host thread per device, the ABI takes a device list) ------
  * mlhip_init sets the process's device list (n_devices = 0: every visible device; the environment variable
@@ -79,16 +83,16 @@ int mlhip_set_device(int device);
  * with MLHIP_EINVAL instead of silently running on device 0.
  * STATUS: spreading is opt-in (nothing is spread unless the caller lists two or more devices) and has so far run only
  * on lists that repeat device 0 of a one-GPU box (tests/test_multi_device.py); see DESIGN.md section 5. */
-int mlhip_init(const int* devices, int n_devices);
-int mlhip_get_devices(int* devices, int cap); /* returns the length of the list, or MLHIP_EINVAL (malformed MLHIP_DEVICES) */
+MLHIP_API int mlhip_init(const int* devices, int n_devices);
+MLHIP_API int mlhip_get_devices(int* devices, int cap); /* returns the length of the list, or MLHIP_EINVAL (malformed MLHIP_DEVICES) */
 /* frees every cached plan / arena and forgets the device list; the next call reads MLHIP_DEVICES again */
-int mlhip_shutdown(void);
+MLHIP_API int mlhip_shutdown(void);
 /* The same MSM with an explicit device list, whatever its size (group: MLHIP_GROUP_G1 / _G2). */
-int mlhip_msm_multi(int curve, int group, const int* devices, int n_devices, const void* points, const void* scalars,
+MLHIP_API int mlhip_msm_multi(int curve, int group, const int* devices, int n_devices, const void* points, const void* scalars,
                     int scalars_mont, size_t n, int window_c, void* out_affine);
 
 /* sizes in bytes for a curve: Fp element, G1 affine, G2 affine, Gt, scalar (always 32) */
-int mlhip_sizes(int curve, size_t* fp, size_t* g1, size_t* g2, size_t* gt);
+MLHIP_API int mlhip_sizes(int curve, size_t* fp, size_t* g1, size_t* g2, size_t* gt);
 
 /* ---- host-buffer entry points (what the cgo shim binds) ------------------------------------- */
 /* out = sum_i [scalars[i]] points[i].  window_c = 0 picks a window from n; BASELINE config 2 uses 16.
@@ -97,61 +101,61 @@ int mlhip_sizes(int curve, size_t* fp, size_t* g1, size_t* g2, size_t* gt);
  * segments of 2^18 (2^17) pairs: upload of one segment under the kernels of the one before;
  * MLHIP_STREAM_SEGMENTS=K fixes the count, 0 = one pass.  Smaller calls upload the points beside the sort of the
  * scalars. */
-int mlhip_msm_g1(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
+MLHIP_API int mlhip_msm_g1(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
                  void* out_affine);
-int mlhip_msm_g2(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
+MLHIP_API int mlhip_msm_g2(int curve, const void* points, const void* scalars, int scalars_mont, size_t n, int window_c,
                  void* out_affine);
 /* out_g1 = sum_i [scalars[i]] points_g1[i] and out_g2 = sum_i [scalars[i]] points_g2[i] over ONE scalar vector
  * (additive: BASELINE configs[3]; in the reference's terms MultiScalarMul(a1, b), driver/gurvy/bls12381/bls12-381.go:766-783,
  * and the G2 sum of g2.Mul(b[i]), :342-358, over the same b): the scalars travel and are sorted once, both groups
  * accumulate from the same entry lists.  Same results as mlhip_msm_g1 + mlhip_msm_g2. */
-int mlhip_msm_g1g2(int curve, const void* points_g1, const void* points_g2, const void* scalars, int scalars_mont, size_t n,
+MLHIP_API int mlhip_msm_g1g2(int curve, const void* points_g1, const void* points_g2, const void* scalars, int scalars_mont, size_t n,
                    int window_c, void* out_g1, void* out_g2);
 
 /* out[k] = prod_{j < pairs_per_product} MillerLoop(g1[k*ppp + j], g2[k*ppp + j]); Pairing = 1, Pairing2 = 2
  * (pairs_per_product <= 4).  Pairs holding an infinity contribute 1.  NOT final-exponentiated: like gurvy's
  * Pairing the value is only meaningful after mlhip_final_exp. */
-int mlhip_miller_loop(int curve, const void* g1, const void* g2, size_t pairs_per_product, size_t n_products,
+MLHIP_API int mlhip_miller_loop(int curve, const void* g1, const void* g2, size_t pairs_per_product, size_t n_products,
                       void* out_gt);
 /* out[i] = in[i]^(k (p^12-1)/r), k = 3 (BLS12 curves) or 2x(6x^2+3x+1) (BN254): gnark's and kilic's value */
-int mlhip_final_exp(int curve, const void* in_gt, size_t n, void* out_gt);
+MLHIP_API int mlhip_final_exp(int curve, const void* in_gt, size_t n, void* out_gt);
 /* out[i] = FExp(Pairing(g2[i], g1[i])) */
-int mlhip_pairing_batch(int curve, const void* g1, const void* g2, size_t n, void* out_gt);
+MLHIP_API int mlhip_pairing_batch(int curve, const void* g1, const void* g2, size_t n, void* out_gt);
 /* out[i] = a[i] * b[i] in Gt (Gt.Mul, driver/gurvy/bls12381/bls12-381.go:417-419), element-wise over n */
-int mlhip_gt_mul(int curve, const void* a_gt, const void* b_gt, size_t n, void* out_gt);
+MLHIP_API int mlhip_gt_mul(int curve, const void* a_gt, const void* b_gt, size_t n, void* out_gt);
 
 /* out[i] = in[i]^(scalars[i]) in Gt (Gt.Exp, driver/gurvy/bls12381/bls12-381.go:399-407), element-wise over n;
  * valid for any Gt value.  Scalars as for the MSM entry points. */
-int mlhip_gt_exp(int curve, const void* in_gt, const void* scalars, int scalars_mont, size_t n, void* out_gt);
+MLHIP_API int mlhip_gt_exp(int curve, const void* in_gt, const void* scalars, int scalars_mont, size_t n, void* out_gt);
 /* out = FExp( prod_i MillerLoop(g1[i], g2[i]) ): a multi-pairing product with ONE shared final exponentiation
  * (what a verifier computes before IsUnity: perf_test.go:254-259).  n Miller loops run one per lane, the
  * product is a log-depth tree of Gt multiplications on the device. */
-int mlhip_pairing_product(int curve, const void* g1, const void* g2, size_t n, void* out_gt);
+MLHIP_API int mlhip_pairing_product(int curve, const void* g1, const void* g2, size_t n, void* out_gt);
 
 /* ---- device-resident entry points (points / scalars already in HBM; resident SRS) ----------- */
 typedef struct mlhip_msm_plan mlhip_msm_plan;
 /* Workspace for MSMs of up to max_n points on the calling thread's device. */
-int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhip_msm_plan** plan);
-int mlhip_msm_plan_destroy(mlhip_msm_plan* plan);
+MLHIP_API int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhip_msm_plan** plan);
+MLHIP_API int mlhip_msm_plan_destroy(mlhip_msm_plan* plan);
 /* d_points / d_scalars are device pointers; stream is a hipStream_t (NULL = default stream).
  * out_affine is HOST memory; the call returns after the result is there.  When out_xyzz is non-NULL
  * the un-normalised partial sum (X,Y,ZZ,ZZZ) is written there too (multi-GPU combine). */
-int mlhip_msm_run(mlhip_msm_plan* plan, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
+MLHIP_API int mlhip_msm_run(mlhip_msm_plan* plan, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
                   void* stream, void* out_affine, void* out_xyzz);
 /* The same in two halves, so consecutive MSMs pipeline: mlhip_msm_launch enqueues the kernels and the
  * D2H of the window sums on `stream` and returns; mlhip_msm_finish waits for them and runs the O(1) host
  * tail.  With two plans on two streams the sort of MSM k+1 overlaps the bucket accumulation of MSM k and
  * the host tail of MSM k overlaps GPU work (a Groth16 prover issues 4-5 MSMs back to back). */
-int mlhip_msm_launch(mlhip_msm_plan* plan, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
+MLHIP_API int mlhip_msm_launch(mlhip_msm_plan* plan, const void* d_points, const void* d_scalars, int scalars_mont, size_t n,
                      void* stream);
-int mlhip_msm_finish(mlhip_msm_plan* plan, void* out_affine, void* out_xyzz);
+MLHIP_API int mlhip_msm_finish(mlhip_msm_plan* plan, void* out_affine, void* out_xyzz);
 /* The G1 MSM and the G2 MSM of ONE scalar vector (additive: BASELINE configs[3] "G1 + G2 MSM, shared scalars"; in the
  * reference's terms MultiScalarMul(a1, b) -- driver/gurvy/bls12381/bls12-381.go:766-783 -- and the G2 sum of
  * g2.Mul(b[i]) -- :342-358 -- over the same b).  Both plans: same curve, device and window width; the (window, bucket)
  * entry lists depend on the scalars only, so they are sorted once and both groups accumulate from them.  Finish each
  * plan with mlhip_msm_finish.  Plans that cannot share (different widths, a second-implementation path) run one after
  * the other with the same results. */
-int mlhip_msm_launch_shared(mlhip_msm_plan* g1_plan, mlhip_msm_plan* g2_plan, const void* d_points_g1,
+MLHIP_API int mlhip_msm_launch_shared(mlhip_msm_plan* g1_plan, mlhip_msm_plan* g2_plan, const void* d_points_g1,
                             const void* d_points_g2, const void* d_scalars, int scalars_mont, size_t n, void* stream);
 /* Phase timings of the last run with profiling on (HIP events on the plan's stream), milliseconds:
  * [0] digits [1] sort (histogram scan + scatter) [2] bucket accumulation [3] bucket reduction
@@ -162,7 +166,7 @@ int mlhip_msm_launch_shared(mlhip_msm_plan* g1_plan, mlhip_msm_plan* g2_plan, co
  * windows W; [9] is 1 when the last launch summed its buckets in twisted Edwards coordinates (a subgroup-trusted
  * BLS12-377 G1 plan or table with the SRS promise, mlhip_msm_plan_assume_srs), else 0.  Returns the number of values written (at most `cap`, at
  * most 10). */
-int mlhip_msm_plan_set_profiling(mlhip_msm_plan* plan, int on);
+MLHIP_API int mlhip_msm_plan_set_profiling(mlhip_msm_plan* plan, int on);
 /* The caller declares (on != 0) that this plan's points are a fixed SRS: (1) the point buffer at a given device address
  * holds the same points at every launch until the promise is taken back (the plan keeps its converted copy of them and
  * converts nothing on later launches), and (2) every point lies in the prime-order subgroup or is the point at infinity --
@@ -172,16 +176,16 @@ int mlhip_msm_plan_set_profiling(mlhip_msm_plan* plan, int on);
  * addition instead of 10; that addition law is complete on the subgroup only): same result bytes, less time.  On the other
  * curves and for G2 only (1) matters.  mlhip_bases_create makes the same promise for its own table after checking (2) on
  * the device.  A promise that does not hold gives an undefined RESULT, never a fault. */
-int mlhip_msm_plan_assume_srs(mlhip_msm_plan* plan, int on);
-int mlhip_msm_plan_timings(mlhip_msm_plan* plan, float* ms, int cap);
+MLHIP_API int mlhip_msm_plan_assume_srs(mlhip_msm_plan* plan, int on);
+MLHIP_API int mlhip_msm_plan_timings(mlhip_msm_plan* plan, float* ms, int cap);
 
-int mlhip_miller_loop_device(int curve, const void* d_g1, const void* d_g2, size_t pairs_per_product,
+MLHIP_API int mlhip_miller_loop_device(int curve, const void* d_g1, const void* d_g2, size_t pairs_per_product,
                              size_t n_products, void* d_out_gt, void* stream);
-int mlhip_final_exp_device(int curve, const void* d_in_gt, size_t n, void* d_out_gt, void* stream);
-int mlhip_pairing_batch_device(int curve, const void* d_g1, const void* d_g2, size_t n, void* d_out_gt,
+MLHIP_API int mlhip_final_exp_device(int curve, const void* d_in_gt, size_t n, void* d_out_gt, void* stream);
+MLHIP_API int mlhip_pairing_batch_device(int curve, const void* d_g1, const void* d_g2, size_t n, void* d_out_gt,
                                void* stream);
-int mlhip_gt_mul_device(int curve, const void* d_a_gt, const void* d_b_gt, size_t n, void* d_out_gt, void* stream);
-int mlhip_gt_exp_device(int curve, const void* d_in_gt, const void* d_scalars, int scalars_mont, size_t n,
+MLHIP_API int mlhip_gt_mul_device(int curve, const void* d_a_gt, const void* d_b_gt, size_t n, void* d_out_gt, void* stream);
+MLHIP_API int mlhip_gt_exp_device(int curve, const void* d_in_gt, const void* d_scalars, int scalars_mont, size_t n,
                         void* d_out_gt, void* stream);
 
 /* out[i] = [scalars[i]] points[i * point_stride]: batched single-scalar multiplication (G1.Mul / G2.Mul,
@@ -191,10 +195,10 @@ int mlhip_gt_exp_device(int curve, const void* d_in_gt, const void* d_scalars, i
  * additions per scalar instead of 256 doublings + 64 additions (MLHIP_FIXED_BASE_MIN=n moves the threshold, 0 = never).
  * The table stays on the device: the next call with the same curve, group and base point skips the build (the comparison
  * runs on the device, the call stays asynchronous; MLHIP_FB_CACHE=0 builds it every time).  Device pointers. */
-int mlhip_scalar_mul_device(int curve, int group, const void* d_points, size_t point_stride, const void* d_scalars,
+MLHIP_API int mlhip_scalar_mul_device(int curve, int group, const void* d_points, size_t point_stride, const void* d_scalars,
                             int scalars_mont, size_t n, void* d_out_affine, void* stream);
 /* host-buffer form */
-int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stride, const void* scalars,
+MLHIP_API int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stride, const void* scalars,
                      int scalars_mont, size_t n, void* out_affine);
 
 /* ---- resident bases (upload-once point table, only the scalars travel per call) ----------
@@ -203,23 +207,23 @@ int mlhip_scalar_mul(int curve, int group, const void* points, size_t point_stri
  * count given at creation).  Calls on one handle from several threads are serialized inside the library (one MSM at a
  * time per handle); handles are independent of each other. */
 typedef struct mlhip_bases mlhip_bases;
-int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** bases);
+MLHIP_API int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** bases);
 /* the table cut into contiguous shards over an explicit device list (mlhip_bases_create does this by itself with the
  * process's list from MLHIP_MULTI_MIN bases on): every mlhip_bases_msm then moves each device's scalars over its own
  * PCIe link and adds the per-device partial sums on the host */
-int mlhip_bases_create_multi(int curve, int group, const int* devices, int n_devices, const void* points, size_t n,
+MLHIP_API int mlhip_bases_create_multi(int curve, int group, const int* devices, int n_devices, const void* points, size_t n,
                              int window_c, mlhip_bases** bases);
-int mlhip_bases_msm(mlhip_bases* bases, const void* scalars, int scalars_mont, size_t n, void* out_affine);
+MLHIP_API int mlhip_bases_msm(mlhip_bases* bases, const void* scalars, int scalars_mont, size_t n, void* out_affine);
 /* 1 when mlhip_bases_create verified, on the device, that every point of the table is on the curve and in the prime-order
  * subgroup (or the point at infinity) -- done for BLS12-377 G1 tables, whose MSMs then sum their buckets in twisted
  * Edwards coordinates (see mlhip_msm_plan_assume_srs); 0 otherwise (other curves, G2, a table with a point outside the
  * subgroup, MLHIP_EDWARDS=0): such tables take the Weierstrass kernels and give the reference's result for any input. */
-int mlhip_bases_checked_subgroup(mlhip_bases* bases);
-int mlhip_bases_destroy(mlhip_bases* bases);
+MLHIP_API int mlhip_bases_checked_subgroup(mlhip_bases* bases);
+MLHIP_API int mlhip_bases_destroy(mlhip_bases* bases);
 
 /* The host-buffer MSM entry points above keep up to 16 plans + input buffers (at most 32 GB) alive between calls (creating and
  * destroying them costs as much as a 2^20-point MSM); this frees the idle ones.  MLHIP_NO_PLAN_CACHE=1 disables the pool. */
-int mlhip_release_cache(void);
+MLHIP_API int mlhip_release_cache(void);
 
 /* ---- wire format (bulk NewG1FromBytes / NewG1FromCompressed and G1.Bytes / G1.Compressed,
  * driver/gurvy/bls12381/bls12-381.go:531-569, :286-296) --------------------------------------------------
@@ -229,27 +233,27 @@ int mlhip_release_cache(void);
  * subgroup; out_affine[i] is (0,0) unless status[i] == 0.  subgroup_check: 0 skips the test (gnark's SetBytes always
  * does it), 1 runs the fastest exact test (BLS12 curves: phi(P) = [-x^2]P for G1, psi(Q) = [x]Q for G2; BN254 G2:
  * [x+1]Q + psi([x]Q) + psi^2([x]Q) = psi^3([2x]Q) -- 64-bit ladders, the criteria gnark uses), 2 forces the plain [r]P ladder (kept for cross-checking). */
-int mlhip_g1_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out_affine,
+MLHIP_API int mlhip_g1_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out_affine,
                         unsigned char* status);
-int mlhip_g1_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire);
-int mlhip_g1_from_bytes_device(int curve, const void* d_wire, size_t n, int compressed, int subgroup_check,
+MLHIP_API int mlhip_g1_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire);
+MLHIP_API int mlhip_g1_from_bytes_device(int curve, const void* d_wire, size_t n, int compressed, int subgroup_check,
                                void* d_out_affine, unsigned char* d_status, void* stream);
-int mlhip_g1_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream);
+MLHIP_API int mlhip_g1_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream);
 /* G2 (NewG2FromBytes / NewG2FromCompressed, bls12-381.go:541-569): 2 / 4 fp-sized big-endian values per point in
  * the order X.A1, X.A0 [, Y.A1, Y.A0]; y recovered by a square root in Fp2; subgroup_check as for G1. */
-int mlhip_g2_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out_affine,
+MLHIP_API int mlhip_g2_from_bytes(int curve, const void* wire, size_t n, int compressed, int subgroup_check, void* out_affine,
                         unsigned char* status);
-int mlhip_g2_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire);
-int mlhip_g2_from_bytes_device(int curve, const void* d_wire, size_t n, int compressed, int subgroup_check,
+MLHIP_API int mlhip_g2_to_bytes(int curve, const void* affine, size_t n, int compressed, void* wire);
+MLHIP_API int mlhip_g2_from_bytes_device(int curve, const void* d_wire, size_t n, int compressed, int subgroup_check,
                                void* d_out_affine, unsigned char* d_status, void* stream);
-int mlhip_g2_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream);
+MLHIP_API int mlhip_g2_to_bytes_device(int curve, const void* d_affine, size_t n, int compressed, void* d_wire, void* stream);
 
 /* ---- group helpers (host, O(n) tiny): combine per-GPU partial results after the RCCL all-gather */
-int mlhip_g1_sum(int curve, const void* affine_points, size_t n, void* out_affine);
-int mlhip_g2_sum(int curve, const void* affine_points, size_t n, void* out_affine);
+MLHIP_API int mlhip_g1_sum(int curve, const void* affine_points, size_t n, void* out_affine);
+MLHIP_API int mlhip_g2_sum(int curve, const void* affine_points, size_t n, void* out_affine);
 
 /* ---- field kernel (parity / roofline probe): out[i] = a[i] * b[i] (Montgomery), device pointers */
-int mlhip_fp_mul_device(int curve, const void* d_a, const void* d_b, size_t n, int repeat, void* d_out,
+MLHIP_API int mlhip_fp_mul_device(int curve, const void* d_a, const void* d_b, size_t n, int repeat, void* d_out,
                         void* stream);
 
 #ifdef __cplusplus

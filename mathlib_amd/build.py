@@ -28,7 +28,10 @@ UNITS = [
     "tu_codec_bls381.hip",
     "tu_codec_bls377.hip",
 ]
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fno-gpu-rdc"] + os.environ.get("MLHIP_EXTRA_HIPCC_FLAGS", "").split()
+# -fvisibility=hidden: the dynamic symbol table is the MLHIP_API functions of include/mlhip.h and nothing else
+# (tests/test_abi.py); kernels keep the protected visibility the HIP runtime needs inside the code objects.
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden",
+         "-fvisibility-inlines-hidden"] + os.environ.get("MLHIP_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc() -> str:
@@ -62,6 +65,25 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def abi_functions() -> list[str]:
+    """The entry points include/mlhip.h declares (MLHIP_API ...): the library's whole dynamic symbol table."""
+    import re
+
+    with open(os.path.join(os.path.dirname(HERE), "include", "mlhip.h")) as f:
+        return sorted(set(re.findall(r"^MLHIP_API\s+[^;(]*?\b(mlhip_[a-z0-9_]+)\s*\(", f.read(), re.M)))
+
+
+def _version_script() -> str:
+    """Linker version script naming exactly the header's functions: everything else -- the kernels' host-side handles,
+    libstdc++ template instantiations, the mlhip_tu_* / mlhip_rt entry points between translation units -- stays local."""
+    path = os.path.join(OBJ, "mlhip.map")
+    text = "MLHIP_1 {\n  global:\n" + "".join("    %s;\n" % n for n in abi_functions()) + "  local:\n    *;\n};\n"
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, "w") as f:
+            f.write(text)
+    return path
+
+
 def _compile(unit: str, newest: float, verbose: bool) -> str:
     src = os.path.join(CSRC, unit)
     obj = os.path.join(OBJ, unit.replace(".hip", ".o"))
@@ -83,7 +105,7 @@ def build(verbose: bool = True, jobs: int | None = None) -> str:
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda u: _compile(u, newest, verbose), UNITS))
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + _version_script(), "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,6 +1,9 @@
 // api.hip -- the extern "C" surface of libmlhip.so (include/mlhip.h): argument checking, device
 // selection, host-buffer staging and dispatch to the per-curve translation units.  No kernels here.
 // There is no CPU fallback: every compute entry point needs a HIP device (MLHIP_ENODEVICE otherwise).
+#include <pthread.h>
+#include <sched.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
@@ -561,6 +564,7 @@ struct HostPool {
   std::atomic<unsigned long> gen{0};
   std::shared_ptr<HostJob> job;  // guarded by mu
   int workers = 0;
+  int spin = 2000;  // pause iterations a worker spins for the next job before it sleeps (host_pool_start)
 };
 HostPool* g_host_pool = nullptr;
 std::once_flag g_host_pool_once;
@@ -570,7 +574,7 @@ void host_worker(HostPool* pool) {
   for (;;) {
     // spin for a few tens of microseconds (a job is often followed by another one at once), then sleep
     bool fresh = false;
-    for (int i = 0; i < 2000 && !fresh; i++) {
+    for (int i = 0; i < pool->spin && !fresh; i++) {
       fresh = pool->gen.load(std::memory_order_acquire) != seen;
       if (!fresh) __builtin_ia32_pause();
     }
@@ -594,17 +598,36 @@ void host_worker(HostPool* pool) {
   }
 }
 
+// Pool size: MLHIP_HOST_THREADS (threads per call incl. the caller) or, by default, what this PROCESS may use -- the
+// affinity mask, not the machine's core count -- divided among the ranks that share the host (LOCAL_WORLD_SIZE, set by
+// torch.distributed.run: `bench.py --gpus 8` is 8 processes on one host, each with its own pool, beside torch's threads):
+// min(8, share) for a lone process, min(8, share / 2) when several ranks share the host, and the workers then spin a
+// tenth as long before they sleep (a spinning worker of one rank is a core another rank's tail cannot have).
 void host_pool_start() {
   int total = 0;
   if (const char* e = getenv("MLHIP_HOST_THREADS")) total = atoi(e);
+  int local_world = 1;
+  if (const char* e = getenv("LOCAL_WORLD_SIZE")) local_world = atoi(e) > 1 ? atoi(e) : 1;
   if (total <= 0) {
-    const unsigned hw = std::thread::hardware_concurrency();
-    total = hw >= 8 ? 8 : (hw > 0 ? (int)hw : 1);
+    int cores = 0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+    if (cores <= 0) cores = (int)std::thread::hardware_concurrency();
+    if (cores <= 0) cores = 1;
+    int share = cores / local_world;
+    if (local_world > 1) share /= 2;
+    total = share >= 8 ? 8 : (share > 0 ? share : 1);
   }
   if (total > 64) total = 64;
   HostPool* pool = new HostPool;  // never freed: the workers outlive every static destructor
   pool->workers = total - 1;
-  for (int i = 0; i < pool->workers; i++) std::thread(host_worker, pool).detach();
+  pool->spin = local_world > 1 ? 200 : 2000;
+  for (int i = 0; i < pool->workers; i++) {
+    std::thread t(host_worker, pool);
+    (void)pthread_setname_np(t.native_handle(), "mlhip-host");  // tests count them (tests/test_dist_gpu.py)
+    t.detach();
+  }
   g_host_pool = pool;
 }
 }  // namespace

@@ -794,10 +794,19 @@ int sort_ahead_prepare(mlhip_msm_plan* p, size_t seg, bool& on) {
       h->nb = p->nb;
       h->nsel = p->nsel;
       h->max_n = seg;
-      p->sort_helper[b] = h;  // owned by p from here on (mlhip_msm_plan_destroy frees what was allocated)
-      int rc = plan_alloc_sort(h);
-      if (rc) return rc;
-      if (h->sort_low <= 0) return 0;  // cannot happen for a shorter max_n; stay on the in-line path if it does
+      // The helper is an optimisation: if its buffers do not fit (two copies of the tile's entry lists; plausible at
+      // 2^24 pairs) the MSM must still run, with the sort in line as before.  The record is registered only once it is
+      // complete -- a half-allocated one left in p->sort_helper would pass the `max_n >= seg` test of the next launch
+      // and hand null list pointers to launch_sort.  MLHIP_FAULT_INJECT=sort_helper_alloc makes the allocation "fail"
+      // (tests/test_gpu_parity.py::test_sort_ahead_helper_allocation_failure).
+      const char* fi = getenv("MLHIP_FAULT_INJECT");
+      int rc = (fi && !strcmp(fi, "sort_helper_alloc")) ? MLHIP_ENOMEM : plan_alloc_sort(h);
+      if (rc || h->sort_low <= 0) {
+        mlhip_msm_plan_destroy(h);  // frees whatever was allocated
+        (void)hipGetLastError();    // an out-of-memory error must not surface in the next HIPCHK
+        return 0;                   // on = false: the in-line path
+      }
+      p->sort_helper[b] = h;  // owned by p from here on
     }
     if (!p->ev_sorted[b]) HIPCHK(hipEventCreateWithFlags(&p->ev_sorted[b], hipEventDisableTiming));
     if (!p->ev_lists_free[b]) HIPCHK(hipEventCreateWithFlags(&p->ev_lists_free[b], hipEventDisableTiming));

@@ -1,4 +1,4 @@
-"""world_size-2 rehearsal (gloo, CPU) of the multi-GPU MSM path: contiguous sharding of the pairs and
+"""world_size-2 and world_size-8 rehearsals (gloo, CPU) of the multi-GPU MSM path: contiguous sharding of the pairs and
 the all-gather + local EC-add combination (mathlib_amd/dist.py).  On the CPU the per-rank partial MSM
 is produced by the oracle (there is no GPU here); the exchange and the combine are the product code."""
 import os
@@ -62,5 +62,16 @@ def test_two_rank_combine_matches_single_msm():
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, 301, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_eight_rank_combine_ragged():
+    """The shape of the one hardware run at N = 8 (BASELINE configs[3] and [4]): eight ranks, n not a multiple of eight
+    (shards of 37 and 38 pairs), G1 / G2 / BN254 partials, config 4's two partials in ONE all-gather, identity partials."""
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 27500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, 301, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)

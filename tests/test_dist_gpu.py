@@ -133,3 +133,71 @@ def test_bench_plain_gpus_n_command(config, log_n):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
     assert "REHEARSAL" in d["data"] and d["config"]["baseline_config"] == config
     assert d["config"]["pairs_total"] == 2 * d["config"]["pairs_per_gpu"] == 2 << log_n if d["scaling"] == "weak" else d["config"]["pairs_total"] == 2 * d["config"]["pairs_per_gpu"] == 1 << log_n
+
+
+@pytest.mark.parametrize("config", [4, 5])
+def test_bench_six_rank_rehearsal_is_self_explaining(config):
+    """the strong-scaling configs as the driver will run them at N = 8, rehearsed with as many ranks as a
+    one-GPU box allows on its card (6: ragged shards of 2^18 pairs), gloo on device 0.  The line must say where an N > 1
+    run's time went: every rank's median step, the exchange (all-gather + local EC additions) timed by itself, the
+    kernels' device time per rank."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, MLHIP_BENCH_REHEARSAL="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--config", str(config), "--log-n", "18",
+                        "--kernels-only", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 6 and d["scaling"] == "strong" and d["value"] > 0 and "REHEARSAL" in d["data"]
+    assert d["config"]["pairs_total"] == 1 << 18 and d["config"]["pairs_per_gpu"] in ((1 << 18) // 6, (1 << 18) // 6 + 1)
+    ex = d["extra"]
+    assert len(ex["per_rank_ms_per_step"]["all"]) == 6 and ex["per_rank_ms_per_step"]["min"] <= ex["per_rank_ms_per_step"]["max"]
+    assert len(ex["exchange_ms"]["per_rank_median"]) == 6 and 0 < ex["exchange_ms"]["median"] <= ex["exchange_ms"]["max"]
+    assert ex["exchange_ms"]["median"] < ex["per_rank_ms_per_step"]["max"]
+    assert 0 < ex["per_rank_device_ms_per_step"]["min"] <= ex["per_rank_device_ms_per_step"]["max"]
+
+
+def test_host_pool_is_sized_per_rank():
+    """api.hip: host_pool_start -- the host-tail worker pool is sized from the process's affinity mask divided by
+    LOCAL_WORLD_SIZE (8 ranks of `bench.py --gpus 8` share one host), halved when ranks share the host; MLHIP_HOST_THREADS
+    overrides.  The workers are named, so a fresh process can count them after one MSM."""
+    import subprocess
+
+    code = r"""
+import os, sys, glob, ctypes
+sys.path.insert(0, %r)
+import numpy as np
+from mathlib_amd import _lib
+from oracle import cref
+lib = _lib.load()
+n = 3000
+pts = cref.gen_points(1, 1, 5, 6, n)
+sc = np.random.default_rng(1).integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+out = ctypes.create_string_buffer(96)
+_lib.check(lib.mlhip_msm_g1(1, pts, sc.tobytes(), 0, n, 12, out))
+assert out.raw == cref.msm(1, 1, pts, sc, n, False, 0, 4)
+names = [open(f).read().strip() for f in glob.glob('/proc/self/task/*/comm')]
+print('WORKERS', sum(1 for x in names if x == 'mlhip-host'), len(os.sched_getaffinity(0)))
+""" % ROOT
+
+    def workers(**env_over):
+        env = dict(os.environ)
+        for k in ("LOCAL_WORLD_SIZE", "MLHIP_HOST_THREADS"):
+            env.pop(k, None)
+        env.update(env_over)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        w, cores = [ln for ln in r.stdout.splitlines() if ln.startswith("WORKERS")][0].split()[1:]
+        return int(w), int(cores)
+
+    w, cores = workers()
+    assert w == min(8, max(1, cores)) - 1, (w, cores)
+    w, cores = workers(LOCAL_WORLD_SIZE="4")
+    assert w == min(8, max(1, cores // 4 // 2)) - 1, (w, cores)
+    w, _ = workers(LOCAL_WORLD_SIZE="4", MLHIP_HOST_THREADS="3")
+    assert w == 2

@@ -848,6 +848,39 @@ def test_msm_resident_tiles(lib, mlhip, curve, group, monkeypatch):
             plan.close()
 
 
+def test_sort_ahead_helper_allocation_failure(lib, mlhip, monkeypatch):
+    """the sort-ahead helper records of a tiled MSM are an optimisation; when their buffers cannot be
+    allocated (MLHIP_FAULT_INJECT=sort_helper_alloc stands in for the out-of-memory) the MSM runs with the sort in
+    line, gives the same bytes, leaves no half-built helper behind, and the same plan then runs again with and without
+    the helpers (it used to keep the half-allocated record and launch the next sort on null list pointers)."""
+    import torch
+    from oracle import cref
+
+    g = load_golden("BLS12-381")
+    cid = g["curve_id"]
+    _, g1b, _, _ = mlhip.sizes(cid)
+    n = 5000
+    pts = cref.gen_points(cid, 1, 515, 7, n)
+    sc = _rand_scalars(n, 9090, 252)
+    want = cref.msm(cid, 1, pts, sc, n, False, 0, 8)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    dp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
+    ds = torch.frombuffer(bytearray(sc.tobytes()), dtype=torch.uint8).to(dev)
+    monkeypatch.setenv("MLHIP_TILE_LOG2", "10")  # five tiles: the sort of tile s + 1 runs ahead of tile s
+    plan = mlhip.MsmPlan(cid, 1, n, 12)
+    try:
+        monkeypatch.setenv("MLHIP_FAULT_INJECT", "sort_helper_alloc")
+        assert plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st) == want  # first launch: helpers "fail", in line
+        assert plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st) == want  # relaunch on the same plan
+        monkeypatch.delenv("MLHIP_FAULT_INJECT")
+        assert plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st) == want  # helpers allocate now: sort ahead
+        monkeypatch.setenv("MLHIP_FAULT_INJECT", "sort_helper_alloc")
+        assert plan.run(dp.data_ptr(), ds.data_ptr(), n, False, st) == want  # existing helpers are kept and used
+    finally:
+        plan.close()
+
+
 def test_msm_edwards_trusted_plan(lib, mlhip, monkeypatch):
     """mlhip_msm_plan_assume_srs: a BLS12-377 G1 plan whose caller vouches for the prime-order subgroup sums its
     buckets in twisted Edwards coordinates (ed28.h / msm_ed.h).  Same bytes as the oracle and as the plan without the
