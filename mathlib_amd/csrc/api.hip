@@ -32,7 +32,7 @@ thread_local int g_device = 0;       // device of the call in progress on this t
 std::mutex g_devs_mu;
 std::vector<int> g_devs;
 bool g_devs_set = false;
-bool g_devs_bad = false;  // MLHIP_DEVICES did not parse: every compute call fails until mlhip_init / mlhip_shutdown
+std::atomic<bool> g_devs_bad{false};  // (read without the lock by ensure_device / mlhip_get_devices) MLHIP_DEVICES did not parse: every compute call fails until mlhip_init / mlhip_shutdown
 constexpr int MLHIP_MAX_DEVICES = 64;  // device indices 0 .. 63 (the per-device tables below are indexed by them)
 size_t g_multi_min_msm = (size_t)1 << 21, g_multi_min_pairing = (size_t)1 << 17;
 
@@ -434,6 +434,7 @@ int stream_segments(int group, size_t n, const mlhip_msm_plan* plan) {
   // one pass) -- the condition stream_begin checks
   (void)group;
   if (!plan->aux || !plan->d_points28) return 1;
+  if (getenv("MLHIP_STREAM_SCHEDULE")) return n >= 2 ? 2 : 1;  // explicit segment weights (msm_plan.h: stream_schedule), any n
   if (const char* e = getenv("MLHIP_STREAM_SEGMENTS")) {
     int v = atoi(e);
     if (v < 2) return 1;
@@ -441,7 +442,8 @@ int stream_segments(int group, size_t n, const mlhip_msm_plan* plan) {
     return n >= (size_t)v ? v : 1;
   }
   // segments of 2^18 pairs: at 2^20 the call drops from 5.9 to 4.5 ms, at 2^22 from 21.9 to 12.8 ms (the device-only time)
-  // G2 (BLS12-381): segments of 2^17 pairs, 14.9 -> 11.4 ms at 2^20
+  // G2 (BLS12-381): segments of 2^17 pairs, 14.9 -> 11.4 ms at 2^20.  For G1 from 2^20 pairs on the count returned here only
+  // says "stream": plan_stream replaces the equal segments by a growing schedule (stream_schedule, round 4)
   const size_t k = n >> (group == MLHIP_GROUP_G1 ? 18 : 17);
   return k < 2 ? 1 : (k > MLHIP_MAX_SEGMENTS ? MLHIP_MAX_SEGMENTS : (int)k);
 }
@@ -738,7 +740,8 @@ int mlhip_shutdown(void) {
   mlhip_release_cache();
   std::lock_guard<std::mutex> lk(g_devs_mu);
   g_devs.clear();
-  g_devs_set = g_devs_bad = false;  // the next call reads MLHIP_DEVICES again
+  g_devs_set = false;  // the next call reads MLHIP_DEVICES again
+  g_devs_bad = false;
   return 0;
 }
 
@@ -837,6 +840,8 @@ int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   for (hipEvent_t e : p->ev_seg)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_seg_sc)
     if (e) (void)hipEventDestroy(e);
   for (auto& tile : p->ev_tile)
     for (hipEvent_t e : tile)
@@ -1004,11 +1009,32 @@ int mlhip_msm_plan_set_profiling(mlhip_msm_plan* p, int on) {
   return 0;
 }
 
+// Room for the twisted Edwards form of the points (168-byte Niels triples instead of 112-byte rows) in a plan that may take
+// that path; called when the SRS promise is made, with nothing in flight on the plan.  A failed allocation is not an error:
+// the plan keeps (or gets back) the smaller buffer and stays on the Weierstrass kernels (plan_use_edwards checks the size).
+static void plan_reserve_edwards(mlhip_msm_plan* p) {
+  if (!p->points28_elem_ed || p->points28_elem >= p->points28_elem_ed || !p->d_points28) return;
+  const char* e = getenv("MLHIP_EDWARDS");
+  if (e && e[0] == '0') return;
+  (void)hipSetDevice(p->device);
+  if (p->aux) (void)hipStreamSynchronize(p->aux);
+  void* bigger = nullptr;
+  if (hipMalloc(&bigger, p->max_n * p->points28_elem_ed) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  (void)hipFree(p->d_points28);
+  p->d_points28 = bigger;
+  p->points28_elem = p->points28_elem_ed;
+  p->conv_src = nullptr;
+}
+
 int mlhip_msm_plan_assume_srs(mlhip_msm_plan* p, int on) {
   if (!p) return mlhip_rt::fail(MLHIP_EINVAL, "null plan");
   if (p->pending) return mlhip_rt::fail(MLHIP_EINVAL, "mlhip_msm_plan_assume_srs with a launch pending");
   p->conv_src = nullptr;  // whatever carry-free copy the plan holds was made under the other promise
   p->points_static = p->trust_subgroup = on != 0;
+  if (on) plan_reserve_edwards(p);
   return 0;
 }
 
@@ -1085,6 +1111,7 @@ static int bases_create_single(int curve, int group, const void* points, size_t 
             hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, b->stream) == hipSuccess &&
             hipStreamSynchronize(b->stream) == hipSuccess) {
           b->plan->trust_subgroup = bad == 0;
+          if (bad == 0) plan_reserve_edwards(b->plan);
         }
         (void)hipFree(d_bad);
       }
@@ -1193,6 +1220,10 @@ int mlhip_bases_msm(mlhip_bases* b, const void* scalars, int scalars_mont, size_
 }
 
 int mlhip_release_cache(void) {
+  // the fixed-base tables of the batched scalar multiplication (one per curve and device; msm_scalar_mul.h)
+  mlhip_tu_release_cache_Bn254();
+  mlhip_tu_release_cache_Bls381();
+  mlhip_tu_release_cache_Bls377();
   std::vector<PoolEntry*> idle;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);

@@ -45,6 +45,11 @@ struct mlhip_msm_plan {
   uint32_t* d_bigprefix = nullptr;  // long buckets: slice counts (prefix) and slice sums
   void* d_bigpart = nullptr;
   void* d_points28 = nullptr;  // G1: the points in the carry-free 28-bit-limb form (ec28.h), rewritten every MSM
+  // bytes per point d_points28 was allocated with, and what the twisted Edwards form (Niels triples, ed28.h) would need
+  // (0: this curve / group has none).  A BLS12-377 G1 plan starts with the 112-byte Weierstrass rows and grows to 168 bytes
+  // only when the caller makes the SRS promise (api.hip: plan_reserve_edwards) -- at 2^24 points that is 0.9 GB not spent
+  // on plans that never take the Edwards path
+  size_t points28_elem = 0, points28_elem_ed = 0;
   bool profiling = false;
   bool reduce_one_lane = false;
   bool reduce28 = false;  // G1: the reduction reads the carry-free bucket state (d_state28) -- k_chunks_q28 / k_masked_sums_q28
@@ -69,6 +74,7 @@ struct mlhip_msm_plan {
   // streamed host-buffer MSMs (plan_stream): raw carry-free bucket accumulators between segments, one event per segment
   void* d_state28 = nullptr;
   hipEvent_t ev_seg[MLHIP_MAX_SEGMENTS] = {};
+  hipEvent_t ev_seg_sc[MLHIP_MAX_SEGMENTS] = {};  // ... and one after the segment's SCALARS alone (the sort needs only them)
   // tiles of device-resident inputs under profiling: before the sort / after it / after the accumulation of each tile
   hipEvent_t ev_tile[MLHIP_MAX_SEGMENTS][3] = {};
   int tiles_timed = 0;  // > 0: the last launch was tiled and recorded ev_tile[0 .. tiles_timed)
@@ -103,7 +109,8 @@ struct mlhip_msm_plan {
   int mlhip_tu_wire_codec_##NAME(int group, int encode, const void* d_in, size_t n, int compressed, int subgroup,   \
                                  void* d_out, void* d_status, hipStream_t st);                                     \
   int mlhip_tu_scalar_mul_##NAME(int group, const void* d_points, size_t point_stride, const void* d_scalars,     \
-                                 int mont, size_t n, void* d_out, hipStream_t st);
+                                 int mont, size_t n, void* d_out, hipStream_t st);                                 \
+  void mlhip_tu_release_cache_##NAME(void);
 // G1 points outside the prime-order subgroup (or off the curve) in an array of affine points: mlhip_bases_create's check
 int mlhip_tu_g1_count_outside_subgroup_Bls377(const void* d_pts, size_t n, uint32_t* d_bad, hipStream_t st);
 MLHIP_DECLARE_CURVE(Bn254)

@@ -31,7 +31,7 @@ inline bool plan_use_edwards(const mlhip_msm_plan* p) {
   if constexpr (C::HAS_EDWARDS && std::is_same<F, FpField<C>>::value) {
     const char* e = getenv("MLHIP_EDWARDS");
     return p->trust_subgroup && p->points_static && p->reduce28 && p->d_points28 && (size_t)p->W * p->M > QUAD_ACC_MAX_BUCKETS &&
-           !(e && e[0] == '0');
+           p->points28_elem >= sizeof(EdNiels28<C>) && !(e && e[0] == '0');
   }
   return false;
 }
@@ -119,9 +119,13 @@ int plan_alloc(mlhip_msm_plan* p) {
     // MLHIP_ACC32=1 selects the boundary-form kernel (kept as the second implementation the tests compare with).
     const char* acc32 = getenv("MLHIP_ACC32");
     const bool want28 = !(acc32 && acc32[0] == '1');
-    // (a curve with a twisted Edwards model keeps room for the Niels triples of a subgroup-trusted launch: 168 B a point)
-    constexpr size_t kPoint28 = F::Curve::HAS_EDWARDS ? sizeof(EdNiels28<typename F::Curve>) : sizeof(Affine28<typename F::Curve>);
-    if (want28) HIPCHK(hipMalloc(&p->d_points28, p->max_n * kPoint28));
+    // (a curve with a twisted Edwards model grows the buffer to the Niels triples' 168 B a point when the SRS promise is made)
+    constexpr size_t kPoint28 = sizeof(Affine28<typename F::Curve>);
+    if (want28) {
+      HIPCHK(hipMalloc(&p->d_points28, p->max_n * kPoint28));
+      p->points28_elem = kPoint28;
+      p->points28_elem_ed = F::Curve::HAS_EDWARDS ? sizeof(EdNiels28<typename F::Curve>) : 0;
+    }
     // ... and so does the quad-lane reduction, on the accumulators as the kernel leaves them (MLHIP_REDUCE32=1: the
     // boundary-form reduction kernels, kept as the second implementation)
     const char* red32 = getenv("MLHIP_REDUCE32");
@@ -601,8 +605,10 @@ struct StreamCtx {
   const void* h_points = nullptr;
   const void* h_scalars = nullptr;
   int mont = 0;
-  size_t n = 0, seg = 0;
+  size_t n = 0, seg = 0;  // seg: the longest segment (what a sort-ahead helper record must hold)
   int K = 0;
+  size_t bound[MLHIP_MAX_SEGMENTS + 1] = {};  // segment s = pairs [bound[s], bound[s + 1])
+  bool scheduled = false;                     // bound[] was filled by the caller (stream_schedule); else K equal segments
   bool resident = false, conv_cached = false, prof = false;
   bool ed = false;  // the buckets are summed in twisted Edwards coordinates (plan_use_edwards)
 };
@@ -616,8 +622,10 @@ int stream_begin(mlhip_msm_plan* p, StreamCtx& cx, hipStream_t st, int min_K) {
   if (cx.n == 0 || cx.K < min_K || cx.K > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "bad segment count");
   const size_t nbuckets = (size_t)p->W * p->M;
   if (!p->d_state28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * kStateBytes));
-  for (int s = 0; s < cx.K; s++)
+  for (int s = 0; s < cx.K; s++) {
     if (!p->ev_seg[s]) HIPCHK(hipEventCreateWithFlags(&p->ev_seg[s], hipEventDisableTiming));
+    if (cx.h_scalars && cx.h_points && !p->ev_seg_sc[s]) HIPCHK(hipEventCreateWithFlags(&p->ev_seg_sc[s], hipEventDisableTiming));
+  }
   // resident points (h_points == nullptr): only the scalars travel (or nothing: h_scalars == nullptr); their carry-free
   // copy is either the plan's (resident bases) or made tile by tile
   cx.resident = cx.h_points == nullptr;
@@ -633,7 +641,15 @@ int stream_begin(mlhip_msm_plan* p, StreamCtx& cx, hipStream_t st, int min_K) {
   p->pending_n = cx.n;
   p->pending = true;
   if (!cx.conv_cached) p->conv_src = nullptr;  // the carry-free copy is being rewritten
-  cx.seg = (cx.n + cx.K - 1) / cx.K;
+  if (!cx.scheduled) {
+    const size_t seg = (cx.n + cx.K - 1) / cx.K;
+    int k = 0;
+    for (size_t off = 0; off < cx.n; off += seg) cx.bound[k++] = off;
+    cx.bound[k] = cx.n;
+    cx.K = k;
+  }
+  cx.seg = 0;
+  for (int s2 = 0; s2 < cx.K; s2++) cx.seg = std::max(cx.seg, cx.bound[s2 + 1] - cx.bound[s2]);
   HIPCHK(hipEventRecord(p->ev_fork, st));  // the staging buffers are free once the work queued before us is done
   HIPCHK(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
   return 0;
@@ -648,8 +664,8 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   typedef XYZZ<F> X;
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
   const size_t nbuckets = (size_t)p->W * p->M;
-  const size_t off = (size_t)s * cx.seg;
-  const size_t len = std::min(cx.seg, cx.n - off);
+  const size_t off = cx.bound[s];
+  const size_t len = cx.bound[s + 1] - off;
   const bool first = off == 0, last = off + len >= cx.n;
   const int flags = (first ? MLHIP_SEG_FIRST : 0) | (last ? MLHIP_SEG_LAST : 0) | (p->reduce28 ? MLHIP_SEG_KEEP28 : 0);
   const char* hp = (const char*)cx.h_points;
@@ -658,6 +674,9 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   A* dpt = (A*)cx.d_points + off;
   const bool prof = cx.prof;
   if (hs) HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
+  // points and scalars both travel: the sort starts when the segment's scalars are there, under the upload of its points
+  const bool split = hs && !cx.resident && p->ev_seg_sc[s];
+  if (split) HIPCHK(hipEventRecord(p->ev_seg_sc[s], p->aux));
   if (!cx.conv_cached) {
     if (!cx.resident) HIPCHK(hipMemcpyAsync(dpt, hp + off * sizeof(A), len * sizeof(A), hipMemcpyHostToDevice, p->aux));
     if constexpr (kG2)
@@ -682,12 +701,12 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   HIPCHK(hipMemsetAsync(p->d_zero, 0, p->zero_bytes, st));
   if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][0], st));
   const bool uploads = hs || !cx.resident;
-  if (uploads) HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));  // the sort needs the uploaded scalars
+  if (uploads) HIPCHK(hipStreamWaitEvent(st, split ? p->ev_seg_sc[s] : p->ev_seg[s], 0));  // the sort needs the uploaded scalars
   if (!sorter) {
     int rc_sort = launch_sort<C>(p, dsc, cx.mont, len, st, false);
     if (rc_sort) return rc_sort;
   }
-  if (!uploads) HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));  // tiles: only the accumulation waits for the conversion
+  if (!uploads || split) HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));  // only the accumulation waits for points / conversion
   if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][1], st));
   const mlhip_msm_plan* sv = sorter ? sorter : p;  // whose entry lists the kernels read
   uint32_t big_threshold = (uint32_t)std::min<size_t>((len >> (p->c - 1)) * 8, 1u << 30);
@@ -830,14 +849,60 @@ template <class C>
 int sort_ahead_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s) {
   const int b = s & 1;
   mlhip_msm_plan* h = p->sort_helper[b];
-  const size_t off = (size_t)s * cx.seg;
-  const size_t len = std::min(cx.seg, cx.n - off);
+  const size_t off = cx.bound[s];
+  const size_t len = cx.bound[s + 1] - off;
   HIPCHK(hipStreamWaitEvent(p->sort_stream, p->ev_lists_free[b], 0));  // never recorded yet: no wait
   HIPCHK(hipMemsetAsync(h->d_zero, 0, h->zero_bytes, p->sort_stream));
   int rc = launch_sort<C>(h, (const char*)cx.d_scalars + off * 32, cx.mont, len, p->sort_stream, false);
   if (rc) return rc;
   HIPCHK(hipEventRecord(p->ev_sorted[b], p->sort_stream));
   return 0;
+}
+
+// Segment schedule of a host-buffer MSM (round 4; profiles/r04_hostapi.txt, same-box A/Bs at 2^20 pairs).  K equal
+// segments expose the whole first upload and pay the per-segment costs (a sort train, one round trip of the bucket state,
+// two pageable copies, shorter bucket lists) K times.  What bounds the call differs between the two host protocols:
+//   (b) resident bases, only the 32-byte scalars travel -- a fifth of the kernels' time: TWO segments, 3 and 13 sixteenths of
+//       the call; the second upload hides under the first segment's kernels and only one extra sort train is paid:
+//       3.37 -> 3.23 ms against four equal segments, 0.02 ms above the resident MSM of the same box;
+//   (c) points and scalars travel, 128 B a pair -- the copies (2.35 ms) run at about the kernels' rate (2.6 ms), so a later
+//       segment may be at most ~1.1x the one before or the kernels wait for it, and every extra segment costs ~0.1 ms:
+//       growing schedules LOSE (1,1,2,3,4,5: 4.28 ms; 2,3,5,6: 4.24; 1,2,2,3,4,4: 4.09) against four equal segments (3.99) --
+//       equal segments of 2^18 pairs stay.  (What round 4 did gain for (c) is the split event: a segment's sort starts on
+//       its scalars, under the upload of its points -- stream_tile.)
+// MLHIP_STREAM_SCHEDULE="w0,w1,..." (weights, at most MLHIP_MAX_SEGMENTS) overrides; MLHIP_STREAM_SEGMENTS = K keeps K equal
+// segments (what the tests use to force many segments on small inputs).
+inline void stream_schedule(StreamCtx& cx, bool points_travel) {
+  int w[MLHIP_MAX_SEGMENTS];
+  int k = 0;
+  if (const char* e = getenv("MLHIP_STREAM_SCHEDULE")) {
+    for (const char* q = e; *q && k < MLHIP_MAX_SEGMENTS;) {
+      const int v = atoi(q);
+      if (v > 0) w[k++] = v;
+      while (*q && *q != ',') q++;
+      if (*q == ',') q++;
+    }
+  } else if (getenv("MLHIP_STREAM_SEGMENTS")) {
+    return;  // K equal segments
+  } else if (cx.n >= ((size_t)1 << 20) && !points_travel) {
+    w[k++] = 3;
+    w[k++] = 13;
+  }
+  if (k < 2) return;
+  long long total = 0;
+  for (int i = 0; i < k; i++) total += w[i];
+  size_t cum = 0;
+  int m = 0;
+  cx.bound[0] = 0;
+  for (int i = 0; i < k; i++) {
+    cum += (size_t)w[i];
+    size_t b = i + 1 == k ? cx.n : ((size_t)((unsigned __int128)cx.n * cum / (size_t)total) + 1023) / 1024 * 1024;
+    if (b > cx.n) b = cx.n;
+    if (b > cx.bound[m]) cx.bound[++m] = b;
+  }
+  if (m < 2) return;
+  cx.K = m;
+  cx.scheduled = true;
 }
 
 template <class C, class F>
@@ -851,6 +916,7 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
   cx.mont = mont;
   cx.n = n;
   cx.K = K;
+  if (h_scalars && std::is_same<F, FpField<C>>::value) stream_schedule(cx, h_points != nullptr);
   int rc = stream_begin<C, F>(p, cx, st, 2);
   if (rc) return rc;
   bool ahead = false;
@@ -859,7 +925,7 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
     if (rc) return rc;
   }
   if (ahead) HIPCHK(hipStreamWaitEvent(p->sort_stream, p->ev_fork, 0));  // the scalars are ready where `st` stood at launch
-  for (int s = 0; (size_t)s * cx.seg < n; s++) {
+  for (int s = 0; s < cx.K; s++) {
     if (ahead) {
       rc = sort_ahead_tile<C>(p, cx, s);
       if (rc) return rc;
@@ -922,7 +988,7 @@ int plan_stream_shared(mlhip_msm_plan* p1, mlhip_msm_plan* p2, void* d_points_g1
     if (rc) return rc;
   }
   if (ahead) HIPCHK(hipStreamWaitEvent(p1->sort_stream, p1->ev_fork, 0));
-  for (int s = 0; (size_t)s * c1.seg < n; s++) {
+  for (int s = 0; s < c1.K; s++) {
     const mlhip_msm_plan* lists = p1;  // whose entry lists the G2 tile reads
     if (ahead) {
       rc = sort_ahead_tile<C>(p1, c1, s);
@@ -932,7 +998,7 @@ int plan_stream_shared(mlhip_msm_plan* p1, mlhip_msm_plan* p2, void* d_points_g1
     }
     rc = stream_tile<C, F1>(p1, c1, s, st, ahead ? lists : nullptr);
     if (rc) return rc;
-    if ((size_t)(s + 1) * c1.seg >= n) {
+    if (s + 1 == c1.K) {
       // G1 is complete: its reduction and its copy to the host go ahead of G2's last accumulation, so that the host
       // tail of the G1 result runs under it
       rc = stream_end<C, F1>(p1, c1, st);

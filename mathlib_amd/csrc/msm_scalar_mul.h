@@ -108,7 +108,29 @@ struct FixedBaseScratch {
   hipEvent_t last = nullptr;  // recorded after the last kernel that reads the buffer
 };
 static std::mutex g_fb_mu;
-static FixedBaseScratch g_fb[64];  // per device
+static FixedBaseScratch g_fb[64];  // per device (and per curve: this header is compiled into one translation unit per curve)
+
+// mlhip_release_cache / mlhip_shutdown: the tables go too (20 MB at w = 12 for G2, 70 MB at w = 14); the next fixed-base
+// call builds its table again.  Waits for the last kernel that reads each buffer.
+static inline void fixed_base_release() {
+  std::lock_guard<std::mutex> lk(g_fb_mu);
+  int cur = 0;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  for (int dev = 0; dev < 64; dev++) {
+    FixedBaseScratch& fb = g_fb[dev];
+    if (!fb.buf && !fb.last) continue;
+    (void)hipSetDevice(dev);
+    if (fb.last) {
+      (void)hipEventSynchronize(fb.last);
+      (void)hipEventDestroy(fb.last);
+      fb.last = nullptr;
+    }
+    if (fb.buf) (void)hipFree(fb.buf);
+    fb.buf = nullptr;
+    fb.cap = 0;
+  }
+  if (have_cur) (void)hipSetDevice(cur);
+}
 
 // header[0] = 1 iff the buffer holds the table of this (tag, base) already; otherwise header[0] = 0 and the tag is cleared
 // until k_fb_commit, queued behind the kernels that build the table, stores the new key -- a call that fails between the
@@ -391,7 +413,7 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
       fb.cap = 0;
       HIPCHK(hipMalloc((void**)&fb.buf, need));
       fb.cap = need;
-      HIPCHK(hipMemset(fb.buf, 0, FB_HEADER));  // tag 0: no table yet
+      HIPCHK(hipMemsetAsync(fb.buf, 0, FB_HEADER, st));  // tag 0: no table yet -- on the call's stream, ahead of k_fb_check
     }
     if (!fb.last)
       HIPCHK(hipEventCreateWithFlags(&fb.last, hipEventDisableTiming));

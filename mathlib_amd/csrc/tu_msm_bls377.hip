@@ -29,3 +29,4 @@ int mlhip_tu_scalar_mul_Bls377(int group, const void* d_points, size_t point_str
     return scalar_mul_device<Bls377, FpField<Bls377>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
   return scalar_mul_device<Bls377, Fp2Field<Bls377>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
 }
+void mlhip_tu_release_cache_Bls377(void) { fixed_base_release(); }

@@ -29,3 +29,4 @@ int mlhip_tu_scalar_mul_Bn254(int group, const void* d_points, size_t point_stri
     return scalar_mul_device<Bn254, FpField<Bn254>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
   return scalar_mul_device<Bn254, Fp2Field<Bn254>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
 }
+void mlhip_tu_release_cache_Bn254(void) { fixed_base_release(); }

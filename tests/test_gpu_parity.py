@@ -302,6 +302,48 @@ def test_msm_g1_skewed_distributions(lib, mlhip, curve, segments, monkeypatch):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_msm_g1_segment_schedules(lib, mlhip, curve, monkeypatch):
+    """msm_plan.h: stream_schedule (round 4) -- a host-buffer G1 MSM streamed in segments of unequal length, for points
+    and scalars from the host (mlhip_msm_g1: the sort of a segment starts on its scalars, under the upload of its points)
+    and for resident bases (mlhip_bases_msm).  Growing, shrinking and single-weight schedules, sixteen segments, weights
+    that round to empty segments, a long bucket in every segment, infinities; the same bytes as the oracle every time."""
+    import numpy as np
+    from oracle import cref
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    _, g1b, _, _ = mlhip.sizes(cid)
+    n = 9000
+    pts = bytearray(cref.gen_points(cid, 1, 60606, 707, n))
+    for i in range(17, n, 900):
+        pts[i * g1b : (i + 1) * g1b] = bytes(g1b)
+    pts = bytes(pts)
+    cases = {"uniform": _rand_scalars(n, 808 + cid, 252)}
+    sk = _rand_scalars(n, 809 + cid, 252)
+    sk[::3] = sk[0]  # one long bucket per window, present in every segment
+    cases["skewed"] = sk
+    handle = ctypes.c_void_p()
+    mlhip.check(lib.mlhip_bases_create(cid, 1, pts, n, 12, ctypes.byref(handle)))
+    try:
+        for name, sc in cases.items():
+            exp = cref.msm(cid, 1, pts, sc, n, False, 0, 8)
+            exp_head = cref.msm(cid, 1, pts, sc, 5000, False, 0, 8)
+            raw = sc.tobytes()
+            for sched in ("1,1,2,3,4,5", "3,13", "5,1,1", "7", "1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1", "1,1000,1", "0,2,x,3"):
+                monkeypatch.setenv("MLHIP_STREAM_SCHEDULE", sched)
+                out = ctypes.create_string_buffer(g1b)
+                mlhip.check(lib.mlhip_msm_g1(cid, pts, raw, 0, n, 12, out))
+                assert out.raw == exp, (curve, name, sched, "msm_g1")
+                mlhip.check(lib.mlhip_bases_msm(handle, raw, 0, n, out))
+                assert out.raw == exp, (curve, name, sched, "bases_msm")
+                mlhip.check(lib.mlhip_bases_msm(handle, raw, 0, 5000, out))  # fewer scalars than bases
+                assert out.raw == exp_head, (curve, name, sched, "bases_msm prefix")
+            monkeypatch.delenv("MLHIP_STREAM_SCHEDULE")
+    finally:
+        mlhip.check(lib.mlhip_bases_destroy(handle))
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_msm_long_buckets_in_slices(lib, mlhip, curve, monkeypatch):
     """Buckets far above the slice length (4096 entries): all scalars one (a plain sum of points: one bucket of n
     entries), scalars below 2^16 with the carry bucket of the next window, G2 with equal scalars -- in one pass and
