@@ -256,6 +256,37 @@ MLHIP_API int mlhip_g2_sum(int curve, const void* affine_points, size_t n, void*
 MLHIP_API int mlhip_fp_mul_device(int curve, const void* d_a, const void* d_b, size_t n, int repeat, void* d_out,
                         void* stream);
 
+/* ---- environment switches (all of them; none is needed for normal use) ---------------------------------------------------
+ * Read by the library at the point named.  "2nd impl" = selects a slower second implementation of the same result that the
+ * parity tests run against the default one; it never changes a result byte.
+ *
+ *   devices and threads (read once per process)
+ *     MLHIP_DEVICES="0,1,.." | "all"   the process's device list (see mlhip_init)
+ *     MLHIP_MULTI_MIN, MLHIP_MULTI_MIN_PAIRINGS   smallest host-buffer MSM / pairing batch that is spread over the list (2^21, 2^17)
+ *     MLHIP_HOST_THREADS=N             threads of the host-tail pool per call incl. the caller (default: min(8, cores of the
+ *                                      affinity mask / LOCAL_WORLD_SIZE, halved when ranks share the host); 1 = none)
+ *     MLHIP_NO_PLAN_CACHE=1            host-buffer MSMs create and destroy their plan per call
+ *   MSM geometry and schedules (read per plan or per launch)
+ *     MLHIP_STREAM_SEGMENTS=K          host-buffer MSMs in K equal segments (0 / 1 = one upload, one pass)
+ *     MLHIP_STREAM_SCHEDULE="w0,w1,.." ... in segments of these relative lengths (default for resident bases: "3,13")
+ *     MLHIP_TILE_LOG2=t                device-resident MSMs in tiles of 2^t pairs (0 = never; default 2^21 G1 / 2^20 G2 from 2^22 / 2^23)
+ *     MLHIP_SORT_AHEAD=0, MLHIP_SORT_AHEAD_PRIO=0   tiles: sort of tile s+1 in line / on a default-priority stream
+ *     MLHIP_SORT_TILE, MLHIP_CHUNK_LOG2, MLHIP_ACC_BLOCK, MLHIP_RED_BLOCK   kernel tile / chunk / workgroup sizes (sweeps)
+ *     MLHIP_FIXED_BASE_MIN=n, MLHIP_FB_WINDOW=w, MLHIP_FB_CACHE=0   batched Mul of one base: table from n scalars on, width, no reuse
+ *     MLHIP_EDWARDS=0                  BLS12-377 G1 over a checked SRS: keep the Weierstrass bucket sums
+ *     MLHIP_PAIRING_QUAD=0|1           BLS12-381: never / always one pairing per quad of lanes (default: up to 2^14 elements)
+ *   2nd impl (parity tests; DESIGN.md section 2 lists which test runs which)
+ *     MLHIP_ACC32=1                    boundary-form (32-bit limb) bucket accumulation, G1 and G2
+ *     MLHIP_REDUCE32=1, MLHIP_REDUCE_ONE_LANE=1   boundary-form / one-point-per-lane bucket reduction
+ *     MLHIP_LEGACY_SORT=1              global-atomic sort (also the default above 2^24 pairs at c = 16)
+ *     MLHIP_SCATTER_STAGED=0           round-1 coarse scatter (one store per entry)
+ *     MLHIP_NO_QUAD_ACC=1              small MSMs: one bucket per lane instead of per quad
+ *     MLHIP_G2_KC=1                    G2 buckets split by coordinate (one-lane Karatsuba Fp2 products; measured 3-5 % slower)
+ *     MLHIP_PAIRING_ONE_LANE=1, MLHIP_PAIRING_SAT=1, MLHIP_SCALAR_MUL_ONE_LANE=1   one-lane / saturated-limb pairing and G2.Mul kernels
+ *   tests only
+ *     MLHIP_FAULT_INJECT=sort_helper_alloc   the sort-ahead helper allocation "fails" (tests/test_gpu_parity.py)
+ */
+
 #ifdef __cplusplus
 }
 #endif

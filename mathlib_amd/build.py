@@ -1,7 +1,11 @@
 """Builds mathlib_amd/libmlhip.so (HIP, gfx950 only) in-tree: one hipcc job per translation unit, in
 parallel, then one link.  `python -m mathlib_amd.build` or `__graft_entry__.build()`.
 
-Objects are cached under mathlib_amd/csrc/_obj and rebuilt when any source/header is newer.
+`python -m mathlib_amd.build --alt` builds the TEST library mathlib_amd/libmlhip_alt.so beside it (-DMLHIP_BUILD_ALT=1):
+the same code plus the second implementations the parity tests compare the default kernels with (mlhip_internal.h);
+`MLHIP_LIB=mathlib_amd/libmlhip_alt.so pytest -m gpu` runs the suite on it, the product library skips those cases.
+
+Objects are cached under mathlib_amd/csrc/_obj (_obj_alt) and rebuilt when any source/header is newer.
 """
 from __future__ import annotations
 
@@ -84,26 +88,42 @@ def _version_script() -> str:
     return path
 
 
-def _compile(unit: str, newest: float, verbose: bool) -> str:
+def _compile(unit: str, newest: float, verbose: bool, alt: bool = False) -> str:
     src = os.path.join(CSRC, unit)
-    obj = os.path.join(OBJ, unit.replace(".hip", ".o"))
+    obj = os.path.join(OBJ + ("_alt" if alt else ""), unit.replace(".hip", ".o"))
     if os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj
-    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + (["-DMLHIP_BUILD_ALT=1"] if alt else []) + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (unit, r.stdout, r.stderr))
+    # hipcc compiles the unit twice (device pass, then host pass): a header saved between the two gives an object whose host
+    # code launches kernels its code object does not have ("Cannot find Symbol" at the first launch; it happened in round 4).
+    # The object is therefore stamped with the time the compile STARTED -- any dependency saved after that makes it stale --
+    # and a compile that was overtaken by an edit is repeated at once.
+    for _ in range(3):
+        import time
+
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (unit, r.stdout, r.stderr))
+        os.utime(obj, (t0, t0))
+        if _deps_mtime() <= t0:
+            break
     return obj
 
 
-def build(verbose: bool = True, jobs: int | None = None) -> str:
+LIB_ALT = os.path.join(HERE, "libmlhip_alt.so")
+
+
+def build(verbose: bool = True, jobs: int | None = None, alt: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(OBJ + ("_alt" if alt else ""), exist_ok=True)
     newest = _deps_mtime()
     jobs = jobs or min(len(UNITS), max(1, (os.cpu_count() or 2)))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda u: _compile(u, newest, verbose), UNITS))
+        objs = list(ex.map(lambda u: _compile(u, newest, verbose, alt), UNITS))
+    LIB = LIB_ALT if alt else globals()["LIB"]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + _version_script(), "-o", LIB] + objs
         if verbose:
@@ -118,4 +138,4 @@ if __name__ == "__main__":
     if "--source-hash" in sys.argv:
         print(source_hash())
     else:
-        print(build(verbose="-q" not in sys.argv))
+        print(build(verbose="-q" not in sys.argv, alt="--alt" in sys.argv))

@@ -688,7 +688,8 @@ void host_parallel(int njobs, void (*fn)(const void*, int, void*), const void* i
 
 extern "C" {
 
-int mlhip_version(void) { return 100; }
+// 104 = round 4; bit 16 set in the test build (MLHIP_BUILD_ALT=1: the second implementations are compiled in)
+int mlhip_version(void) { return 104 | (kBuildAlt ? 0x10000 : 0); }
 
 const char* mlhip_last_error(void) { return g_err.c_str(); }
 

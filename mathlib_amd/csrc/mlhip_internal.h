@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/mlhip.h"
@@ -25,6 +26,22 @@ void host_parallel(int njobs, void (*fn)(const void*, int, void*), const void* i
   } while (0)
 
 #define MLHIP_MAX_SEGMENTS 16
+
+// MLHIP_BUILD_ALT=1 (python -m mathlib_amd.build --alt -> libmlhip_alt.so): the test build.  It also contains the second
+// implementations the parity tests compare the default kernels with -- boundary-form (32-bit limb) bucket accumulation and
+// reduction, the one-point-per-lane reduction, G2 buckets split by coordinate, one-lane / saturated-limb pairing and G2.Mul
+// kernels -- behind their MLHIP_* switches (include/mlhip.h, "2nd impl").  The product library is built without it: those
+// kernels are not instantiated, their switches are ignored, and mlhip_version() has bit 16 clear.
+#ifndef MLHIP_BUILD_ALT
+#define MLHIP_BUILD_ALT 0
+#endif
+constexpr bool kBuildAlt = MLHIP_BUILD_ALT != 0;
+// an alternate-implementation switch: set to '1' AND compiled in
+static inline bool mlhip_alt_switch(const char* name) {
+  if (!kBuildAlt) return false;
+  const char* e = getenv(name);
+  return e && e[0] == '1';
+}
 
 struct mlhip_msm_plan {
   int curve, group, device, c, W, L, lgL, nb, nsel;

@@ -16,10 +16,7 @@ constexpr bool g2_carry_free_v = true;
 // instructions per addition, but three 64-bit column combinations per product column and 130 spilled registers instead of
 // 63 -- measured 3-5 % SLOWER; kept as a second implementation for the parity tests).  Read per launch
 // so that a test can switch paths; both leave bit-identical bucket states.
-static inline bool g2_split_by_coordinate() {
-  const char* e = getenv("MLHIP_G2_KC");
-  return e && e[0] == '1';
-}
+static inline bool g2_split_by_coordinate() { return mlhip_alt_switch("MLHIP_G2_KC"); }
 
 // Does this plan sum its buckets in twisted Edwards coordinates (ed28.h)?  G1 of a curve with the model, the SRS promise
 // (mlhip_msm_plan_assume_srs, or a table mlhip_bases_create has checked: every point in the subgroup, and the converted copy
@@ -111,14 +108,12 @@ int plan_alloc(mlhip_msm_plan* p) {
     if (v == 64 || v == 128 || v == 256) p->acc_block = v;
   }
   {
-    const char* one_lane = getenv("MLHIP_REDUCE_ONE_LANE");  // =1: the one-point-per-lane reduction kernels
-    p->reduce_one_lane = one_lane && one_lane[0] == '1';
+    p->reduce_one_lane = mlhip_alt_switch("MLHIP_REDUCE_ONE_LANE");  // =1: the one-point-per-lane reduction kernels
   }
   if constexpr (std::is_same<F, FpField<typename F::Curve>>::value) {
     // G1 accumulation runs in the carry-free form (fp28.h): -24 % time for the 12-limb fields, -7 % for BN254.
     // MLHIP_ACC32=1 selects the boundary-form kernel (kept as the second implementation the tests compare with).
-    const char* acc32 = getenv("MLHIP_ACC32");
-    const bool want28 = !(acc32 && acc32[0] == '1');
+    const bool want28 = !mlhip_alt_switch("MLHIP_ACC32");
     // (a curve with a twisted Edwards model grows the buffer to the Niels triples' 168 B a point when the SRS promise is made)
     constexpr size_t kPoint28 = sizeof(Affine28<typename F::Curve>);
     if (want28) {
@@ -128,18 +123,15 @@ int plan_alloc(mlhip_msm_plan* p) {
     }
     // ... and so does the quad-lane reduction, on the accumulators as the kernel leaves them (MLHIP_REDUCE32=1: the
     // boundary-form reduction kernels, kept as the second implementation)
-    const char* red32 = getenv("MLHIP_REDUCE32");
-    p->reduce28 = want28 && !p->reduce_one_lane && !(red32 && red32[0] == '1');
+    p->reduce28 = want28 && !p->reduce_one_lane && !mlhip_alt_switch("MLHIP_REDUCE32");
     if (p->reduce28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * sizeof(XYZZ28<typename F::Curve>)));
   }
   if constexpr (std::is_same<F, Fp2Field<typename F::Curve>>::value && g2_carry_free_v<typename F::Curve>) {
     // G2 in the carry-free form (g2_carry_free_v above)
-    const char* acc32 = getenv("MLHIP_ACC32");
-    if (!(acc32 && acc32[0] == '1')) {
+    if (!mlhip_alt_switch("MLHIP_ACC32")) {
       HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(AffineG2_28<typename F::Curve>)));
       // ... and the lane-pair reduction reads the accumulators as the kernel leaves them (MLHIP_REDUCE32=1: boundary form)
-      const char* red32 = getenv("MLHIP_REDUCE32");
-      p->reduce28 = !(red32 && red32[0] == '1');
+      p->reduce28 = !mlhip_alt_switch("MLHIP_REDUCE32");
       if (p->reduce28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * 2 * sizeof(XYZZ28L<Fp28<typename F::Curve>>)));
     }
   }
@@ -332,12 +324,16 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
           done28 = true;
         }
       }
-      if (!done28) {
-        k_chunks_lp<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
-                                                                                          p->L, (X*)p->d_A, (X*)p->d_W0);
-        constexpr int RB = 512;  // 256 lane pairs, 128 slots x 384 B = 48 KB of LDS per block
-        k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
-            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      if constexpr (kBuildAlt) {  // (boundary-form lane pairs: MLHIP_REDUCE32 / MLHIP_ACC32, test build only)
+        if (!done28) {
+          k_chunks_lp<C><<<dim3((unsigned)((2 * n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                            p->L, (X*)p->d_A, (X*)p->d_W0);
+          constexpr int RB = 512;  // 256 lane pairs, 128 slots x 384 B = 48 KB of LDS per block
+          k_masked_sums_lp<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
+              (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+        }
+      } else if (!done28) {
+        return mlhip_rt::fail(MLHIP_EINVAL, "G2 reduction: the carry-free bucket state is missing");
       }
     } else {
       if (p->reduce28) {
@@ -355,23 +351,31 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
           }
         }
         if (!done_ed) {
-          k_chunks_q28<C><<<cgrid, cblock, 0, st>>>((const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
+          const char* two = getenv("MLHIP_CHUNKS_TWO");
+          if (two && two[0] == '1')
+            k_chunks_q28<C, false, true><<<cgrid, cblock, 0, st>>>((const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
+          else
+            k_chunks_q28<C><<<cgrid, cblock, 0, st>>>((const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
           k_masked_sums_q28<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X28), st>>>(
               (const X28*)p->d_A, (const X28*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
         }
-      } else if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created
-        k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
-                                                                                     p->L, (X*)p->d_A, (X*)p->d_W0);
-        constexpr int RB = 256;  // 48 KB of LDS per block
-        k_masked_sums<F, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), RB * sizeof(X), st>>>(
-            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+      } else if constexpr (kBuildAlt) {  // boundary-form reductions: test build only
+        if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created
+          k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                       p->L, (X*)p->d_A, (X*)p->d_W0);
+          constexpr int RB = 256;  // 48 KB of LDS per block
+          k_masked_sums<F, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), RB * sizeof(X), st>>>(
+              (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+        } else {
+          // one point per quad of lanes: a group addition is 4 rounds of one multiplication instead of 14 in a row
+          k_chunks_q<C><<<dim3((unsigned)((4 * n_chunks + p->red_block - 1) / p->red_block)), dim3(p->red_block), 0, st>>>((const X*)p->d_buckets, n_chunks,
+                                                                                           p->L, (X*)p->d_A, (X*)p->d_W0);
+          constexpr int RB = 512;  // 128 quads, 24 KB of LDS per block
+          k_masked_sums_q<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
+              (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+        }
       } else {
-        // one point per quad of lanes: a group addition is 4 rounds of one multiplication instead of 14 in a row
-        k_chunks_q<C><<<dim3((unsigned)((4 * n_chunks + p->red_block - 1) / p->red_block)), dim3(p->red_block), 0, st>>>((const X*)p->d_buckets, n_chunks,
-                                                                                         p->L, (X*)p->d_A, (X*)p->d_W0);
-        constexpr int RB = 512;  // 128 quads, 24 KB of LDS per block
-        k_masked_sums_q<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X), st>>>(
-            (const X*)p->d_A, (const X*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+        return mlhip_rt::fail(MLHIP_EINVAL, "G1 reduction: the carry-free bucket state is missing");
       }
     }
   }
@@ -488,7 +492,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
             if (p->reduce28) {  // one segment that is first and last, leaving the raw accumulators for k_chunks_lp28
               const dim3 grid((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), block(p->acc_block);
               bool kc = false;
-              if constexpr (C::BETA == -1) {
+              if constexpr (C::BETA == -1 && kBuildAlt) {
                 if (g2_split_by_coordinate()) {
                   k_accumulate28_kc_seg<C><<<grid, block, 0, st>>>(
                       (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
@@ -505,17 +509,21 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
               done28 = true;
             }
           }
-          if (!done28)
-            k_accumulate28_lp<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-                (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
-                big_threshold, p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
+          if constexpr (kBuildAlt) {  // (MLHIP_REDUCE32=1: the buckets leave in the boundary form)
+            if (!done28)
+              k_accumulate28_lp<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+                  (const AffineG2_28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order,
+                  big_threshold, p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
+          }
           done28 = true;
         }
       }
-      if (!done28)
-        k_accumulate_lp<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-            (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
-            p->d_bigcount, (X*)p->d_buckets);
+      if constexpr (kBuildAlt) {  // (MLHIP_ACC32=1)
+        if (!done28)
+          k_accumulate_lp<C><<<dim3((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
+              (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
+              p->d_bigcount, (X*)p->d_buckets);
+      }
     } else if (p->d_points28) {
       HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
       if (p->reduce28 && nbuckets <= QUAD_ACC_MAX_BUCKETS && !getenv("MLHIP_NO_QUAD_ACC"))
@@ -533,11 +541,11 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
             (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
             p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, MLHIP_SEG_FIRST | MLHIP_SEG_LAST | MLHIP_SEG_KEEP28,
             (X*)p->d_buckets);
-      else
+      else if constexpr (kBuildAlt)  // (MLHIP_REDUCE32=1 / MLHIP_REDUCE_ONE_LANE=1: the buckets leave in the boundary form)
         k_accumulate28<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
             (const Affine28<C>*)p->d_points28, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold,
             p->d_biglist, p->d_bigcount, (X*)p->d_buckets);
-    } else {
+    } else if constexpr (kBuildAlt) {  // (MLHIP_ACC32=1)
       k_accumulate<F><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
           (const A*)d_points, p->d_sorted, p->d_offsets, p->d_counts, nbuckets, p->d_order, big_threshold, p->d_biglist,
           p->d_bigcount, (X*)p->d_buckets);
@@ -570,9 +578,11 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
           folded = true;
         }
       }
-      if (!folded)
-        k_accumulate_big<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
-                                                                              (const X*)p->d_bigpart, (X*)p->d_buckets);
+      if constexpr (kBuildAlt) {  // (boundary-form buckets)
+        if (!folded)
+          k_accumulate_big<F, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(p->d_biglist, p->d_bigcount, p->d_bigprefix,
+                                                                                (const X*)p->d_bigpart, (X*)p->d_buckets);
+      }
     }
     {
       int rc_red = launch_reduce<C, F>(p, st);
@@ -714,7 +724,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   if constexpr (kG2) {
     const dim3 grid((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), block(p->acc_block);
     bool kc = false;
-    if constexpr (C::BETA == -1) {
+    if constexpr (C::BETA == -1 && kBuildAlt) {
       if (g2_split_by_coordinate()) {
         k_accumulate28_kc_seg<C><<<grid, block, 0, st>>>(
             (const AffineG2_28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,

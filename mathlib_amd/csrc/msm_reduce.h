@@ -193,7 +193,7 @@ __device__ __forceinline__ void quad28_add_any(Fp28<C>& a, const Fp28<C>& b) {
     quad28_xyzz_add<C, QuadDevice28<C>>(a, b);
 }
 
-template <class C, bool ED = false>
+template <class C, bool ED = false, bool TWO = false>
 __global__ void __launch_bounds__(256) k_chunks_q28(const XYZZ28<C>* __restrict__ buckets, size_t n_chunks, int l_eff,
                                                     XYZZ28<C>* __restrict__ A, XYZZ28<C>* __restrict__ W0) {
   const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
@@ -203,6 +203,21 @@ __global__ void __launch_bounds__(256) k_chunks_q28(const XYZZ28<C>* __restrict_
   quad28_empty<C, ED>(acc);
   quad28_empty<C, ED>(w0);
   quad28_load<C>(cur, b, l_eff - 1);
+  if constexpr (TWO) {
+    // the two additions of a bucket written out (acc += b[i]; w0 += acc) instead of one body that selects its operands:
+    // 56 selects less per step, twice the code (MLHIP_CHUNKS_TWO=1, A/B of round 4)
+#pragma unroll 1
+    for (int i = l_eff - 1; i >= 0; i--) {
+      Fp28<C> nxt = cur;
+      if (i > 0) quad28_load<C>(nxt, b, i - 1);
+      quad28_add_any<C, ED>(acc, cur);
+      if (i > 0) quad28_add_any<C, ED>(w0, acc);
+      cur = nxt;
+    }
+    quad28_store<C>(A, g, acc);
+    quad28_store<C>(W0, g, w0);
+    return;
+  }
   const int steps = 2 * (l_eff - 1) + 1;  // acc += b[i]; w0 += acc; ... ; acc += b[0]
 #pragma unroll 1
   for (int s = 0; s < steps; s++) {

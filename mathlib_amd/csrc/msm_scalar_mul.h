@@ -99,7 +99,10 @@ __global__ void __launch_bounds__(64) k_scalar_mul(const Affine<F>* __restrict__
 // later one a tenth of it.
 constexpr size_t FIXED_BASE_MIN = (size_t)1 << 12;
 constexpr int FB_W_G1 = 12, FB_W_G2 = 12, FB_W_MIN = 4, FB_W_MAX = 14;
-constexpr size_t FB_HEADER = 512;  // bytes in front of the table: [flag | tag | base point (<= 192 bytes)]
+constexpr size_t FB_HEADER = 512;  // bytes in front of the table: [flag | tag | base point (<= 192 bytes) | ... | FB_FLAG_ED]
+// header word: 1 iff the base lies in the prime-order subgroup ([r]P = infinity, computed by the table build itself as one
+// extra entry) on a curve with a twisted Edwards model -- the products then run on the 7-product Edwards addition (ed28.h)
+constexpr uint32_t FB_FLAG_ED = 120;
 MLHIP_HD int fb_windows(int w) { return (256 + w - 1) / w; }
 
 struct FixedBaseScratch {
@@ -147,20 +150,36 @@ static __global__ void __launch_bounds__(64) k_fb_check(uint32_t* __restrict__ h
   }
 }
 static __global__ void __launch_bounds__(64) k_fb_commit(uint32_t* __restrict__ header, const uint32_t* __restrict__ base,
-                                                         uint32_t nwords, uint32_t tag) {
-  if (header[0]) return;  // the table was there already
+                                                         uint32_t nwords, uint32_t tag, const uint32_t* __restrict__ r_times_base) {
+  if (header[0]) return;  // the table was there already (and so is its subgroup flag)
   const uint32_t lane = threadIdx.x;
   if (lane < nwords) header[2 + lane] = base[lane];
+  // r_times_base: the table build's extra entry [r]P (affine, (0, 0) = infinity) -- nullptr on curves without the Edwards path
+  bool zero = true;
+  if (r_times_base && lane < nwords) zero = r_times_base[lane] == 0u;
+  const bool in_subgroup = r_times_base != nullptr && __all(zero) != 0;
   __syncthreads();
-  if (lane == 0) header[1] = tag;
+  if (lane == 0) {
+    header[FB_FLAG_ED] = in_subgroup ? 1u : 0u;
+    header[1] = tag;
+  }
 }
 
 // the table's scalars: entry t = j * row + (m - 1) is the plain integer m 2^(wj); where that does not fit 256 bits (the
 // upper part of the top window's row, which no scalar below 2^255 reaches) the entry is 0 = the point at infinity
+struct FbOrder {
+  uint32_t w[8];  // the group order r as a plain integer (the extra entry [r]P of a table on a curve with the Edwards path)
+};
 static __global__ void __launch_bounds__(256) k_fb_scalars(uint32_t* __restrict__ out, int w, uint32_t entries,
-                                                           const uint32_t* __restrict__ skip) {
+                                                           const uint32_t* __restrict__ skip, FbOrder order, int extra) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= entries || *skip) return;
+  if (*skip) return;
+  if (extra && t == entries) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[8 * t + k] = order.w[k];
+    return;
+  }
+  if (t >= entries) return;
   const uint32_t row = 1u << (w - 1);
   const uint32_t j = t / row, m = t % row + 1;
   const uint32_t off = j * (uint32_t)w, word = off >> 5, sh = off & 31u;
@@ -182,11 +201,90 @@ static __global__ void __launch_bounds__(256) k_fb_scalars(uint32_t* __restrict_
   for (int k = 0; k < 8; k++) out[8 * t + k] = fits ? o[k] : 0u;
 }
 
+// the table in the form the product kernel of this call wants: Weierstrass rows, or (subgroup flag set) halved Niels triples
+template <class C>
+__global__ void __launch_bounds__(256) k_fb_table_to28(const Affine<FpField<C>>* __restrict__ points, size_t n,
+                                                       Affine28<C>* __restrict__ out, const uint32_t* __restrict__ header, int ed_on) {
+  if constexpr (C::HAS_EDWARDS)
+    if (ed_on && header[FB_FLAG_ED]) return;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine28<C> q;
+  affine28_from<C>(q, points[i]);
+  out[i] = q;
+}
+template <class C>
+__global__ void __launch_bounds__(256) k_fb_table_to_ed28(const Affine<FpField<C>>* __restrict__ points, size_t n,
+                                                          EdNiels28<C>* __restrict__ out, const uint32_t* __restrict__ header, int ed_on) {
+  if (!ed_on || !header[FB_FLAG_ED]) return;
+  constexpr int K = 4;  // four points share one inversion (k_points_to_ed28)
+  const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * K;
+  if (i0 >= n) return;
+  Affine<FpField<C>> in[K];
+  Fp<C> xh[K], yh[K];
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    if (i0 + j < n) {
+      in[j] = points[i0 + j];
+    } else {
+      fp_zero<C>(in[j].x);
+      fp_zero<C>(in[j].y);
+    }
+  }
+  ed_affine_halves_batch<C, K>(xh, yh, in);
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    if (i0 + j < n) {
+      EdNiels28<C> q;
+      ed_niels_from_halves<C>(q, xh[j], yh[j]);
+      out[i0 + j] = q;
+    }
+  }
+}
+
+// [s_i]P from the Niels table of a base in the prime-order subgroup (BLS12-377 G1): ceil(256 / w) unified mixed additions of
+// 7 products each -- no square, no carry propagation, no P = +-Q test (ed28_madd) -- against 10 products + the filter of the
+// XYZZ form below; one conversion back to the Weierstrass curve (10 products) and one inversion per result.
+template <class C>
+__global__ void __launch_bounds__(64) k_fixed_base_ed(const EdNiels28<C>* __restrict__ table, const uint32_t* __restrict__ scalars,
+                                                      int mont, size_t n, Affine<FpField<C>>* __restrict__ out, int w,
+                                                      const uint32_t* __restrict__ header, int ed_on) {
+  typedef FpField<C> F;
+  if (!ed_on || !header[FB_FLAG_ED]) return;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+  fr_canonical<C>(s, scalars + 8 * i, mont != 0);
+  EdExt28<C> acc;
+  ed28_set_identity<C>(acc);
+  const int nw = fb_windows(w);
+  uint32_t carry = 0, neg = 0;
+#pragma unroll 1
+  for (int j = 0; j < nw; j++) {
+    const uint32_t m = msm_window_digit(s, j * w, w, carry, neg);
+    if (m) {
+      const EdNiels28<C> q = table[((size_t)j << (w - 1)) + m - 1];
+      ed28_madd<C>(acc, q, neg != 0);
+    }
+  }
+  XYZZ28<C> x28;
+  bool inf;
+  ed28_to_xyzz28<C>(x28, inf, acc);
+  XYZZ<F> r;
+  xyzz28_to<C>(r, x28, inf);
+  Affine<F> a;
+  xyzz_to_affine<F>(a, r);
+  out[i] = a;
+}
+
 template <class C>
 __global__ void __launch_bounds__(64) k_fixed_base_g1(const Affine28<C>* __restrict__ table,
                                                       const uint32_t* __restrict__ scalars, int mont, size_t n,
-                                                      Affine<FpField<C>>* __restrict__ out, int w) {
+                                                      Affine<FpField<C>>* __restrict__ out, int w,
+                                                      const uint32_t* __restrict__ header, int ed_on) {
   typedef FpField<C> F;
+  if constexpr (C::HAS_EDWARDS)
+    if (ed_on && header[FB_FLAG_ED]) return;  // k_fixed_base_ed computes this call's products
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -378,8 +476,7 @@ template <class C, class F>
 int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_scalars, int mont, size_t n, void* d_out,
                       hipStream_t st) {
   if (n == 0) return 0;
-  const char* ol = getenv("MLHIP_SCALAR_MUL_ONE_LANE");
-  const bool one_lane = ol && ol[0] == '1';
+  const bool one_lane = mlhip_alt_switch("MLHIP_SCALAR_MUL_ONE_LANE");  // G2 on one lane per product: test build only
   (void)one_lane;
   size_t fb_min = FIXED_BASE_MIN;  // MLHIP_FIXED_BASE_MIN overrides (0 = never: always the double-and-add kernel)
   if (const char* e = getenv("MLHIP_FIXED_BASE_MIN")) {
@@ -396,11 +493,14 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
     const char* ce = getenv("MLHIP_FB_CACHE");
     const int use_cache = !(ce && ce[0] == '0');
     const size_t entries = (size_t)fb_windows(w) << (w - 1);
+    // a curve with the twisted Edwards model builds one entry more, [r]P: (0, 0) iff the base is in the prime-order subgroup
+    constexpr bool kEd = kG1 && C::HAS_EDWARDS;
+    const size_t built = entries + (kEd ? 1 : 0);
     // scratch: [header | table | its scalars | the table in the carry-free form] in one persistent buffer per device.
     // Calls on different streams reuse it in the order they take the lock: each waits for the event the previous
     // one recorded after its last kernel.  (hipMallocAsync here gave intermittently wrong results on this runtime.)
-    const size_t tab_bytes = entries * sizeof(Affine<F>), sc_bytes = entries * 32;
-    const size_t t28_bytes = kG1 ? entries * sizeof(Affine28<C>) : entries * sizeof(AffineG2_28<C>);
+    const size_t tab_bytes = built * sizeof(Affine<F>), sc_bytes = built * 32;
+    const size_t t28_bytes = kG1 ? entries * (kEd ? sizeof(EdNiels28<C>) : sizeof(Affine28<C>)) : entries * sizeof(AffineG2_28<C>);
     const size_t need = FB_HEADER + tab_bytes + sc_bytes + t28_bytes;
     static_assert(8 + sizeof(Affine<F>) <= FB_HEADER && sizeof(Affine<F>) / 4 <= 64, "the key fits the header and one wave");
     int dev = 0;
@@ -427,37 +527,52 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
     // and the lane-pair one give the same bytes; the bit only keeps an A/B honest)
     const uint32_t tag = 0x80000000u | ((uint32_t)C::ID << 16) | ((kG1 ? 1u : 2u) << 8) | (uint32_t)w | (one_lane ? 0x4000u : 0u);
     k_fb_check<<<dim3(1), dim3(64), 0, st>>>(header, (const uint32_t*)d_points, (uint32_t)(sizeof(Affine<F>) / 4), tag, use_cache);
-    k_fb_scalars<<<dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st>>>(tsc, w, (uint32_t)entries, header);
+    FbOrder order;
+    for (int k = 0; k < 8; k++) order.w[k] = C::FR[k];
+    k_fb_scalars<<<dim3((unsigned)((built + 255) / 256)), dim3(256), 0, st>>>(tsc, w, (uint32_t)entries, header, order, kEd ? 1 : 0);
     if constexpr (!kG1) {
       if (!one_lane)
         k_scalar_mul_lp<C><<<dim3((unsigned)((2 * entries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc,
                                                                                         -1, entries, table, header);
-      else
+      else if constexpr (kBuildAlt)
         k_scalar_mul<C, F><<<dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
                                                                                        entries, table, header);
     } else {
-      k_scalar_mul<C, F><<<dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
-                                                                                     entries, table, header);
+      k_scalar_mul<C, F><<<dim3((unsigned)((built + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, 0, tsc, -1,
+                                                                                   built, table, header);
     }
-    k_fb_commit<<<dim3(1), dim3(64), 0, st>>>(header, (const uint32_t*)d_points, (uint32_t)(sizeof(Affine<F>) / 4), tag);
+    k_fb_commit<<<dim3(1), dim3(64), 0, st>>>(header, (const uint32_t*)d_points, (uint32_t)(sizeof(Affine<F>) / 4), tag,
+                                              kEd ? (const uint32_t*)(table + entries) : nullptr);
     if constexpr (kG1) {
-      Affine28<C>* t28 = (Affine28<C>*)(scratch + tab_bytes + sc_bytes);
-      k_points_to28<C><<<dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st>>>(table, entries, t28);
-      k_fixed_base_g1<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(t28, (const uint32_t*)d_scalars, mont, n,
-                                                                             (Affine<F>*)d_out, w);
+      // the header's subgroup flag picks ONE of the two product kernels (the other returns at once): the Edwards form for a
+      // base in the prime-order subgroup -- generators, Pedersen bases -- the XYZZ form for any other curve point
+      char* t28raw = scratch + tab_bytes + sc_bytes;
+      const char* ede = getenv("MLHIP_EDWARDS");  // =0: the XYZZ products for every base (second implementation, A/B)
+      const int ed_on = (ede && ede[0] == '0') ? 0 : 1;
+      k_fb_table_to28<C><<<dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st>>>(table, entries, (Affine28<C>*)t28raw, header, ed_on);
+      if constexpr (kEd) {
+        k_fb_table_to_ed28<C><<<dim3((unsigned)(((entries + 3) / 4 + 255) / 256)), dim3(256), 0, st>>>(table, entries,
+                                                                                                  (EdNiels28<C>*)t28raw, header, ed_on);
+        k_fixed_base_ed<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const EdNiels28<C>*)t28raw, (const uint32_t*)d_scalars,
+                                                                               mont, n, (Affine<F>*)d_out, w, header, ed_on);
+      }
+      k_fixed_base_g1<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Affine28<C>*)t28raw, (const uint32_t*)d_scalars,
+                                                                             mont, n, (Affine<F>*)d_out, w, header, ed_on);
     } else {
-      const char* a32 = getenv("MLHIP_ACC32");  // =1: the boundary-form lane-pair kernel (second implementation)
-      if (!one_lane && !(a32 && a32[0] == '1')) {
+      const bool a32 = mlhip_alt_switch("MLHIP_ACC32");  // =1: the boundary-form lane-pair kernel (second implementation)
+      if (!one_lane && !a32) {
         AffineG2_28<C>* t28 = (AffineG2_28<C>*)(scratch + tab_bytes + sc_bytes);
         k_points_to28_g2<C><<<dim3((unsigned)((4 * entries + 255) / 256)), dim3(256), 0, st>>>(table, entries, t28);
         k_fixed_base_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>(t28, (const uint32_t*)d_scalars, mont, n,
                                                                                     (Affine<F>*)d_out, w);
-      } else if (!one_lane)
-        k_fixed_base_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
-                                                                                  (Affine<F>*)d_out, w);
-      else
-        k_fixed_base<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
-                                                                             (Affine<F>*)d_out, w);
+      } else if constexpr (kBuildAlt) {
+        if (!one_lane)
+          k_fixed_base_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
+                                                                                    (Affine<F>*)d_out, w);
+        else
+          k_fixed_base<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>(table, (const uint32_t*)d_scalars, mont, n,
+                                                                               (Affine<F>*)d_out, w);
+      }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(fb.last, st));
@@ -472,9 +587,11 @@ int scalar_mul_device(const void* d_points, size_t point_stride, const void* d_s
       return 0;
     }
   }
-  k_scalar_mul<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, point_stride,
-                                                                          (const uint32_t*)d_scalars, mont, n,
-                                                                          (Affine<F>*)d_out);
+  // G1, or (test build) G2 on one lane per product
+  if constexpr (std::is_same<F, FpField<C>>::value || kBuildAlt)
+    k_scalar_mul<C, F><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Affine<F>*)d_points, point_stride,
+                                                                            (const uint32_t*)d_scalars, mont, n,
+                                                                            (Affine<F>*)d_out);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -391,8 +391,7 @@ __global__ void __launch_bounds__(256) k_fp_mul(const Fp<C>* __restrict__ a, con
 template <class C>
 bool lp28_enabled() {
   (void)C::ID;  // all three curves
-  const char* e = getenv("MLHIP_PAIRING_SAT");
-  return !(e && e[0] == '1');
+  return !mlhip_alt_switch("MLHIP_PAIRING_SAT");  // (the saturated lane-pair kernels: test build only, except BN254's Miller loop)
 }
 
 // The batched entry points run the lane-pair kernels (two lanes per pairing); the one-lane-per-pairing
@@ -403,20 +402,21 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
   if (n == 0) return 0;
   typedef Affine<FpField<C>> A1;
   typedef Affine<Fp2Field<C>> A2;
-  const char* one_lane_env = getenv("MLHIP_PAIRING_ONE_LANE");  // read per batch so a test can switch paths
-  const bool one_lane = one_lane_env && one_lane_env[0] == '1';
+  const bool one_lane = mlhip_alt_switch("MLHIP_PAIRING_ONE_LANE");  // read per batch so a test can switch paths (test build only)
   if (one_lane) {
-    unsigned blocks = (unsigned)((n + 63) / 64);
-    switch (what) {
-      case 0:
-        k_miller<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, (Fp12<C>*)d_out);
-        break;
-      case 1:
-        k_final_exp<C><<<dim3(blocks), dim3(64), 0, st>>>((const Fp12<C>*)d_in, n, (Fp12<C>*)d_out);
-        break;
-      default:
-        k_pairing<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, (Fp12<C>*)d_out);
-        break;
+    if constexpr (kBuildAlt) {
+      unsigned blocks = (unsigned)((n + 63) / 64);
+      switch (what) {
+        case 0:
+          k_miller<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, (Fp12<C>*)d_out);
+          break;
+        case 1:
+          k_final_exp<C><<<dim3(blocks), dim3(64), 0, st>>>((const Fp12<C>*)d_in, n, (Fp12<C>*)d_out);
+          break;
+        default:
+          k_pairing<C><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, n, (Fp12<C>*)d_out);
+          break;
+      }
     }
   } else if (lp28_enabled<C>() && !(C::IS_BN && what == 0)) {
     // lane pairs in the carry-free form (MLHIP_PAIRING_SAT=1 selects the saturated lane-pair kernels below; BN254's Miller
@@ -468,23 +468,28 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
       }
     }
   } else {
+    // saturated lane pairs: BN254's Miller loop (the default there) and, in the test build, everything else (MLHIP_PAIRING_SAT=1)
     unsigned blocks = (unsigned)((2 * n + 63) / 64);
     switch (what) {
       case 0:
-        if (ppp == 1)
-          k_pairing_lp<C, 0, 1><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr,
-                                                                  (Fp12<C>*)d_out);
-        else
-          k_pairing_lp<C, 0, 4><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, nullptr,
-                                                                  (Fp12<C>*)d_out);
+        if constexpr (C::IS_BN || kBuildAlt) {
+          if (ppp == 1)
+            k_pairing_lp<C, 0, 1><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr,
+                                                                    (Fp12<C>*)d_out);
+          else
+            k_pairing_lp<C, 0, 4><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, (int)ppp, n, nullptr,
+                                                                    (Fp12<C>*)d_out);
+        }
         break;
       case 1:
-        k_pairing_lp<C, 1, 1><<<dim3(blocks), dim3(64), 0, st>>>(nullptr, nullptr, 1, n, (const Fp12<C>*)d_in,
-                                                             (Fp12<C>*)d_out);
+        if constexpr (kBuildAlt)
+          k_pairing_lp<C, 1, 1><<<dim3(blocks), dim3(64), 0, st>>>(nullptr, nullptr, 1, n, (const Fp12<C>*)d_in,
+                                                               (Fp12<C>*)d_out);
         break;
       default:
-        k_pairing_lp<C, 2, 1><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr,
-                                                             (Fp12<C>*)d_out);
+        if constexpr (kBuildAlt)
+          k_pairing_lp<C, 2, 1><<<dim3(blocks), dim3(64), 0, st>>>((const A1*)d_g1, (const A2*)d_g2, 1, n, nullptr,
+                                                               (Fp12<C>*)d_out);
         break;
     }
   }
@@ -649,11 +654,11 @@ __global__ void __launch_bounds__(64) MLHIP_LP_OCC k_gt_exp_lp28(const Fp12<C>* 
 
 template <class C>
 int gt_exp_device(const void* d_in, const void* d_scalars, int mont, size_t n, void* d_out, hipStream_t st) {
-  const char* one_lane_env = getenv("MLHIP_PAIRING_ONE_LANE");
-  if (one_lane_env && one_lane_env[0] == '1')
-    k_gt_exp<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars, mont, n,
-                                                                   (Fp12<C>*)d_out);
-  else if (lp28_enabled<C>()) {
+  if (mlhip_alt_switch("MLHIP_PAIRING_ONE_LANE")) {
+    if constexpr (kBuildAlt)
+      k_gt_exp<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars, mont, n,
+                                                                     (Fp12<C>*)d_out);
+  } else if (lp28_enabled<C>()) {
     if constexpr (C::ID == 1) {
       // quads at every size: the windowed chain is generic squarings and products, where a quad does the lane pair's work
       // in half the rounds without the 84-word operands crossing scratch (65 536: 15.7 ms against 19.2; 1 024: 4.0 / 7.9);
@@ -669,9 +674,10 @@ int gt_exp_device(const void* d_in, const void* d_scalars, int mont, size_t n, v
       k_gt_exp_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,
                                                                               mont, n, (Fp12<C>*)d_out);
     }
-  } else
+  } else if constexpr (kBuildAlt) {
     k_gt_exp_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,
                                                                           mont, n, (Fp12<C>*)d_out);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

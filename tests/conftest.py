@@ -45,6 +45,34 @@ def hostmath():
     return ctypes.CDLL(so)
 
 
+# switches that select a second implementation which only the test build contains (python -m mathlib_amd.build --alt,
+# MLHIP_LIB=mathlib_amd/libmlhip_alt.so); include/mlhip.h lists them under "2nd impl"
+ALT_SWITCHES = ("MLHIP_ACC32", "MLHIP_REDUCE32", "MLHIP_REDUCE_ONE_LANE", "MLHIP_G2_KC", "MLHIP_PAIRING_ONE_LANE", "MLHIP_PAIRING_SAT",
+                "MLHIP_SCALAR_MUL_ONE_LANE")
+
+
+def alt_build() -> bool:
+    """Is the loaded library the test build (mlhip_version() bit 16)?"""
+    from mathlib_amd import _lib
+
+    return bool(_lib.load().mlhip_version() & 0x10000)
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, except that switching on a second implementation the loaded library does not contain skips
+    the test (the product library ignores those switches: the test would silently re-run the default path)."""
+    plain = monkeypatch.setenv
+
+    def setenv(name, value, *a, **k):
+        if name in ALT_SWITCHES and str(value) == "1" and not alt_build():
+            pytest.skip("%s=1 needs the test build (python -m mathlib_amd.build --alt; MLHIP_LIB=mathlib_amd/libmlhip_alt.so)" % name)
+        return plain(name, value, *a, **k)
+
+    monkeypatch.setenv = setenv
+    return monkeypatch
+
+
 @pytest.fixture(scope="session")
 def mlhip():
     from mathlib_amd import _lib

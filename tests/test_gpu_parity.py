@@ -609,7 +609,10 @@ def test_pairing_saturated_lane_pair_kernels_agree(lib, mlhip, monkeypatch):
     p1, p2 = bytes(p1), bytes(p2)
     want = cref.pairing_batch(cid, p1, p2, n, 8)
     res = {}
-    for sat in ("0", "1"):
+    from conftest import alt_build
+
+    sats = ("0", "1") if alt_build() else ("0",)  # the saturated kernels are in the test build only
+    for sat in sats:
         monkeypatch.setenv("MLHIP_PAIRING_SAT", sat)
         out = ctypes.create_string_buffer(gtb * n)
         mlhip.check(lib.mlhip_pairing_batch(cid, p1, p2, n, out))
@@ -635,8 +638,8 @@ def test_pairing_saturated_lane_pair_kernels_agree(lib, mlhip, monkeypatch):
         ge = ctypes.create_string_buffer(gtb * m)
         mlhip.check(lib.mlhip_gt_exp(cid, ml.raw[: gtb * m], sc.tobytes(), 0, m, ge))
         res["gt_exp" + sat] = ge.raw
-    assert res["gt_exp0"] == res["gt_exp1"]
-    assert res["0"] == res["1"] == cref.final_exp(cid, cref.miller_loop(cid, p1, p2, 2, n // 2, 8), n // 2, 8)
+    assert all(res["gt_exp" + x] == res["gt_exp0"] for x in sats)
+    assert all(res[x] == cref.final_exp(cid, cref.miller_loop(cid, p1, p2, 2, n // 2, 8), n // 2, 8) for x in sats)
 
 
 def test_pairing_quad_lane_kernels_agree(lib, mlhip, monkeypatch):
@@ -1083,8 +1086,10 @@ def test_msm_shared_scalars(lib, mlhip, curve, monkeypatch):
         ds = torch.frombuffer(bytearray(sc.tobytes()), dtype=torch.uint8).to(dev)
         want1 = cref.msm(cid, 1, p1, sc, n, False, 0, 8)
         want2 = cref.msm(cid, 2, p2, sc, n, False, 0, 8)
-        for env, c1, c2 in (({}, 12, 12), ({"MLHIP_TILE_LOG2": "10"}, 12, 12), ({"MLHIP_TILE_LOG2": "9"}, 8, 8), ({}, 12, 9),
-                            ({"MLHIP_ACC32": "1"}, 12, 12)):
+        from conftest import alt_build
+
+        for env, c1, c2 in (({}, 12, 12), ({"MLHIP_TILE_LOG2": "10"}, 12, 12), ({"MLHIP_TILE_LOG2": "9"}, 8, 8), ({}, 12, 9)) + (
+                (({"MLHIP_ACC32": "1"}, 12, 12),) if alt_build() else ()):  # plans that cannot share: test build only
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             a = mlhip.MsmPlan(cid, 1, n, c1)

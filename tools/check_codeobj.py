@@ -18,6 +18,11 @@ Two checks, both on the disassembly of the shipped code objects (llvm-objdump; a
      deepest chain of callee frames (frames read from the prologues, the call graph from the s_getpc / s_swappc pairs),
      no kernel uses a dynamic stack, and every call target resolves to a function of the same code object.
 
+  3. host / device agreement -- every kernel the host side of the library can launch (its handle symbols, named like the
+     kernels) exists in one of the code objects.  hipcc compiles a translation unit twice, device pass first: a header
+     edited between the two passes of a running build gives a library whose launches abort with "Cannot find Symbol"
+     (it happened in round 4; the build is never edited under any more, and this check catches it if it is).
+
 Usage: tools/check_codeobj.py [path ...]   (default: mathlib_amd/libmlhip.so); exit status 1 on any finding.
 Used by tests/test_codeobj.py.
 """
@@ -25,6 +30,7 @@ from __future__ import annotations
 
 import os
 import re
+import shutil
 import struct
 import subprocess
 import sys
@@ -263,7 +269,8 @@ def check_code_object(co: bytes) -> tuple[list[str], dict]:
     funcs, kernels = disassemble(co)
     analyse_frames(funcs, kernels)
     findings = []
-    stats = {"functions": len(funcs), "kernels": len(kernels), "kernels_with_calls": 0, "flat_insns": 0, "max_scratch": 0}
+    stats = {"functions": len(funcs), "kernels": len(kernels), "kernels_with_calls": 0, "flat_insns": 0, "max_scratch": 0,
+             "kernel_names": sorted(kernels)}
     memo: dict[str, int] = {}
     for f in funcs.values():
         findings += check_flat_bias(f)
@@ -290,6 +297,25 @@ def _check_one(co: bytes):
     return check_code_object(co)
 
 
+def host_kernel_handles(path: str) -> set[str]:
+    """Mangled names of the kernels the host code of `path` registers: for every `__device_stub__` function clang emits a
+    data symbol (the launch handle) that carries the kernel's own mangled name."""
+    out = subprocess.run([shutil.which("nm") or _tool("llvm-nm"), path], capture_output=True, text=True)
+    if out.returncode != 0:
+        return set()
+    data, stubs = set(), 0
+    for ln in out.stdout.splitlines():
+        parts = ln.split()
+        if len(parts) < 2:
+            continue
+        typ, name = parts[-2], parts[-1]
+        if "__device_stub__" in name:
+            stubs += 1
+        elif typ in "VvBbDd" and name.startswith("_Z") and re.search(r"\d+k_[a-z0-9_]+", name):
+            data.add(name)
+    return data if stubs else set()
+
+
 def check_file(path: str, jobs: int = 1) -> tuple[list[str], dict]:
     total = {"code_objects": 0, "functions": 0, "kernels": 0, "kernels_with_calls": 0, "flat_insns": 0, "max_scratch": 0}
     findings = []
@@ -301,6 +327,13 @@ def check_file(path: str, jobs: int = 1) -> tuple[list[str], dict]:
             results = list(ex.map(_check_one, cos))
     else:
         results = [check_code_object(co) for co in cos]
+    device_kernels = set()
+    for _, st in results:
+        device_kernels |= set(st.pop("kernel_names"))
+    handles = host_kernel_handles(path)
+    total["host_kernel_handles"] = len(handles)
+    for h in sorted(handles - device_kernels):
+        findings.append("host code can launch %s but no code object defines it (sources edited during the build?)" % h)
     for f, s in results:
         findings += f
         total["code_objects"] += 1

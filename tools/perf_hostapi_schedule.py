@@ -63,10 +63,12 @@ def setenv(kind, val):
         os.environ["MLHIP_STREAM_SCHEDULE"] = val
 
 
-variants_c = [("default", ""), ("equal", "4"), ("equal", "0"), ("sched", "1,1,2,3,4,5"), ("sched", "1,2,3,4,6"), ("sched", "1,1,2,4,8"),
-              ("sched", "2,3,5,6"), ("sched", "1,3,5,7"), ("sched", "1,1,1,2,3,3,5"), ("sched", "1,2,2,3,4,4")]
-variants_b = [("default", ""), ("equal", "4"), ("equal", "0"), ("equal", "2"), ("sched", "3,13"), ("sched", "2,14"), ("sched", "1,4,11"),
-              ("sched", "1,3,12"), ("sched", "4,12"), ("sched", "2,6,8")]
+variants_c = [("default", ""), ("equal", "4"), ("equal", "0"), ("equal", "5"), ("equal", "6"), ("equal", "8"), ("sched", "1,2,2,3,4,4"),
+              ("sched", "5,6,7,7,7"), ("sched", "3,4,4,5"), ("sched", "4,5,5,5,6,7"), ("sched", "2,3,5,6"), ("sched", "1,1,2,3,4,5")]
+variants_b = [("default", ""), ("equal", "4"), ("equal", "0"), ("sched", "3,13"), ("sched", "1,4,11"), ("sched", "4,12"), ("sched", "2,6,8")]
+if len(sys.argv) > 3:  # a third argument keeps only the default and the round 1-3 form (quick A/B at other sizes)
+    variants_c = variants_c[:3]
+    variants_b = variants_b[:3]
 rounds = 3  # alternate the variants: box drift shows up as spread inside a variant, not as a difference between them
 acc = {("c",) + v: [] for v in variants_c}
 acc.update({("b",) + v: [] for v in variants_b})
