@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "ec28.h"
+#include "ec_jac.h"
 #include "ed28.h"
 #include "ec28_lp.h"
 #include "ec28_kc.h"

@@ -194,16 +194,11 @@ void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
   memcpy(blob.data() + sizeof(h), p->h_out, sums);
   std::vector<XYZZ<F>> V(p->W);
   mlhip_rt::host_parallel(p->W, host_tail_window<F>, blob.data(), blob.size(), V.data(), sizeof(XYZZ<F>));
-  xyzz_set_inf<F>(total);
-  for (int w = p->W - 1; w >= 0; w--) {
-    xyzz_add<F>(total, V[w]);
-    const int down = w > 0 ? msm_win_off(wl.base, wl.rem, w) - msm_win_off(wl.base, wl.rem, w - 1) : 0;
-    for (int k = 0; k < down; k++) {
-      XYZZ<F> d;
-      xyzz_dbl<F>(d, total);
-      total = d;
-    }
-  }
+  // the sequential part: one doubling per scalar bit.  In Jacobian coordinates since round 4 (ec_jac.h: 2M + 5S a doubling
+  // instead of 6M + 3S; the 16 additions are dearer and do not matter)
+  std::vector<int> down(p->W, 0);
+  for (int w = 1; w < p->W; w++) down[w] = msm_win_off(wl.base, wl.rem, w) - msm_win_off(wl.base, wl.rem, w - 1);
+  horner_jac<F>(total, V.data(), p->W, down.data());
 }
 
 // slice sums of the long buckets listed by the accumulation kernel (nothing to do, two near-empty launches, when
@@ -351,11 +346,7 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
           }
         }
         if (!done_ed) {
-          const char* two = getenv("MLHIP_CHUNKS_TWO");
-          if (two && two[0] == '1')
-            k_chunks_q28<C, false, true><<<cgrid, cblock, 0, st>>>((const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
-          else
-            k_chunks_q28<C><<<cgrid, cblock, 0, st>>>((const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
+          k_chunks_q28<C><<<cgrid, cblock, 0, st>>>((const X28*)p->d_state28, n_chunks, p->L, (X28*)p->d_A, (X28*)p->d_W0);
           k_masked_sums_q28<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X28), st>>>(
               (const X28*)p->d_A, (const X28*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
         }
@@ -882,7 +873,7 @@ int sort_ahead_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s) {
 //       its scalars, under the upload of its points -- stream_tile.)
 // MLHIP_STREAM_SCHEDULE="w0,w1,..." (weights, at most MLHIP_MAX_SEGMENTS) overrides; MLHIP_STREAM_SEGMENTS = K keeps K equal
 // segments (what the tests use to force many segments on small inputs).
-inline void stream_schedule(StreamCtx& cx, bool points_travel) {
+inline void stream_schedule(StreamCtx& cx, bool points_travel, size_t tile) {
   int w[MLHIP_MAX_SEGMENTS];
   int k = 0;
   if (const char* e = getenv("MLHIP_STREAM_SCHEDULE")) {
@@ -895,8 +886,26 @@ inline void stream_schedule(StreamCtx& cx, bool points_travel) {
   } else if (getenv("MLHIP_STREAM_SEGMENTS")) {
     return;  // K equal segments
   } else if (cx.n >= ((size_t)1 << 20) && !points_travel) {
-    w[k++] = 3;
-    w[k++] = 13;
+    // resident bases: 3 x 2^16 pairs first, then segments that grow fourfold (the scalars of the next segment -- 0.6 ns a
+    // pair on the wire -- must arrive within the kernels of this one -- 2.5 ns a pair) up to one tile (2^21 pairs: what keeps
+    // a segment's W passes over its points near the chip, resident_tiles); a remainder shorter than the first segment joins
+    // the segment before it.  2^20: 3 | 13 sixteenths; 2^21: 0.19 | 0.75 | 1.06 M; 2^22: 0.19 | 0.75 | 2.0 | 1.06 M.
+    const size_t first = (size_t)3 << 16;
+    size_t off = 0, len = first;
+    int m = 0;
+    cx.bound[0] = 0;
+    while (off < cx.n && m < MLHIP_MAX_SEGMENTS) {
+      size_t take = std::min(len, cx.n - off);
+      if (cx.n - off - take < first || m + 1 == MLHIP_MAX_SEGMENTS) take = cx.n - off;  // no crumb at the end
+      off += take;
+      cx.bound[++m] = off;
+      len = std::min(len * 4, tile);
+    }
+    if (m >= 2) {
+      cx.K = m;
+      cx.scheduled = true;
+    }
+    return;
   }
   if (k < 2) return;
   long long total = 0;
@@ -926,7 +935,8 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
   cx.mont = mont;
   cx.n = n;
   cx.K = K;
-  if (h_scalars && std::is_same<F, FpField<C>>::value) stream_schedule(cx, h_points != nullptr);
+  if (h_scalars && std::is_same<F, FpField<C>>::value)
+    stream_schedule(cx, h_points != nullptr, (size_t)1 << (plan_use_edwards<C, F>(p) ? 20 : 21));  // the tile of resident_tiles
   int rc = stream_begin<C, F>(p, cx, st, 2);
   if (rc) return rc;
   bool ahead = false;

@@ -193,42 +193,26 @@ __device__ __forceinline__ void quad28_add_any(Fp28<C>& a, const Fp28<C>& b) {
     quad28_xyzz_add<C, QuadDevice28<C>>(a, b);
 }
 
-template <class C, bool ED = false, bool TWO = false>
+// Per chunk of l_eff consecutive buckets: A = sum_i b[i] and W0 = sum_i i b[i] as a running sum from the top bucket down
+// (acc += b[i]; w0 += acc).  The two additions of a bucket are written out (round 4; one loop body that selected its
+// operands cost 56 selects per step: reduction 0.420 -> 0.410 ms at 2^20, profiles/r04_chunks_two_ab.txt).
+template <class C, bool ED = false>
 __global__ void __launch_bounds__(256) k_chunks_q28(const XYZZ28<C>* __restrict__ buckets, size_t n_chunks, int l_eff,
                                                     XYZZ28<C>* __restrict__ A, XYZZ28<C>* __restrict__ W0) {
   const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   if (g >= n_chunks) return;  // quad-uniform
   const XYZZ28<C>* b = buckets + g * (size_t)l_eff;
-  Fp28<C> acc, w0, cur, x, y;
+  Fp28<C> acc, w0, cur;
   quad28_empty<C, ED>(acc);
   quad28_empty<C, ED>(w0);
   quad28_load<C>(cur, b, l_eff - 1);
-  if constexpr (TWO) {
-    // the two additions of a bucket written out (acc += b[i]; w0 += acc) instead of one body that selects its operands:
-    // 56 selects less per step, twice the code (MLHIP_CHUNKS_TWO=1, A/B of round 4)
 #pragma unroll 1
-    for (int i = l_eff - 1; i >= 0; i--) {
-      Fp28<C> nxt = cur;
-      if (i > 0) quad28_load<C>(nxt, b, i - 1);
-      quad28_add_any<C, ED>(acc, cur);
-      if (i > 0) quad28_add_any<C, ED>(w0, acc);
-      cur = nxt;
-    }
-    quad28_store<C>(A, g, acc);
-    quad28_store<C>(W0, g, w0);
-    return;
-  }
-  const int steps = 2 * (l_eff - 1) + 1;  // acc += b[i]; w0 += acc; ... ; acc += b[0]
-#pragma unroll 1
-  for (int s = 0; s < steps; s++) {
-    const bool odd = (s & 1) != 0;
-    const int i = l_eff - 1 - (s >> 1);
-    fp28_select<C>(x, odd, w0, acc);
-    fp28_select<C>(y, odd, acc, cur);
-    if (!odd && i > 0) quad28_load<C>(cur, b, i - 1);  // the next bucket arrives under this addition
-    quad28_add_any<C, ED>(x, y);
-    fp28_select<C>(w0, odd, x, w0);
-    fp28_select<C>(acc, odd, acc, x);
+  for (int i = l_eff - 1; i >= 0; i--) {
+    Fp28<C> nxt = cur;
+    if (i > 0) quad28_load<C>(nxt, b, i - 1);  // the next bucket arrives under these additions
+    quad28_add_any<C, ED>(acc, cur);
+    if (i > 0) quad28_add_any<C, ED>(w0, acc);
+    cur = nxt;
   }
   quad28_store<C>(A, g, acc);
   quad28_store<C>(W0, g, w0);

@@ -9,6 +9,7 @@
 #include "../../mathlib_amd/csrc/msm_body.h"
 #include "../../mathlib_amd/csrc/codec.h"
 #include "../../mathlib_amd/csrc/ec28.h"
+#include "../../mathlib_amd/csrc/ec_jac.h"
 #include "../../mathlib_amd/csrc/ec_quad.h"
 #include "../../mathlib_amd/csrc/ec_quad28.h"
 #include "../../mathlib_amd/csrc/ec28_lp.h"
@@ -166,6 +167,30 @@ struct Ops {
       memcpy((char*)outA + g * sizeof(A1), &r, sizeof(A1));
       xyzz_to_affine<FpField<C>>(r, W0[g]);
       memcpy((char*)outW0 + g * sizeof(A1), &r, sizeof(A1));
+    }
+    return 0;
+  }
+  // the Horner pass of the host tail (msm_plan.h: host_tail): sum_w 2^off[w] V[w] over affine inputs V[w], in XYZZ (which = 0,
+  // rounds 1-3) or Jacobian coordinates (which = 1, ec_jac.h); group 1 or 2; affine result
+  static int horner(int group, const void* pts, int W, const int* down, int which, void* out) {
+    if (group == 1) {
+      const A1* p = (const A1*)pts;
+      std::vector<X1> V(W);
+      for (int i = 0; i < W; i++) xyzz_from_affine<FpField<C>>(V[i], p[i]);
+      X1 t;
+      if (which) horner_jac<FpField<C>>(t, V.data(), W, down); else horner_xyzz<FpField<C>>(t, V.data(), W, down);
+      A1 r;
+      xyzz_to_affine<FpField<C>>(r, t);
+      memcpy(out, &r, sizeof(A1));
+    } else {
+      const A2* p = (const A2*)pts;
+      std::vector<X2> V(W);
+      for (int i = 0; i < W; i++) xyzz_from_affine<Fp2Field<C>>(V[i], p[i]);
+      X2 t;
+      if (which) horner_jac<Fp2Field<C>>(t, V.data(), W, down); else horner_xyzz<Fp2Field<C>>(t, V.data(), W, down);
+      A2 r;
+      xyzz_to_affine<Fp2Field<C>>(r, t);
+      memcpy(out, &r, sizeof(A2));
     }
     return 0;
   }
@@ -816,6 +841,7 @@ int hm_g2_sum(int curve, const void* pts, const uint8_t* neg, int n, void* out) 
 int hm_g1_tree(int curve, const void* pts, int n, void* out) { DISPATCH(curve, g1_tree(pts, n, out)) }
 int hm_g2_tree(int curve, const void* pts, int n, void* out) { DISPATCH(curve, g2_tree(pts, n, out)) }
 int hm_digits(int curve, const void* scalar, int mont, int c, uint32_t* out, int cap) { DISPATCH(curve, digits(scalar, mont, c, out, cap)) }
+int hm_horner(int curve, int group, const void* pts, int W, const int* down, int which, void* out) { DISPATCH(curve, horner(group, pts, W, down, which, out)) }
 int hm_chunks(int curve, const void* pts, int n_chunks, void* outA, void* outW0) { DISPATCH(curve, chunks(pts, n_chunks, outA, outW0)) }
 int hm_g1_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g1dec(w, compressed, subgroup, out)) }
 int hm_g1_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g1enc(pt, compressed, w)) }

@@ -63,6 +63,45 @@ def test_fp12_tower(hostmath, name):
 
 
 @pytest.mark.parametrize("name", CURVES)
+def test_host_tail_horner_in_jacobian_coordinates(hostmath, name):
+    """ec_jac.h (round 4): the Horner pass of an MSM's host tail, sum_w 2^off[w] V[w], in Jacobian coordinates (dbl-2009-l,
+    add-2007-bl, XYZZ <-> Jacobian without an inversion) against the XYZZ pass it replaces and against Python integers:
+    G1 and G2, window sums that are infinity, equal (the addition's doubling branch: 2 V + V after one doubling of V),
+    opposite, uneven window widths."""
+    cp = R.CURVES[name]
+    L, cid, n = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("hm/horner/" + name)
+    for group in (1, 2):
+        rand, add, neg, mul = (R.random_g1, R.g1_add, R.g1_neg, R.g1_mul_unreduced) if group == 1 else (R.random_g2, R.g2_add, R.g2_neg, R.g2_mul_unreduced)
+        enc = R.g1_to_mont_bytes if group == 1 else R.g2_to_mont_bytes
+        dec = R.g1_from_mont_bytes if group == 1 else R.g2_from_mont_bytes
+        size = (2 if group == 1 else 4) * n
+        p, q = rand(cp, d), rand(cp, d)
+        cases = [
+            ([rand(cp, d) for _ in range(16)], [0] + [16] * 15),
+            ([rand(cp, d) for _ in range(5)], [0, 3, 1, 7, 2]),
+            ([None, p, None, q, None], [0, 2, 2, 1, 5]),
+            ([p, p], [0, 1]),               # 2 p + p
+            ([mul(cp, p, 2), neg(cp, p)], [0, 1]),   # 2 (-p) + 2 p = infinity
+            ([add(cp, p, p), p], [0, 1]),   # acc = 2 p after the doubling, then + 2 p: the addition's doubling branch
+            ([None, None, None], [0, 4, 4]),
+            ([q], [0]),
+        ]
+        for V, down in cases:
+            want = None
+            for w in range(len(V) - 1, -1, -1):
+                want = add(cp, want, V[w])
+                if down[w]:
+                    want = mul(cp, want, 1 << down[w])
+            buf = b"".join(enc(cp, v) for v in V)
+            dn = (ctypes.c_int * len(V))(*down)
+            for which in (0, 1):
+                out = ctypes.create_string_buffer(size)
+                assert L.hm_horner(cid, group, buf, len(V), dn, which, out) == 0
+                assert dec(cp, out.raw) == want, (name, group, down, which)
+
+
+@pytest.mark.parametrize("name", CURVES)
 def test_group_law_including_exceptional_cases(hostmath, name):
     cp = R.CURVES[name]
     L, cid, n = hostmath, cp.curve_id, cp.fp_bytes

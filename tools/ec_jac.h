@@ -14,25 +14,11 @@
 // decremented register pair addresses a flat access.  Measured once fixed (profiles/r04_jac_repro.txt): bit-identical to
 // the XYZZ kernel at 64 / 4 099 / 2^20 products and SLOWER, 76.1 against 64.5 ms per 2^20 -- the XYZZ kernel stays.
 #pragma once
-#include "../mathlib_amd/csrc/ec.h"
+#include "../mathlib_amd/csrc/ec_jac.h"
 
 namespace mlhip {
 
-template <class F>
-struct Jac {
-  typename F::T x, y, z;
-};
-
-template <class F>
-MLHIP_HD void jac_set_inf(Jac<F>& r) {
-  F::one(r.x);
-  F::one(r.y);
-  F::zero(r.z);
-}
-template <class F>
-MLHIP_HD bool jac_is_inf(const Jac<F>& p) {
-  return F::is_zero(p.z);
-}
+// (Jac, jac_set_inf, jac_is_inf, jac_dbl: the product's mathlib_amd/csrc/ec_jac.h, where the host tail's Horner pass uses them)
 template <class F>
 MLHIP_HD void jac_from_affine(Jac<F>& r, const Affine<F>& p) {
   if (affine_is_inf<F>(p)) {
@@ -42,33 +28,6 @@ MLHIP_HD void jac_from_affine(Jac<F>& r, const Affine<F>& p) {
   r.x = p.x;
   r.y = p.y;
   F::one(r.z);
-}
-
-// r = 2 p   (dbl-2009-l; Y = 0, a point of order two, gives Z3 = 0 = infinity by itself)
-template <class F>
-MLHIP_HD void jac_dbl(Jac<F>& r, const Jac<F>& p) {
-  typename F::T A, B, Cc, D, E, Fq, t;
-  F::sqr(A, p.x);
-  F::sqr(B, p.y);
-  F::sqr(Cc, B);
-  F::add(t, p.x, B);
-  F::sqr(t, t);
-  F::sub(t, t, A);
-  F::sub(t, t, Cc);
-  F::dbl(D, t);  // D = 2 ((X + B)^2 - A - C)
-  F::dbl(E, A);
-  F::add(E, E, A);  // E = 3 A
-  F::sqr(Fq, E);
-  F::mul(t, p.y, p.z);  // before r.y is written: r may alias p
-  F::sub(r.x, Fq, D);
-  F::sub(r.x, r.x, D);  // X3 = F - 2 D
-  F::dbl(r.z, t);       // Z3 = 2 Y Z
-  F::sub(t, D, r.x);
-  F::mul(t, E, t);
-  F::dbl(Cc, Cc);
-  F::dbl(Cc, Cc);
-  F::dbl(Cc, Cc);
-  F::sub(r.y, t, Cc);  // Y3 = E (D - X3) - 8 C
 }
 
 // acc += (affine q), q negated first when `negate`   (madd-2007-bl)

@@ -48,9 +48,11 @@ while time.time() - t0 < budget:
             os.environ["MLHIP_FB_WINDOW"] = str(w)
         if rnd.random() < 0.25:
             os.environ["MLHIP_FB_CACHE"] = "0"
+        if rnd.random() < 0.3:  # BLS12-377 G1: the XYZZ products instead of the Edwards ones (round 4), on the same kept table
+            os.environ["MLHIP_EDWARDS"] = "0"
         out = ctypes.create_string_buffer(sz * n)
         _lib.check(lib.mlhip_scalar_mul(cid, group, base, 0, b"".join(v.to_bytes(32, "little") for v in vals), 0, n, out))
-        for k in ("MLHIP_FIXED_BASE_MIN", "MLHIP_FB_WINDOW", "MLHIP_FB_CACHE"):
+        for k in ("MLHIP_FIXED_BASE_MIN", "MLHIP_FB_WINDOW", "MLHIP_FB_CACHE", "MLHIP_EDWARDS"):
             os.environ.pop(k, None)
         for i in {0, n - 1, rnd.randrange(n), rnd.randrange(n)}:
             if out.raw[i * sz : (i + 1) * sz] != cref.point_mul(cid, group, base, vals[i]):
@@ -82,6 +84,10 @@ while time.time() - t0 < budget:
         # half of the calls stream the pairs in a random number of segments (the library reads the switch per call)
         segs = rnd.choice([0, 0, 0, 2, 3, 5, 16])
         os.environ["MLHIP_STREAM_SEGMENTS"] = str(segs)
+        # round 4: segments of unequal length (msm_plan.h: stream_schedule; it takes precedence over the count above)
+        os.environ.pop("MLHIP_STREAM_SCHEDULE", None)
+        if rnd.random() < 0.3:
+            os.environ["MLHIP_STREAM_SCHEDULE"] = ",".join(str(rnd.randrange(1, 9)) for _ in range(rnd.randrange(2, 8)))
         # round-3 paths, read per launch: the coarse scatter staged in LDS (default) or one store per entry; the next
         # tile's sort on a second stream (default) or in line
         os.environ["MLHIP_SCATTER_STAGED"] = rnd.choice(["1", "1", "0"])
