@@ -403,6 +403,13 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
   typedef Affine<FpField<C>> A1;
   typedef Affine<Fp2Field<C>> A2;
   const bool one_lane = mlhip_alt_switch("MLHIP_PAIRING_ONE_LANE");  // read per batch so a test can switch paths (test build only)
+  // BN254's Miller loop ALONE is a product-bound kernel and stays on the saturated lane pairs (7.3 against 7.45 ms per 65 536)
+  // -- except where a quad's shorter chain decides: batches that leave the chip under-filled (round 4)
+  bool bn_miller_saturated = C::IS_BN && what == 0;
+  if (bn_miller_saturated && ppp <= 4) {
+    const char* qe = getenv("MLHIP_PAIRING_QUAD");
+    if (qe ? qe[0] == '1' : n <= ((size_t)1 << 14)) bn_miller_saturated = false;
+  }
   if (one_lane) {
     if constexpr (kBuildAlt) {
       unsigned blocks = (unsigned)((n + 63) / 64);
@@ -418,12 +425,12 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
           break;
       }
     }
-  } else if (lp28_enabled<C>() && !(C::IS_BN && what == 0)) {
+  } else if (lp28_enabled<C>() && !bn_miller_saturated) {
     // lane pairs in the carry-free form (MLHIP_PAIRING_SAT=1 selects the saturated lane-pair kernels below; BN254's Miller
     // loop alone stays on them: 7.3 against 7.45 ms per 65 536 -- its 10-limb products gain nothing, the final exponentiation's
     // additions and squarings do: 8.6 -> 7.3 ms, the fused pairing 15.9 -> 14.1 ms)
     unsigned blocks = (unsigned)((2 * n + 63) / 64);
-    if constexpr (C::ID == 1) {
+    {  // BLS12-381 and, since round 4, BLS12-377 (D-twist line product, u^2 = -5) and BN254 (Frobenius lines, BN hard part)
       // One pairing per QUAD of lanes (pairing_quad.h) while the batch leaves the chip under-filled: up to 2^14 elements
       // (65 536 lanes = one wave per SIMD) a batch takes the time of ONE pairing's dependent chain, which is 1.5 x
       // shorter on a quad (1 024 pairings: 5.7 ms instead of 8.5; single Pairing 2.6 / FExp 3.1 ms instead of 3.9 / 4.6);
@@ -432,7 +439,10 @@ int pairing_device(int what, const void* d_g1, const void* d_g2, size_t ppp, siz
       const char* qe = getenv("MLHIP_PAIRING_QUAD");
       // (round 2 also ran the Miller loop of single pairs on quads at every size -- 65 536 loops 9.0 ms against the pairs'
       // 9.2; since round 3 the pairs' loop keeps T and P in LDS and squares and multiplies by the line in one call: 8.6 ms)
-      const bool quads = qe ? qe[0] == '1' : n <= ((size_t)1 << 14);
+      // BLS12-377 (profiles/r04_pairing_quad_bls377.txt): quads win up to 2^15 elements (16 384 pairings 7.4 ms against 13.5,
+      // 32 768: 12.9 / 14.9, 65 536: 25.2 / 23.9), its Miller loop alone at every size
+      const size_t quad_max = (size_t)1 << (C::ID == 2 ? 15 : 14);
+      const bool quads = qe ? qe[0] == '1' : (n <= quad_max || (C::ID == 2 && what == 0));
       if (quads && (what != 0 || ppp <= 4)) {
         const unsigned qblocks = (unsigned)((4 * n + 63) / 64);
         if (what == 0 && ppp == 1)
@@ -659,10 +669,10 @@ int gt_exp_device(const void* d_in, const void* d_scalars, int mont, size_t n, v
       k_gt_exp<C><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars, mont, n,
                                                                      (Fp12<C>*)d_out);
   } else if (lp28_enabled<C>()) {
-    if constexpr (C::ID == 1) {
+    {
       // quads at every size: the windowed chain is generic squarings and products, where a quad does the lane pair's work
       // in half the rounds without the 84-word operands crossing scratch (65 536: 15.7 ms against 19.2; 1 024: 4.0 / 7.9);
-      // MLHIP_PAIRING_QUAD=0 keeps the lane-pair kernel
+      // MLHIP_PAIRING_QUAD=0 keeps the lane-pair kernel.  BLS12-377 (round 4): profiles/r04_pairing_quad_bls377.txt
       const char* qe = getenv("MLHIP_PAIRING_QUAD");
       if (!(qe && qe[0] == '0'))
         k_gt_exp_q28<C><<<dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,
@@ -670,9 +680,6 @@ int gt_exp_device(const void* d_in, const void* d_scalars, int mont, size_t n, v
       else
         k_gt_exp_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in,
                                                                                 (const uint32_t*)d_scalars, mont, n, (Fp12<C>*)d_out);
-    } else {
-      k_gt_exp_lp28<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,
-                                                                              mont, n, (Fp12<C>*)d_out);
     }
   } else if constexpr (kBuildAlt) {
     k_gt_exp_lp<C><<<dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st>>>((const Fp12<C>*)d_in, (const uint32_t*)d_scalars,

@@ -1,4 +1,5 @@
-// pairing_quad.h -- the BLS12-381 pairing with ONE PAIRING PER QUAD OF LANES (carry-free element, fp2_lanes28.h).
+// pairing_quad.h -- the pairings (BLS12-381; since round 4 BLS12-377: D-twist line, u^2 = -5, and BN254: 10 limbs, xi = 9 + u,
+// the two Frobenius lines, the Fuentes-Castaneda hard part on plain squarings) with ONE PAIRING PER QUAD OF LANES (carry-free element, fp2_lanes28.h).
 //
 // Layout.  Lane pairs stay what they are in fp2_lanes28.h: lane 2i holds the real and lane 2i+1 the imaginary part of
 // an Fp2 value, and every fp2_* / fp6_* function of tower.h works on a lane pair without knowing its neighbours -- so in
@@ -301,6 +302,7 @@ MLHIP_HD_NOINLINE void fp12q_inv(Fp12Q<C, E>& r, const Fp12Q<C, E>& a) {
   fp6_mul<C>(m, a.v, t);  // A: a0 / n | B: a1 / n
   fp6_neg<C>(n, m);
   fp6q_sel_b<C>(r.v, n, m);
+  if constexpr (C::BETA != -1) fp6_reduce<C>(r.v);  // u^2 = -5: un-reduced Fp6 products may not travel on (as fp12_inv, tower.h)
 }
 
 // Frobenius f -> f^(p^K): w-basis positions g0 = c0.c0, g1 = c1.c0, g2 = c0.c1, g3 = c1.c1, g4 = c0.c2, g5 = c1.c2 --
@@ -355,14 +357,32 @@ MLHIP_Q28_FN void fp12q_mul_by_014(Fp12Q<C, E>& f, const E& c0, const E& c1, con
   fp6_reduce<C>(f.v);
 }
 
+// f *= (c0 + c3 w + c4 v w), the line of a D-twist curve (BLS12-377; round 4); c0, c3, c4 replicated on both pairs:
+//     pair A: f0 c0 + v f1 (c3 + c4 v)        pair B: f1 c0 + f0 (c3 + c4 v)
+// fp6_mul_by_0 on (f0 | f1) and fp6_mul_by_01 on the swapped halves (f1 | f0): 3 + 5 Fp2 products deep, as the M-twist form
+template <class C, class E>
+MLHIP_Q28_FN void fp12q_mul_by_034(Fp12Q<C, E>& f, const E& c0, const E& c3, const E& c4) {
+  Fp6<C, E> t0, t1, fs, u;
+  fp6_mul_by_0<C>(t0, f.v, c0);  // A: f0 c0 | B: f1 c0                                  1, 1, 1
+  fp6q_swap<C>(fs, f.v);
+  fp6_mul_by_01<C>(t1, fs, c3, c4);  // A: f1 (c3 + c4 v) | B: f0 (c3 + c4 v)            raw: 3, 3, 2
+  fp6_mul_v<C>(u, t1);
+  fp6_add<C>(u, t0, u);    // A: f0 c0 + v f1 (c3 + c4 v)
+  fp6_add<C>(t0, t0, t1);  // B: f1 c0 + f0 (c3 + c4 v)
+  fp6q_sel_b<C>(f.v, t0, u);
+  fp6_reduce<C>(f.v);
+}
+
 template <class C, class E, class EP>
 MLHIP_HD void mul_by_line_q(Fp12Q<C, E>& f, const Line<C, E>& l, const EP& px, const EP& py) {
-  static_assert(C::MTWIST, "the quad-lane pairing is written for the M-twist line (BLS12-381)");
   E a, b, c = l.r2;
   fp2_mul_fp<C>(a, l.r0, py);
   fp2_mul_fp<C>(b, l.r1, px);
   fp2_norm<C>(c);
-  fp12q_mul_by_014<C>(f, c, b, a);
+  if constexpr (C::MTWIST)
+    fp12q_mul_by_014<C>(f, c, b, a);
+  else
+    fp12q_mul_by_034<C>(f, a, b, c);
 }
 
 // T <- 2T with the line through T, T: the formulas of g2_double_step (pairing.h) with the nine Fp2 products spread over the
@@ -371,7 +391,6 @@ MLHIP_HD void mul_by_line_q(Fp12Q<C, E>& f, const Line<C, E>& l, const EP& px, c
 // T, the line and every linear combination are replicated on both pairs (quad_on_a / quad_on_b pick a round's results).
 template <class C, class E2>
 MLHIP_HD void g2_double_step_q(G2Proj<C, E2>& T, Line<C, E2>& l) {
-  static_assert(C::ID == 1, "BLS12-381 (b' = 4 xi)");
   E2 A, B, Cc, E, F, G, H, I, J, EE, GG, s, t, u, r1, r2;
   fp2_add<C>(s, T.y, T.z);
   fp2_norm<C>(s);
@@ -385,8 +404,15 @@ MLHIP_HD void g2_double_step_q(G2Proj<C, E2>& T, Line<C, E2>& l) {
   quad_on_b<C>(Cc, r1);
   quad_on_a<C>(H, r2);
   quad_on_b<C>(J, r2);
-  fp2_mul_xi<C>(E, Cc);
-  fp2_mul_small<C>(E, E, 12);
+  if constexpr (C::ID == 1) {
+    // BLS12-381: b' = 4 (1 + u) = 4 xi, so 3 b' Z^2 = 12 xi Z^2 -- additions instead of an Fp2 product
+    fp2_mul_xi<C>(E, Cc);
+    fp2_mul_small<C>(E, E, 12);
+  } else {
+    E2 b3;  // (Cc is replicated on both pairs: so is this product)
+    fp2_from_const<C>(b3, C::B3_TW);
+    fp2_mul<C>(E, Cc, b3);
+  }
   fp2_reduce<C>(E);  // 3 b' Z^2: squared below
   fp2_dbl<C>(F, E);
   fp2_add<C>(F, F, E);  // 3E
@@ -424,7 +450,6 @@ MLHIP_HD void g2_double_step_q(G2Proj<C, E2>& T, Line<C, E2>& l) {
 template <class C, int MAXP, class E, class EP>
 MLHIP_HD void miller_loop_q(Fp12Q<C, E>& f, const EP* px, const EP* py, const E* qx, const E* qy, const bool* live,
                             int n_pairs) {
-  static_assert(!C::IS_BN, "BLS12 loop");
   G2Proj<C, E> T[MAXP];
   int any = 0;
   for (int k = 0; k < n_pairs && k < MAXP; k++) {
@@ -449,6 +474,26 @@ MLHIP_HD void miller_loop_q(Fp12Q<C, E>& f, const EP* px, const EP* py, const E*
         g2_add_step<C>(T[k], qx[k], qy[k], l);
         mul_by_line_q<C>(f, l, px[k], py[k]);
       }
+    }
+  }
+  if constexpr (C::IS_BN) {
+    // BN254 (round 4): the lines through pi(Q) and -pi^2(Q), as miller_loop_core (pairing.h); everything replicated on the pairs
+    for (int k = 0; k < n_pairs && k < MAXP; k++) {
+      if (!live[k]) continue;
+      E x1, y1, x2, y2, g;
+      fp2_conj<C>(x1, qx[k]);
+      fp2_from_const<C>(g, C::GAMMA1[2]);
+      fp2_mul<C>(x1, x1, g);
+      fp2_conj<C>(y1, qy[k]);
+      fp2_from_const<C>(g, C::GAMMA1[3]);
+      fp2_mul<C>(y1, y1, g);
+      fp2_mul_by_real_const<C>(x2, qx[k], C::GAMMA2[2]);
+      fp2_mul_by_real_const<C>(y2, qy[k], C::GAMMA2[3]);
+      fp2_neg<C>(y2, y2);
+      g2_add_step<C>(T[k], x1, y1, l);
+      mul_by_line_q<C>(f, l, px[k], py[k]);
+      g2_add_step<C>(T[k], x2, y2, l);
+      mul_by_line_q<C>(f, l, px[k], py[k]);
     }
   }
   if (C::X_NEG) fp12q_conj<C>(f, f);
@@ -517,8 +562,19 @@ MLHIP_HD_NOINLINE void fp12q_expt(Fp12Q<C, E>& r, const Fp12Q<C, E>& z) {
   int top = 63;
   while (!((C::X_ABS >> top) & 1)) top--;
   constexpr int NSET = mlhip_popcount64(C::X_ABS);
-  static_assert(NSET <= 8, "seed with few set bits (BLS12-381, BLS12-377)");
-  constexpr int NS = NSET - (int)(C::X_ABS & 1);
+  if constexpr (NSET > 8) {
+    // BN254's seed: plain square-and-multiply; on a quad the generic square is ONE Fp6 product, which is what a Granger-Scott
+    // squaring spread over the pairs would cost as well
+    Fp12Q<C, E> acc = z;
+    for (int i = top - 1; i >= 0; i--) {
+      fp12q_sqr<C>(acc, acc);
+      if ((C::X_ABS >> i) & 1) fp12q_mul<C>(acc, acc, z);
+    }
+    if (C::X_NEG) fp12q_conj<C>(acc, acc);
+    r = acc;
+    return;
+  }
+  constexpr int NS = (NSET <= 8 ? NSET : 1) - (int)(C::X_ABS & 1);
   CycloCompQ<C, E> k, saved[NS > 0 ? NS : 1];
   cyclo_compress_q<C>(k, z);
   int ns = 0;
@@ -573,7 +629,6 @@ MLHIP_HD_NOINLINE void fp12q_expt(Fp12Q<C, E>& r, const Fp12Q<C, E>& z) {
 // r = f^(3 (p^12 - 1)/r_order): pairing.h's final_exp (BLS12 branch) on the quad form
 template <class C, class E>
 MLHIP_HD void final_exp_q(Fp12Q<C, E>& out, const Fp12Q<C, E>& f) {
-  static_assert(!C::IS_BN, "BLS12 chain");
   Fp12Q<C, E> r, t0, t1, t2;
   // easy part: f^((p^6-1)(p^2+1))
   fp12q_conj<C>(t0, f);
@@ -581,6 +636,32 @@ MLHIP_HD void final_exp_q(Fp12Q<C, E>& out, const Fp12Q<C, E>& f) {
   fp12q_mul<C>(t0, t0, t1);
   fp12q_frob<C, 2>(t1, t0);
   fp12q_mul<C>(r, t1, t0);
+  if constexpr (C::IS_BN) {
+    // hard part of pairing.h's BN branch (Fuentes-Castaneda): exponent l0 + l1 p + l2 p^2 + l3 p^3 = 2x(6x^2+3x+1)(p^4-p^2+1)/r
+    Fp12Q<C, E> fx, f2x, f6x, f6x2, f12x3, a, b;
+    fp12q_expt<C>(fx, r);
+    fp12q_sqr<C>(f2x, fx);
+    fp12q_sqr<C>(t0, f2x);  // 4x
+    fp12q_mul<C>(f6x, t0, f2x);
+    fp12q_expt<C>(f6x2, f6x);
+    fp12q_sqr<C>(t0, f6x2);  // 12x^2
+    fp12q_expt<C>(f12x3, t0);
+    fp12q_mul<C>(a, f12x3, f6x2);
+    fp12q_mul<C>(a, a, f6x);
+    fp12q_conj<C>(t0, f2x);
+    fp12q_mul<C>(b, a, t0);
+    fp12q_mul<C>(t0, a, f6x2);
+    fp12q_mul<C>(t0, t0, r);
+    fp12q_frob<C, 1>(t1, b);
+    fp12q_mul<C>(t0, t0, t1);
+    fp12q_frob<C, 2>(t1, a);
+    fp12q_mul<C>(t0, t0, t1);
+    fp12q_conj<C>(t1, r);
+    fp12q_mul<C>(t1, b, t1);
+    fp12q_frob<C, 3>(t2, t1);
+    fp12q_mul<C>(out, t0, t2);
+    return;
+  }
   // hard part, exponent (x-1)^2 (x+p) (x^2+p^2-1) + 3
   fp12q_sqr<C>(t0, r);
   fp12q_expt<C>(t1, r);

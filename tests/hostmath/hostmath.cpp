@@ -702,9 +702,10 @@ struct Lp28T {
 
 typedef Lp28T<Bls381> Lp28;
 
-// the quad-lane pairing (pairing_quad.h) through its host model Fp2Q28H: pair A / pair B of a quad
-struct Q28 {
-  typedef Bls381 C;
+// the quad-lane pairing (pairing_quad.h) through its host model Fp2Q28H: pair A / pair B of a quad (BLS12-381, BLS12-377)
+template <class CC>
+struct Q28T {
+  typedef CC C;
   typedef Fp2Q28H<C> E;
   typedef Fp12Q<C, E> F12q;
   static void to_q(F12q& r, const Fp12<C>& a) {
@@ -780,14 +781,17 @@ struct Q28 {
         fp12q_from_replicated<C>(hr, v);
         break;
       }
-      case 13: {  // f *= line (c0, c1, c4): b holds the three Fp2 coefficients
+      case 13: {  // f *= line (c0, c1, c4) [M-twist] / (c0, c3, c4) [D-twist]: b holds the three Fp2 coefficients
         const Fp2<C>* l = (const Fp2<C>*)b;
         E c0, c1, c4;
         rep(c0, l[0]);
         rep(c1, l[1]);
         rep(c4, l[2]);
         hr = hx;
-        fp12q_mul_by_014<C>(hr, c0, c1, c4);
+        if constexpr (C::MTWIST)
+          fp12q_mul_by_014<C>(hr, c0, c1, c4);
+        else
+          fp12q_mul_by_034<C>(hr, c0, c1, c4);
         break;
       }
       default: return -1;
@@ -823,6 +827,7 @@ struct Q28 {
     return max_w(f);
   }
 };
+typedef Q28T<Bls381> Q28;
 
 #define DISPATCH(curve, call)                 \
   switch (curve) {                            \
@@ -872,6 +877,19 @@ int hm_lp28c_pairing(int curve, const void* g1s, const void* g2s, int n_pairs, i
 }
 int hm_q28_fp12_op(int op, const void* a, const void* b, void* out) { return Q28::fp12_op(op, a, b, out); }
 int hm_q28_pairing(const void* g1, const void* g2, int n_pairs, int with_fexp, void* out) { return Q28::pairing(g1, g2, n_pairs, with_fexp, out); }
+// the same for a curve id: BLS12-381 (1) or BLS12-377 (2: D-twist line, u^2 = -5, xi = u)
+int hm_q28c_fp12_op(int curve, int op, const void* a, const void* b, void* out) {
+  if (curve == 1) return Q28T<Bls381>::fp12_op(op, a, b, out);
+  if (curve == 2) return Q28T<Bls377>::fp12_op(op, a, b, out);
+  if (curve == 0) return Q28T<Bn254>::fp12_op(op, a, b, out);
+  return -2;
+}
+int hm_q28c_pairing(int curve, const void* g1, const void* g2, int n_pairs, int with_fexp, void* out) {
+  if (curve == 1) return Q28T<Bls381>::pairing(g1, g2, n_pairs, with_fexp, out);
+  if (curve == 2) return Q28T<Bls377>::pairing(g1, g2, n_pairs, with_fexp, out);
+  if (curve == 0) return Q28T<Bn254>::pairing(g1, g2, n_pairs, with_fexp, out);
+  return -2;
+}
 int hm_fp28_reduce(int curve, const int32_t* in, int32_t* out) {
   if (curve != 1) return -2;
   Fp28<Bls381> a, r;

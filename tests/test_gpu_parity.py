@@ -642,13 +642,15 @@ def test_pairing_saturated_lane_pair_kernels_agree(lib, mlhip, monkeypatch):
     assert all(res[x] == cref.final_exp(cid, cref.miller_loop(cid, p1, p2, 2, n // 2, 8), n // 2, 8) for x in sats)
 
 
-def test_pairing_quad_lane_kernels_agree(lib, mlhip, monkeypatch):
-    """MLHIP_PAIRING_QUAD=1: one BLS12-381 pairing per quad of lanes (pairing_quad.h, k_pairing_q28) -- Miller loop
-    (compared after the final exponentiation, the raw value is not canonical), final exponentiation on the lane-pair
-    kernels' raw Miller values, and the fused pairing, against the oracle: goldens and a ragged batch with infinities."""
+@pytest.mark.parametrize("curve", ["BLS12-381", "BLS12-377", "BN254"])
+def test_pairing_quad_lane_kernels_agree(lib, mlhip, curve, monkeypatch):
+    """MLHIP_PAIRING_QUAD=1: one pairing per quad of lanes (pairing_quad.h, k_pairing_q28; BLS12-381 and, since round 4,
+    BLS12-377 with its D-twist line product and BN254 with its Frobenius lines and hard part) -- Miller loop (compared after the final exponentiation, the raw value is
+    not canonical), final exponentiation on the lane-pair kernels' raw Miller values, and the fused pairing, against the
+    oracle: goldens and a ragged batch with infinities; Gt.Exp on quads against the lane pairs."""
     from oracle import cref
 
-    g = load_golden("BLS12-381")
+    g = load_golden(curve)
     cid = g["curve_id"]
     _, g1b, g2b, gtb = mlhip.sizes(cid)
     n = 83  # ragged: the last wave holds 3 quads
@@ -662,6 +664,7 @@ def test_pairing_quad_lane_kernels_agree(lib, mlhip, monkeypatch):
     raw_pairs = ctypes.create_string_buffer(gtb * n)  # raw Miller values from the lane-pair kernels
     mlhip.check(lib.mlhip_miller_loop(cid, p1, p2, 1, n, raw_pairs))
     # batches up to 2^14 run on quads by default; "1" forces them, "0" keeps this small batch on the lane-pair kernels
+    gt_exp_results = []
     for quad in ("1", "0", None):
         if quad is None:
             monkeypatch.delenv("MLHIP_PAIRING_QUAD")
@@ -686,6 +689,18 @@ def test_pairing_quad_lane_kernels_agree(lib, mlhip, monkeypatch):
         ml2 = ctypes.create_string_buffer(gtb * (n // 2))
         mlhip.check(lib.mlhip_miller_loop(cid, p1, p2, 2, n // 2, ml2))
         assert cref.final_exp(cid, ml2.raw, n // 2, 8) == cref.final_exp(cid, cref.miller_loop(cid, p1, p2, 2, n // 2, 8), n // 2, 8)
+        # Gt.Exp of the raw Miller values (any Fp12 value is a valid input): the same bytes on quads and on lane pairs
+        m = 40
+        sc = _rand_scalars(m, 4711, 253)
+        sc[0] = 0
+        sc[1] = (1, 0, 0, 0)
+        ge = ctypes.create_string_buffer(gtb * m)
+        mlhip.check(lib.mlhip_gt_exp(cid, raw_pairs.raw[: gtb * m], sc.tobytes(), 0, m, ge))
+        gt_exp_results.append(ge.raw)
+    assert gt_exp_results[0] == gt_exp_results[1] == gt_exp_results[2]
+    one = ctypes.create_string_buffer(gtb)  # x^0 = 1 and x^1 = x
+    mlhip.check(lib.mlhip_final_exp(cid, bytes(gtb), 0, one))
+    assert gt_exp_results[0][gtb : 2 * gtb] == raw_pairs.raw[gtb : 2 * gtb]
 
 
 @pytest.mark.parametrize("curve", CURVES)

@@ -863,3 +863,63 @@ def test_q28_pairing_matches_oracle(hostmath):
     one = tuple([(1, 0)] + [(0, 0)] * 5)
     assert L.hm_q28_pairing(bytes(96), g2, 1, 1, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
     assert L.hm_q28_pairing(g1, bytes(192), 1, 1, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
+
+
+@pytest.mark.parametrize("name", ["BLS12-377", "BN254"])
+def test_q28_other_curves_tower_and_pairing(hostmath, name):
+    """Round 4: the quad-lane pairing on BLS12-377 (pairing_quad.h: the D-twist line product fp12q_mul_by_034, the doubling
+    step with 3 b' as a constant, u^2 = -5 in every Fp2 product of both pairs) and on BN254 (10 limbs, xi = 9 + u, the two
+    Frobenius lines after the loop, the Fuentes-Castaneda hard part on plain squarings) through the quad host model --
+    every weight and value budget checked, no branch on a value that differs between the pairs: the Fp12 operations,
+    squaring chains, the sparse line product, final exponentiation, pairings with one and two pairs, infinities."""
+    cp = R.CURVES[name]
+    cid = cp.curve_id
+    T = R.tower(cp)
+    L = hostmath
+    d = R.Drbg("hm/q28/" + name)
+    n = cp.fp_bytes
+    rf = lambda: tuple((d.below(cp.p), d.below(cp.p)) for _ in range(6))  # noqa: E731
+    gb = lambda f: R.gt_to_mont_bytes(cp, f)  # noqa: E731
+    out = ctypes.create_string_buffer(12 * n)
+    f, g = rf(), rf()
+    c = T.f12_mul(T.f12_conj(f), T.f12_inv(f))
+    c = T.f12_mul(T.f12_frob(c, 2), c)  # cyclotomic subgroup element
+    cases = [(0, f, T.f12_mul(f, g)), (1, f, T.f12_sqr(f)), (10, f, T.f12_mul(f, g)), (11, f, T.f12_sqr(f)), (2, f, T.f12_inv(f)),
+             (3, f, T.f12_frob(f, 1)), (4, f, T.f12_frob(f, 2)), (5, f, T.f12_frob(f, 3)), (7, f, T.f12_conj(f)),
+             (8, c, T.f12_pow(c, abs(cp.x))), (9, f, R.final_exp(cp, f))]
+    for op, a, exp in cases:
+        assert L.hm_q28c_fp12_op(cid, op, gb(a), gb(g), out) == 1, op
+        assert R.gt_from_mont_bytes(cp, out.raw) == exp, op
+    for reps in (() if name == "BN254" else (1, 2, 17, 63)):  # compressed squarings: the BLS12 chains only
+        assert L.hm_q28c_fp12_op(cid, 12, gb(c), bytes([reps]) + bytes(12 * n - 1), out) == 1
+        exp = c
+        for _ in range(reps):
+            exp = T.f12_sqr(exp)
+        assert R.gt_from_mont_bytes(cp, out.raw) == exp, reps
+    # the sparse D-twist line c0 + c3 w + c4 v w against the full product
+    l0, l3, l4 = [(d.below(cp.p), d.below(cp.p)) for _ in range(3)]
+    zero = (0, 0)
+    line = (l0, l3, zero, l4, zero, zero)  # pyref keeps an Fp12 in the w-basis: c0 + c3 w + c4 (v w = w^3)
+    lb = b"".join(R.fp_to_mont_bytes(cp, x[0]) + R.fp_to_mont_bytes(cp, x[1]) for x in (l0, l3, l4))
+    assert L.hm_q28c_fp12_op(cid, 13, gb(f), lb, out) == 1
+    assert R.gt_from_mont_bytes(cp, out.raw) == T.f12_mul(f, line)
+    one = tuple([(1, 0)] + [(0, 0)] * 5)
+    assert L.hm_q28c_fp12_op(cid, 9, gb(one), None, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
+    # whole pairings
+    P, Q = R.random_g1(cp, d), R.random_g2(cp, d)
+    P2, Q2 = R.random_g1(cp, d), R.random_g2(cp, d)
+    g1, g2 = R.g1_to_mont_bytes(cp, P), R.g2_to_mont_bytes(cp, Q)
+    assert L.hm_q28c_pairing(cid, g1, g2, 1, 1, out) == 1
+    assert R.gt_from_mont_bytes(cp, out.raw) == R.pairing(cp, P, Q)
+    assert L.hm_q28c_pairing(cid, g1, g2, 1, 0, out) == 1
+    assert R.final_exp(cp, R.gt_from_mont_bytes(cp, out.raw)) == R.pairing(cp, P, Q)
+    assert L.hm_q28c_pairing(cid, g1 + R.g1_to_mont_bytes(cp, P2), g2 + R.g2_to_mont_bytes(cp, Q2), 2, 1, out) == 1
+    assert R.gt_from_mont_bytes(cp, out.raw) == R.final_exp(cp, R.miller_loop(cp, [(P, Q), (P2, Q2)]))
+    assert L.hm_q28c_pairing(cid, g1 + bytes(2 * n), g2 + R.g2_to_mont_bytes(cp, Q2), 2, 1, out) == 1  # second pair not live
+    assert R.gt_from_mont_bytes(cp, out.raw) == R.pairing(cp, P, Q)
+    gold = load_golden(name)
+    c0 = gold["pairing"][0]
+    assert L.hm_q28c_pairing(cid, bytes.fromhex(c0["g1"]), bytes.fromhex(c0["g2"]), 1, 1, out) == 1
+    assert out.raw.hex() == c0["fexp"]
+    assert L.hm_q28c_pairing(cid, bytes(2 * n), g2, 1, 1, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
+    assert L.hm_q28c_pairing(cid, g1, bytes(4 * n), 1, 1, out) == 1 and R.gt_from_mont_bytes(cp, out.raw) == one
