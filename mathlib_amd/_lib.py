@@ -81,13 +81,58 @@ class MlhipError(RuntimeError):
 
 
 _lib = None
+ALT_PATH = os.path.join(HERE, "libmlhip_alt.so")  # the test build (python -m mathlib_amd.build --alt)
+_alt = None
+_use_alt = False
 
 
-def load() -> ctypes.CDLL:
+class _Active:
+    """What load() hands out: the product library -- or, while a TEST has asked for a second implementation the product
+    does not contain (tests/conftest.py: use_alt), the test build.  Attribute access goes to whichever is active, so the
+    `lib` objects tests already hold follow the switch.  Nothing outside the tests ever calls use_alt."""
+
+    def __getattr__(self, name):
+        return getattr(_alt if (_use_alt and _alt is not None) else _lib, name)
+
+
+_active = _Active()
+
+
+def alt_available() -> bool:
+    """Is an up-to-date test build next to the product library?  (build.py stamps both with the hash of the sources.)"""
+    if LIB_PATH == ALT_PATH:
+        return True
+    try:
+        from .build import source_hash
+
+        with open(ALT_PATH + ".srchash") as f:
+            return os.path.exists(ALT_PATH) and f.read().strip() == source_hash()
+    except OSError:
+        return False
+
+
+def concrete():
+    """The library that is active right now, as the ctypes object itself: what an object that owns a library handle (MsmPlan,
+    driver.Bases) binds at creation, so that the handle is used and destroyed by the library that made it whatever is active
+    later."""
+    load()
+    return _alt if (_use_alt and _alt is not None) else _lib
+
+
+def use_alt(on: bool) -> None:
+    """Tests only: route every call through the test build (True) or back to the product library (False)."""
+    global _alt, _use_alt
+    if on and _alt is None and LIB_PATH != ALT_PATH:
+        load()
+        _alt = _bind(ctypes.CDLL(ALT_PATH))
+    _use_alt = bool(on)
+
+
+def load():
     """Load libmlhip.so; raises if it has not been built (python -m mathlib_amd.build)."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _active
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "mathlib_amd: %s is missing -- the HIP extension has not been built "
@@ -100,7 +145,12 @@ def load() -> ctypes.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = ctypes.CDLL(LIB_PATH)
+    _lib = _bind(ctypes.CDLL(LIB_PATH))
+    return _active
+
+
+def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
+    """argument and result types of every entry point"""
     vp, sz, ci = c_void_p, c_size_t, c_int
     lib.mlhip_version.restype = ci
     lib.mlhip_last_error.restype = c_char_p
@@ -155,7 +205,6 @@ def load() -> ctypes.CDLL:
     for name in SYMBOLS:
         if name not in ("mlhip_last_error",):
             getattr(lib, name).restype = ci
-    _lib = lib
     return lib
 
 
@@ -197,22 +246,22 @@ class MsmPlan:
 
     def __init__(self, curve: int, group: int, max_n: int, window_c: int = 0):
         self._h = c_void_p()
-        lib = load()
+        lib = self._lib = concrete()
         check(lib.mlhip_msm_plan_create(curve, group, max_n, window_c, byref(self._h)))
         _, g1, g2, _ = sizes(curve)
         self.point_bytes = g1 if group == GROUP_G1 else g2
         self.curve, self.group = curve, group
 
     def set_profiling(self, on: bool) -> None:
-        check(load().mlhip_msm_plan_set_profiling(self._h, 1 if on else 0))
+        check(self._lib.mlhip_msm_plan_set_profiling(self._h, 1 if on else 0))
 
     def assume_srs(self, on: bool) -> None:
         """the points are a fixed SRS: immutable at their address and in the prime-order subgroup (include/mlhip.h)"""
-        check(load().mlhip_msm_plan_assume_srs(self._h, 1 if on else 0))
+        check(self._lib.mlhip_msm_plan_assume_srs(self._h, 1 if on else 0))
 
     def timings(self):
         buf = (c_float * 10)()
-        k = load().mlhip_msm_plan_timings(self._h, buf, 10)
+        k = self._lib.mlhip_msm_plan_timings(self._h, buf, 10)
         names = ["digits", "sort", "accumulate", "reduce", "device_total", "host_tail", "tiles"]
         t = {names[i]: float(buf[i]) for i in range(min(k, 7))}
         if k >= 10:
@@ -222,37 +271,37 @@ class MsmPlan:
     def window(self):
         """(c, W): the window width the plan runs with (the library's pick for window_c = 0) and its number of windows"""
         buf = (c_float * 9)()
-        load().mlhip_msm_plan_timings(self._h, buf, 9)
+        self._lib.mlhip_msm_plan_timings(self._h, buf, 9)
         return int(buf[7]), int(buf[8])
 
     def run(self, d_points: int, d_scalars: int, n: int, scalars_mont: bool, stream: int = 0, want_xyzz: bool = False):
         out = ctypes.create_string_buffer(self.point_bytes)
         xyzz = ctypes.create_string_buffer(2 * self.point_bytes) if want_xyzz else None
         check(
-            load().mlhip_msm_run(
+            self._lib.mlhip_msm_run(
                 self._h, c_void_p(d_points), c_void_p(d_scalars), 1 if scalars_mont else 0, n, c_void_p(stream), out, xyzz
             )
         )
         return (out.raw, xyzz.raw) if want_xyzz else out.raw
 
     def launch(self, d_points: int, d_scalars: int, n: int, scalars_mont: bool, stream: int = 0) -> None:
-        check(load().mlhip_msm_launch(self._h, c_void_p(d_points), c_void_p(d_scalars), 1 if scalars_mont else 0, n, c_void_p(stream)))
+        check(self._lib.mlhip_msm_launch(self._h, c_void_p(d_points), c_void_p(d_scalars), 1 if scalars_mont else 0, n, c_void_p(stream)))
 
     def launch_shared(self, g2_plan: "MsmPlan", d_points_g1: int, d_points_g2: int, d_scalars: int, n: int, scalars_mont: bool,
                       stream: int = 0) -> None:
         """self = the G1 plan: the G1 and the G2 MSM of one scalar vector, sorted once (finish both plans afterwards)"""
-        check(load().mlhip_msm_launch_shared(self._h, g2_plan._h, c_void_p(d_points_g1), c_void_p(d_points_g2), c_void_p(d_scalars),
+        check(self._lib.mlhip_msm_launch_shared(self._h, g2_plan._h, c_void_p(d_points_g1), c_void_p(d_points_g2), c_void_p(d_scalars),
                                              1 if scalars_mont else 0, n, c_void_p(stream)))
 
     def finish(self, want_xyzz: bool = False):
         out = ctypes.create_string_buffer(self.point_bytes)
         xyzz = ctypes.create_string_buffer(2 * self.point_bytes) if want_xyzz else None
-        check(load().mlhip_msm_finish(self._h, out, xyzz))
+        check(self._lib.mlhip_msm_finish(self._h, out, xyzz))
         return (out.raw, xyzz.raw) if want_xyzz else out.raw
 
     def close(self) -> None:
         if self._h:
-            load().mlhip_msm_plan_destroy(self._h)
+            self._lib.mlhip_msm_plan_destroy(self._h)
             self._h = c_void_p()
 
     def __del__(self):

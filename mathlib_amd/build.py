@@ -131,6 +131,10 @@ def build(verbose: bool = True, jobs: int | None = None, alt: bool = False) -> s
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # which sources this library was built from (mathlib_amd/_lib.py: alt_available -- the tests use the test build only when
+    # it matches the tree)
+    with open(LIB + ".srchash", "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

@@ -26,6 +26,7 @@ from typing import List, Sequence
 
 from . import _lib
 from ._lib import CURVE_BLS12_377, CURVE_BLS12_381, CURVE_BN254, GROUP_G1, GROUP_G2, check, load
+from ._lib import concrete as _concrete
 
 _X381 = -0xD201000000010000
 _X377 = 0x8508C00000000001
@@ -505,23 +506,24 @@ class Bases:
         self.n = len(points)
         self._h = ctypes.c_void_p()
         blob = b"".join(p.raw for p in points)
-        check(load().mlhip_bases_create(curve.id, GROUP_G1, blob, self.n, curve.window_c, ctypes.byref(self._h)))
+        self._lib = _concrete()  # the handle stays with the library that made it
+        check(self._lib.mlhip_bases_create(curve.id, GROUP_G1, blob, self.n, curve.window_c, ctypes.byref(self._h)))
 
     def MultiScalarMul(self, scalars: Sequence[Zr]) -> G1:
         if len(scalars) > self.n:
             raise IndexError("MultiScalarMul: more scalars than resident bases")
         out = ctypes.create_string_buffer(self.curve.g1_bytes)
         c = self.curve
-        check(load().mlhip_bases_msm(self._h, c._scalars(scalars), 1 if c.scalars_mont else 0, len(scalars), out))
+        check(self._lib.mlhip_bases_msm(self._h, c._scalars(scalars), 1 if c.scalars_mont else 0, len(scalars), out))
         return G1(out.raw, c)
 
     def CheckedSubgroup(self) -> bool:
         """every point of the table was verified on the device to lie in G1 (BLS12-377: Edwards bucket sums)"""
-        return load().mlhip_bases_checked_subgroup(self._h) == 1
+        return self._lib.mlhip_bases_checked_subgroup(self._h) == 1
 
     def Close(self) -> None:
         if self._h:
-            load().mlhip_bases_destroy(self._h)
+            self._lib.mlhip_bases_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):

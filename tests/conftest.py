@@ -52,25 +52,39 @@ ALT_SWITCHES = ("MLHIP_ACC32", "MLHIP_REDUCE32", "MLHIP_REDUCE_ONE_LANE", "MLHIP
 
 
 def alt_build() -> bool:
-    """Is the loaded library the test build (mlhip_version() bit 16)?"""
+    """Can this test run a second implementation?  Either the loaded library is the test build (mlhip_version() bit 16), or
+    an up-to-date libmlhip_alt.so lies next to the product library and the `monkeypatch` fixture below will route the test
+    through it when it turns such a switch on."""
     from mathlib_amd import _lib
 
-    return bool(_lib.load().mlhip_version() & 0x10000)
+    return bool(_lib.load().mlhip_version() & 0x10000) or _lib.alt_available()
 
 
 @pytest.fixture
 def monkeypatch(monkeypatch):
-    """pytest's monkeypatch, except that switching on a second implementation the loaded library does not contain skips
-    the test (the product library ignores those switches: the test would silently re-run the default path)."""
+    """pytest's monkeypatch, except that switching on a second implementation the product library does not contain routes
+    the REST OF THE TEST through the test build (mathlib_amd/_lib.py: use_alt; back to the product at teardown) -- or skips
+    the test when there is no up-to-date test build (the product ignores those switches: the test would silently re-run the
+    default path).  Tests that reach such a switch only after creating library objects guard it with alt_build() and create
+    the objects afterwards: a handle never crosses from one library to the other."""
+    from mathlib_amd import _lib
+
     plain = monkeypatch.setenv
+    switched = []
 
     def setenv(name, value, *a, **k):
-        if name in ALT_SWITCHES and str(value) == "1" and not alt_build():
-            pytest.skip("%s=1 needs the test build (python -m mathlib_amd.build --alt; MLHIP_LIB=mathlib_amd/libmlhip_alt.so)" % name)
+        if name in ALT_SWITCHES and str(value) == "1" and not (_lib.load().mlhip_version() & 0x10000):
+            if not _lib.alt_available():
+                pytest.skip("%s=1 needs the test build (python -m mathlib_amd.build --alt)" % name)
+            _lib.use_alt(True)
+            switched.append(name)
         return plain(name, value, *a, **k)
 
     monkeypatch.setenv = setenv
-    return monkeypatch
+    yield monkeypatch
+    if switched:
+        _lib.load().mlhip_release_cache()
+        _lib.use_alt(False)
 
 
 @pytest.fixture(scope="session")
