@@ -511,6 +511,41 @@ def main() -> None:
                         tb.append((time.perf_counter() - t1) * 1e3)
                 same_b = world > 1 or out_h.raw == res[G1]
                 _lib.check(lib.mlhip_bases_destroy(handle))
+                # ... and the same handle with the geometry left to the library (window_c = 0): from 2^17 bases on it keeps
+                # shifted-base tables (include/mlhip.h: mlhip_bases_create; msm_fold.h) -- 13 digits of 20 bits into ONE bucket
+                # set instead of 16 windows.  Not BASELINE's "c = 16", so never `value`; timed as protocol (b) and with the scalars
+                # resident (mlhip_bases_msm_device), phases from the handle's plan.
+                t1 = time.perf_counter()
+                _lib.check(lib.mlhip_bases_create(CURVE, G1, hp, n, 0, ctypes.byref(handle)))
+                create_ms = (time.perf_counter() - t1) * 1e3
+                tplan = lib.mlhip_bases_plan(handle)
+                _lib.check(lib.mlhip_msm_plan_set_profiling(tplan, 1))
+                tbt, tdt = [], []
+                for i in range(nwarm + ntimed):
+                    t1 = time.perf_counter()
+                    _lib.check(lib.mlhip_bases_msm(handle, hs, 0, n, out_h))
+                    if i >= nwarm:
+                        tbt.append((time.perf_counter() - t1) * 1e3)
+                same_t = world > 1 or out_h.raw == res[G1]
+                for i in range(nwarm + ntimed):
+                    t1 = time.perf_counter()
+                    _lib.check(lib.mlhip_bases_msm_device(handle, scalars.data_ptr(), 0, n, stream, out_h))
+                    if i >= nwarm:
+                        tdt.append((time.perf_counter() - t1) * 1e3)
+                same_t = same_t and (world > 1 or out_h.raw == res[G1])
+                tph = _lib.plan_timings(lib, tplan)
+                _lib.check(lib.mlhip_bases_destroy(handle))
+                extra["resident_bases_library_geometry"] = {
+                    "shifted_base_tables": tph.get("tables", 0.0) == 1.0, "digit_bits": tph.get("window_c"), "digits_per_scalar": tph.get("digits_per_scalar"),
+                    "create_ms": create_ms,
+                    "protocol_b_scalars_from_host_ms": {"median": statistics.median(tbt), "min": min(tbt), "max": max(tbt)},
+                    "scalars_resident_ms": {"median": statistics.median(tdt), "min": min(tdt), "max": max(tdt)},
+                    "protocol_b_scalar_muls_per_s": n / (statistics.median(tbt) * 1e-3),
+                    "scalars_resident_scalar_muls_per_s": n / (statistics.median(tdt) * 1e-3),
+                    "phase_ms_scalars_resident": {k: tph[k] for k in ("digits", "sort", "accumulate", "reduce", "device_total", "host_tail") if k in tph},
+                    "edwards_bucket_sums": tph.get("edwards", 0.0) == 1.0, "group": "G1", "pairs": n, "match_resident_result": bool(same_t),
+                    "note": "not BASELINE's c = 16 geometry: reported beside `value`, never as it",
+                }
                 for i in range(nwarm + ntimed):
                     t1 = time.perf_counter()
                     _lib.check(lib.mlhip_msm_g1(CURVE, hp, hs, 0, n, cfg.get("window_c", WINDOW_C), out_h))
@@ -526,6 +561,7 @@ def main() -> None:
                     "match_resident_result": bool(same_b and same_c),
                 }
                 extra["headline_protocol_b"] = extra["pcie_inclusive"]["protocol_b_scalar_muls_per_s"]
+                extra["headline_protocol_b_library_geometry"] = extra["resident_bases_library_geometry"]["protocol_b_scalar_muls_per_s"]
                 del hp, hs
                 lib.mlhip_release_cache()
         # ---- batched pairing beside the MSM headline (BASELINE configs[2]): 65 536 x (Miller loop + FExp)

@@ -164,8 +164,9 @@ MLHIP_API int mlhip_msm_launch_shared(mlhip_msm_plan* g1_plan, mlhip_msm_plan* g
  * MSM (mlhip_msm_g1 and friends on a pooled plan) records no phase events: [0..5] are then 0.  [7] and [8] are not times:
  * the window width c the plan runs with (the library's pick when it was created with window_c = 0) and its number of
  * windows W; [9] is 1 when the last launch summed its buckets in twisted Edwards coordinates (a subgroup-trusted
- * BLS12-377 G1 plan or table with the SRS promise, mlhip_msm_plan_assume_srs), else 0.  Returns the number of values written (at most `cap`, at
- * most 10). */
+ * BLS12-377 G1 plan or table with the SRS promise, mlhip_msm_plan_assume_srs), else 0; [10] is 1 when the plan reads the
+ * shifted-base tables of a mlhip_bases handle ([8] is then the number of digits a scalar is cut into).  Returns the number of
+ * values written (at most `cap`, at most 11). */
 MLHIP_API int mlhip_msm_plan_set_profiling(mlhip_msm_plan* plan, int on);
 /* The caller declares (on != 0) that this plan's points are a fixed SRS: (1) the point buffer at a given device address
  * holds the same points at every launch until the promise is taken back (the plan keeps its converted copy of them and
@@ -207,6 +208,13 @@ MLHIP_API int mlhip_scalar_mul(int curve, int group, const void* points, size_t 
  * count given at creation).  Calls on one handle from several threads are serialized inside the library (one MSM at a
  * time per handle); handles are independent of each other. */
 typedef struct mlhip_bases mlhip_bases;
+/* window_c = 0 leaves the geometry to the library, and lets it keep SHIFTED-BASE TABLES for the handle (tables of at least
+ * 2^17 bases that fit a quarter of the free device memory; MLHIP_BASES_TABLES=0 never, =1 always): besides P_i the device
+ * holds 2^off(j) P_i for every digit position j (first bit off(j)) of a signed-digit scalar (13-14 rows a base, 2.9 GB for 2^20 BLS12-381
+ * G1 bases, built once in ~60 ms), so that all digits of all scalars add into ONE set of 2^(c-1) buckets: a wider digit at the
+ * same reduction cost (13-19 % fewer bucket additions) and a host tail of 15 doublings instead of 256.  Same result bytes.
+ * An explicit window_c asks for that Pippenger geometry over the plain table (what BASELINE's "c = 16" names).  The
+ * reference has no counterpart: its MultiScalarMul takes fresh slices (driver/gurvy/bls12381/bls12-381.go:766-783). */
 MLHIP_API int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** bases);
 /* the table cut into contiguous shards over an explicit device list (mlhip_bases_create does this by itself with the
  * process's list from MLHIP_MULTI_MIN bases on): every mlhip_bases_msm then moves each device's scalars over its own
@@ -214,6 +222,13 @@ MLHIP_API int mlhip_bases_create(int curve, int group, const void* points, size_
 MLHIP_API int mlhip_bases_create_multi(int curve, int group, const int* devices, int n_devices, const void* points, size_t n,
                              int window_c, mlhip_bases** bases);
 MLHIP_API int mlhip_bases_msm(mlhip_bases* bases, const void* scalars, int scalars_mont, size_t n, void* out_affine);
+/* the same MSM with the n scalars already in device memory (a prover whose witness was computed on the device); `stream`
+ * as in mlhip_msm_run; single-device handles only (MLHIP_EINVAL for a table spread over several devices) */
+MLHIP_API int mlhip_bases_msm_device(mlhip_bases* bases, const void* d_scalars, int scalars_mont, size_t n, void* stream,
+                           void* out_affine);
+/* the plan a single-device handle runs its MSMs on (NULL otherwise) -- for mlhip_msm_plan_set_profiling /
+ * mlhip_msm_plan_timings only; it stays owned by the handle */
+MLHIP_API mlhip_msm_plan* mlhip_bases_plan(mlhip_bases* bases);
 /* 1 when mlhip_bases_create verified, on the device, that every point of the table is on the curve and in the prime-order
  * subgroup (or the point at infinity) -- done for BLS12-377 G1 tables, whose MSMs then sum their buckets in twisted
  * Edwards coordinates (see mlhip_msm_plan_assume_srs); 0 otherwise (other curves, G2, a table with a point outside the
@@ -274,6 +289,8 @@ MLHIP_API int mlhip_fp_mul_device(int curve, const void* d_a, const void* d_b, s
  *     MLHIP_SORT_TILE, MLHIP_CHUNK_LOG2, MLHIP_ACC_BLOCK, MLHIP_RED_BLOCK   kernel tile / chunk / workgroup sizes (sweeps)
  *     MLHIP_FIXED_BASE_MIN=n, MLHIP_FB_WINDOW=w, MLHIP_FB_CACHE=0   batched Mul of one base: table from n scalars on, width, no reuse
  *     MLHIP_EDWARDS=0                  BLS12-377 G1 over a checked SRS: keep the Weierstrass bucket sums
+ *     MLHIP_BASES_TABLES=0|1           mlhip_bases_create: never / always keep shifted-base tables (default: see there)
+ *     MLHIP_FOLD_WINDOW=c, MLHIP_FOLD_TILE_LOG2=t   ... their digit width (default 20) and tile (2^20 bases)
  *     MLHIP_PAIRING_QUAD=0|1           BLS12-381: never / always one pairing per quad of lanes (default: up to 2^14 elements)
  *   2nd impl (parity tests; DESIGN.md section 2 lists which test runs which)
  *     MLHIP_ACC32=1                    boundary-form (32-bit limb) bucket accumulation, G1 and G2

@@ -57,6 +57,8 @@ SYMBOLS = [
     "mlhip_scalar_mul",
     "mlhip_bases_create",
     "mlhip_bases_msm",
+    "mlhip_bases_msm_device",
+    "mlhip_bases_plan",
     "mlhip_bases_checked_subgroup",
     "mlhip_bases_destroy",
     "mlhip_release_cache",
@@ -189,6 +191,9 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.mlhip_scalar_mul.argtypes = [ci, ci, vp, sz, vp, ci, sz, vp]
     lib.mlhip_bases_create.argtypes = [ci, ci, vp, sz, ci, ctypes.POINTER(c_void_p)]
     lib.mlhip_bases_msm.argtypes = [vp, vp, ci, sz, vp]
+    lib.mlhip_bases_msm_device.argtypes = [vp, vp, ci, sz, vp, vp]
+    lib.mlhip_bases_plan.argtypes = [vp]
+    lib.mlhip_bases_plan.restype = c_void_p
     lib.mlhip_bases_destroy.argtypes = [vp]
     lib.mlhip_bases_checked_subgroup.argtypes = [vp]
     lib.mlhip_g1_from_bytes.argtypes = [ci, vp, sz, ci, ci, vp, vp]
@@ -203,7 +208,7 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.mlhip_g2_sum.argtypes = [ci, vp, sz, vp]
     lib.mlhip_fp_mul_device.argtypes = [ci, vp, vp, sz, ci, vp, vp]
     for name in SYMBOLS:
-        if name not in ("mlhip_last_error",):
+        if name not in ("mlhip_last_error", "mlhip_bases_plan"):
             getattr(lib, name).restype = ci
     return lib
 
@@ -241,6 +246,21 @@ def device_count() -> int:
     return n.value
 
 
+def plan_timings(lib, handle):
+    """mlhip_msm_plan_timings as a dict (include/mlhip.h): phase times in ms, tiles, and the two path flags"""
+    buf = (c_float * 11)()
+    k = lib.mlhip_msm_plan_timings(handle, buf, 11)
+    names = ["digits", "sort", "accumulate", "reduce", "device_total", "host_tail", "tiles"]
+    t = {names[i]: float(buf[i]) for i in range(min(k, 7))}
+    if k >= 9:
+        t["window_c"], t["digits_per_scalar"] = int(buf[7]), int(buf[8])
+    if k >= 10:
+        t["edwards"] = float(buf[9])
+    if k >= 11:
+        t["tables"] = float(buf[10])
+    return t
+
+
 class MsmPlan:
     """Device workspace for repeated MSMs over device-resident points/scalars (include/mlhip.h)."""
 
@@ -260,13 +280,7 @@ class MsmPlan:
         check(self._lib.mlhip_msm_plan_assume_srs(self._h, 1 if on else 0))
 
     def timings(self):
-        buf = (c_float * 10)()
-        k = self._lib.mlhip_msm_plan_timings(self._h, buf, 10)
-        names = ["digits", "sort", "accumulate", "reduce", "device_total", "host_tail", "tiles"]
-        t = {names[i]: float(buf[i]) for i in range(min(k, 7))}
-        if k >= 10:
-            t["edwards"] = float(buf[9])
-        return t
+        return plan_timings(self._lib, self._h)
 
     def window(self):
         """(c, W): the window width the plan runs with (the library's pick for window_c = 0) and its number of windows"""

@@ -776,7 +776,10 @@ int mlhip_sizes(int curve, size_t* fp, size_t* g1, size_t* g2, size_t* gt) {
   return 0;
 }
 
-int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhip_msm_plan** out) {
+// fold_tile != 0: a plan over shifted-base tables (msm_fold.h, mlhip_internal.h) -- window_c is the digit width, the
+// 2^(c-1) buckets all digits share are cut into groups of at most 2^15 for the reduction; the table itself is built by
+// mlhip_tu_plan_fold_build_* (mlhip_bases_create).
+static int plan_create_ex(int curve, int group, size_t max_n, int window_c, size_t fold_tile, mlhip_msm_plan** out) {
   if (!out) return mlhip_rt::fail(MLHIP_EINVAL, "null plan pointer");
   *out = nullptr;
   Sizes sz;
@@ -786,9 +789,17 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
   if (max_n == 0 || max_n > ((size_t)1 << 27)) return mlhip_rt::fail(MLHIP_EINVAL, "max_n out of range (1 .. 2^27)");
   if (window_c == 0) window_c = pick_window(max_n, sz.fr_bits);
   if (window_c < 4 || window_c > 20) return mlhip_rt::fail(MLHIP_EINVAL, "window_c out of range (4 .. 20)");
+  const int digits = msm_num_windows(sz.fr_bits, window_c);
   // sorted-entry offsets, cursors and scans are 32-bit: W * max_n entries must be addressable
-  if ((size_t)msm_num_windows(sz.fr_bits, window_c) * max_n > 0xFFFFFFFFull)
+  if (!fold_tile && (size_t)digits * max_n > 0xFFFFFFFFull)
     return mlhip_rt::fail(MLHIP_EINVAL, "window_c too small for max_n: W * max_n entries exceed 2^32 - 1");
+  if (fold_tile) {
+    // an entry = table row index (below Wd fold_tile) | sign: 31 bits + 1; the tiles of one MSM are its segments
+    if ((size_t)digits * fold_tile > ((size_t)1 << 30)) return mlhip_rt::fail(MLHIP_EINVAL, "shifted-base tables: tile too long");
+    // the sort's per-block bin counts are 16-bit and a block of 1024 scalars may put all its 1024 Wd entries into one bin
+    if ((size_t)digits * 1024 >= 65536) return mlhip_rt::fail(MLHIP_EINVAL, "shifted-base tables: digit width below 5 bits");
+    if ((max_n + fold_tile - 1) / fold_tile > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "shifted-base tables: too many tiles");
+  }
   int rc = ensure_device();
   if (rc) return rc;
   mlhip_msm_plan* p = new mlhip_msm_plan();
@@ -796,9 +807,18 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
   p->group = group;
   p->device = g_device;
   p->c = window_c;
-  p->W = msm_num_windows(sz.fr_bits, window_c);
+  p->Wd = digits;
   p->max_n = max_n;
-  p->M = 1u << (window_c - 1);
+  if (fold_tile) {
+    p->fold = 1;
+    p->fold_tile = fold_tile;
+    const uint32_t nbuckets = 1u << (window_c - 1);
+    p->M = nbuckets < 32768u ? nbuckets : 32768u;
+    p->W = (int)(nbuckets / p->M);
+  } else {
+    p->W = digits;
+    p->M = 1u << (window_c - 1);
+  }
   // buckets per level-1 reduction chunk: 16 for G1 (the quad-lane kernels are bound by work, and a longer chunk
   // halves the second level), 8 for G2 on the boundary-form curves and for tiny windows
   // (and for small bucket sets, where the chunk pass is a dependent chain rather than work: 2^12 points, c = 13:
@@ -819,6 +839,8 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
     case MLHIP_CURVE_BLS12_381: rc = mlhip_tu_plan_alloc_Bls381(p); break;
     default: rc = mlhip_tu_plan_alloc_Bls377(p); break;
   }
+  if (!rc && p->fold && (p->sort_low <= 0 || !p->reduce28))
+    rc = mlhip_rt::fail(MLHIP_EINVAL, "shifted-base tables need the two-level sort and the carry-free kernels");
   if (rc) {
     mlhip_msm_plan_destroy(p);
     return rc;
@@ -827,11 +849,16 @@ int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhi
   return 0;
 }
 
+int mlhip_msm_plan_create(int curve, int group, size_t max_n, int window_c, mlhip_msm_plan** out) {
+  return plan_create_ex(curve, group, max_n, window_c, 0, out);
+}
+
 int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->device);
   void* ptrs[] = {p->d_digits, p->d_sorted, p->d_zero, p->d_offsets, p->d_biglist, p->d_buckets, p->d_A, p->d_W0, p->d_out,
-                  p->d_order, p->d_hist, p->d_tilesums, p->d_coarse_off, p->d_points28, p->d_blockhist, p->d_state28, p->d_bigprefix, p->d_bigpart, p->d_binprefix};
+                  p->d_order, p->d_hist, p->d_tilesums, p->d_coarse_off, p->d_points28, p->d_blockhist, p->d_state28, p->d_bigprefix, p->d_bigpart, p->d_binprefix,
+                  p->d_fold_pts};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (p->h_out) (void)hipHostFree(p->h_out);
@@ -1014,7 +1041,7 @@ int mlhip_msm_plan_set_profiling(mlhip_msm_plan* p, int on) {
 // that path; called when the SRS promise is made, with nothing in flight on the plan.  A failed allocation is not an error:
 // the plan keeps (or gets back) the smaller buffer and stays on the Weierstrass kernels (plan_use_edwards checks the size).
 static void plan_reserve_edwards(mlhip_msm_plan* p) {
-  if (!p->points28_elem_ed || p->points28_elem >= p->points28_elem_ed || !p->d_points28) return;
+  if (!p->points28_elem_ed || p->points28_elem >= p->points28_elem_ed || !p->d_points28 || p->fold) return;
   const char* e = getenv("MLHIP_EDWARDS");
   if (e && e[0] == '0') return;
   (void)hipSetDevice(p->device);
@@ -1033,6 +1060,7 @@ static void plan_reserve_edwards(mlhip_msm_plan* p) {
 int mlhip_msm_plan_assume_srs(mlhip_msm_plan* p, int on) {
   if (!p) return mlhip_rt::fail(MLHIP_EINVAL, "null plan");
   if (p->pending) return mlhip_rt::fail(MLHIP_EINVAL, "mlhip_msm_plan_assume_srs with a launch pending");
+  if (p->fold) return mlhip_rt::fail(MLHIP_EINVAL, "mlhip_msm_plan_assume_srs: this plan reads the tables of a mlhip_bases handle");
   p->conv_src = nullptr;  // whatever carry-free copy the plan holds was made under the other promise
   p->points_static = p->trust_subgroup = on != 0;
   if (on) plan_reserve_edwards(p);
@@ -1041,12 +1069,13 @@ int mlhip_msm_plan_assume_srs(mlhip_msm_plan* p, int on) {
 
 int mlhip_msm_plan_timings(mlhip_msm_plan* p, float* ms, int cap) {
   if (!p || !ms) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
-  int k = cap < 10 ? cap : 10;
+  int k = cap < 11 ? cap : 11;
   for (int i = 0; i < k && i < 6; i++) ms[i] = p->ms[i];
   if (k >= 7) ms[6] = p->tiles_timed > 0 ? (float)p->tiles_timed : 1.0f;
   if (k >= 8) ms[7] = (float)p->c;
-  if (k >= 9) ms[8] = (float)p->W;
+  if (k >= 9) ms[8] = (float)p->Wd;
   if (k >= 10) ms[9] = p->last_ed ? 1.0f : 0.0f;
+  if (k >= 11) ms[10] = p->fold ? 1.0f : 0.0f;
   return k;
 }
 
@@ -1077,6 +1106,51 @@ int mlhip_bases_destroy(mlhip_bases* b) {
   return 0;
 }
 
+static int tu_plan_fold_build(mlhip_msm_plan* p, const void* d_pts, size_t n, hipStream_t st) {
+  switch (p->curve) {
+    case MLHIP_CURVE_BN254: return mlhip_tu_plan_fold_build_Bn254(p, d_pts, n, st);
+    case MLHIP_CURVE_BLS12_381: return mlhip_tu_plan_fold_build_Bls381(p, d_pts, n, st);
+    default: return mlhip_tu_plan_fold_build_Bls377(p, d_pts, n, st);
+  }
+}
+
+// Shifted-base tables for a table of n resident bases (msm_fold.h)?  They cost Wd rows per base (208 B a row for a 48-byte
+// field: 2.9 GB for 2^20 BLS12-381 G1 bases) and ~60 ms per 2^20 bases to build, and pay from the first few MSMs on.
+//   MLHIP_BASES_TABLES = 0: never; = 1: always (any size: what the tests use); unset: for tables of at least 2^17 bases
+//   created with window_c = 0 (an explicit window width asks for that Pippenger geometry) that fit a quarter of the free memory.
+//   MLHIP_FOLD_WINDOW = c: the digit width (default 20, see below); MLHIP_FOLD_TILE_LOG2 = t: tiles of 2^t bases (20).
+static bool bases_want_tables(int group, size_t n, int window_c, int fr_bits, size_t ptsz, int* c_out, size_t* tile_out) {
+  const char* e = getenv("MLHIP_BASES_TABLES");
+  const bool forced = e && e[0] == '1';
+  if (e && e[0] == '0') return false;
+  (void)group;
+  if (!forced && (n < ((size_t)1 << 17) || window_c != 0)) return false;
+  int lg_tile = 20;
+  if (const char* t = getenv("MLHIP_FOLD_TILE_LOG2")) {
+    const int v = atoi(t);
+    if (v >= 4 && v <= 24) lg_tile = v;
+  }
+  size_t tile = (size_t)1 << lg_tile;
+  if (n < tile) tile = n;
+  int c = 0;
+  if (const char* w = getenv("MLHIP_FOLD_WINDOW")) c = atoi(w);
+  // 20 bits (13 digits for a 253-255-bit group order) at every size from 2^17 on: narrower digits mean more of them and, in
+  // the even digit layout, most of the 2^(c-1) buckets half-used -- same-box runs (profiles/r04_fold.txt), BLS12-381 G1,
+  // resident scalars, c = 18 / 19 / 20 against the plain table: 2^17 1.11 / 0.83 / 0.80 (0.90) ms, 2^18 1.68 / 1.10 / 1.02
+  // (1.19), 2^19 - / 1.61 / 1.50 (1.75), 2^20 5.15 / 3.10 / 2.75 (3.16)
+  if (c < 5 || c > 20) c = 20;
+  const size_t tiles = (n + tile - 1) / tile;
+  const size_t rows = tiles * (size_t)msm_num_windows(fr_bits, c) * tile;
+  if (!forced) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    if (rows * (ptsz + ptsz + ptsz / 6 + 56) > free_b / 4) return false;  // boundary-form rows + carry-free rows (or Niels triples)
+  }
+  *c_out = c;
+  *tile_out = tile;
+  return true;
+}
+
 static int bases_create_single(int curve, int group, const void* points, size_t n, int window_c, size_t ptsz,
                                mlhip_bases** out) {
   int rc = ensure_device();
@@ -1087,7 +1161,15 @@ static int bases_create_single(int curve, int group, const void* points, size_t 
   b->group = group;
   b->n = n;
   b->ptsz = ptsz;
-  rc = mlhip_msm_plan_create(curve, group, n, window_c, &b->plan);
+  {
+    Sizes sz;
+    int fold_c = 0;
+    size_t fold_tile = 0;
+    if (curve_sizes(curve, sz) && bases_want_tables(group, n, window_c, sz.fr_bits, ptsz, &fold_c, &fold_tile)) {
+      if (plan_create_ex(curve, group, n, fold_c, fold_tile, &b->plan) != 0) b->plan = nullptr;  // (the plain plan below)
+    }
+  }
+  rc = b->plan ? 0 : mlhip_msm_plan_create(curve, group, n, window_c, &b->plan);
   if (!rc && (hipMalloc(&b->d_pts, n * b->ptsz) != hipSuccess || hipMalloc(&b->d_sc, n * 32) != hipSuccess))
     rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of the bases failed");
   if (!rc && hipMemcpy(b->d_pts, points, n * b->ptsz, hipMemcpyHostToDevice) != hipSuccess)
@@ -1116,6 +1198,26 @@ static int bases_create_single(int curve, int group, const void* points, size_t 
         }
         (void)hipFree(d_bad);
       }
+    }
+  }
+  if (b->plan->fold) {
+    // the shifted-base table, in the form the plan will read (after the subgroup check: Niels triples or Weierstrass rows).
+    // If it cannot be built (memory), the handle falls back to a plain plan over the uploaded bases.
+    rc = tu_plan_fold_build(b->plan, b->d_pts, n, b->stream);
+    if (!rc && hipStreamSynchronize(b->stream) != hipSuccess) rc = MLHIP_EHIP;
+    if (rc) {
+      (void)hipGetLastError();
+      const bool trusted = b->plan->trust_subgroup;
+      mlhip_msm_plan_destroy(b->plan);
+      b->plan = nullptr;
+      rc = mlhip_msm_plan_create(curve, group, n, window_c, &b->plan);
+      if (rc) {
+        mlhip_bases_destroy(b);
+        return rc;
+      }
+      b->plan->points_static = true;
+      b->plan->trust_subgroup = trusted;
+      if (trusted) plan_reserve_edwards(b->plan);
     }
   }
   *out = b;
@@ -1219,6 +1321,22 @@ int mlhip_bases_msm(mlhip_bases* b, const void* scalars, int scalars_mont, size_
     return mlhip_rt::fail(MLHIP_EHIP, "hipMemcpy of MSM scalars failed");
   return mlhip_msm_run(b->plan, b->d_pts, b->d_sc, scalars_mont, n, b->stream, out_affine, nullptr);
 }
+
+int mlhip_bases_msm_device(mlhip_bases* b, const void* d_scalars, int scalars_mont, size_t n, void* stream, void* out_affine) {
+  if (!b || !out_affine) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  if (!b->shards.empty()) return mlhip_rt::fail(MLHIP_EINVAL, "mlhip_bases_msm_device: the handle is spread over several devices");
+  if (n > b->n) return mlhip_rt::fail(MLHIP_EINVAL, "more scalars than resident bases");
+  if (n == 0) {
+    memset(out_affine, 0, b->ptsz);
+    return 0;
+  }
+  if (!d_scalars) return mlhip_rt::fail(MLHIP_EINVAL, "null pointer");
+  if (hipSetDevice(b->device) != hipSuccess) return mlhip_rt::fail(MLHIP_EHIP, "hipSetDevice failed");
+  std::lock_guard<std::mutex> lk(b->mu);
+  return mlhip_msm_run(b->plan, b->d_pts, d_scalars, scalars_mont, n, stream, out_affine, nullptr);
+}
+
+mlhip_msm_plan* mlhip_bases_plan(mlhip_bases* b) { return b && b->shards.empty() ? b->plan : nullptr; }
 
 int mlhip_release_cache(void) {
   // the fixed-base tables of the batched scalar multiplication (one per curve and device; msm_scalar_mul.h)

@@ -25,7 +25,7 @@ void host_parallel(int njobs, void (*fn)(const void*, int, void*), const void* i
     if (e_ != hipSuccess) return mlhip_rt::fail(MLHIP_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-#define MLHIP_MAX_SEGMENTS 16
+#define MLHIP_MAX_SEGMENTS 24
 
 // MLHIP_BUILD_ALT=1 (python -m mathlib_amd.build --alt -> libmlhip_alt.so): the test build.  It also contains the second
 // implementations the parity tests compare the default kernels with -- boundary-form (32-bit limb) bucket accumulation and
@@ -47,6 +47,21 @@ struct mlhip_msm_plan {
   int curve, group, device, c, W, L, lgL, nb, nsel;
   size_t max_n;
   uint32_t M, T;
+  // Shifted-base tables (msm_fold.h; resident bases only).  Wd = digits per scalar.  A plain plan has one bucket set per
+  // digit position: Wd == W windows of M = 2^(c-1) buckets.  A FOLDED plan (fold != 0) has ONE set of 2^(c-1) buckets for
+  // all Wd digits -- digit j of scalar i adds row (j, i) = 2^off(j) P_i of the table (off(j) = first bit of digit j) instead of P_i -- cut into W groups of
+  // M consecutive buckets for the reduction kernels; the host tail then has lg M doublings instead of one per scalar bit,
+  // the reduction 2^(c-1) buckets instead of Wd 2^(c-1), and c can grow (fewer digits = fewer additions).
+  // The table is tile-major: bases [k fold_tile, (k + 1) fold_tile) own rows [(k Wd + j) fold_tile + i_local], so that an
+  // entry index (i_local + j fold_tile) stays below Wd fold_tile whatever the number of bases; a sorted segment of scalars
+  // never crosses a tile.
+  int Wd = 0, fold = 0;
+  size_t fold_tile = 0, fold_n = 0;  // rows per digit block; bases tabulated
+  size_t fold_rows = 0;              // rows allocated in d_points28 / d_fold_pts (tiles x Wd x fold_tile)
+  void* d_fold_pts = nullptr;        // the rows in the boundary form (Affine<F>): what the sliced sums of long buckets read
+  // G1: the W groups' sums are combined on the device into the sums of one window of W T chunks (k_group_combine_q);
+  // d_out / h_out then hold fold_nsel2 = 4 + nb + lg W more entries behind the W x nsel ones, and the host tail reads those
+  int fold_nsel2 = 0;
   size_t pt_size, xyzz_size;
   uint32_t *d_digits = nullptr, *d_sorted = nullptr, *d_zero = nullptr, *d_offsets = nullptr, *d_biglist = nullptr;
   int sort_low = 0, sort_idx_bits = 0;  // two-level sort: fine bits per coarse bin (0 = legacy path)
@@ -127,6 +142,7 @@ struct mlhip_msm_plan {
                                  void* d_out, void* d_status, hipStream_t st);                                     \
   int mlhip_tu_scalar_mul_##NAME(int group, const void* d_points, size_t point_stride, const void* d_scalars,     \
                                  int mont, size_t n, void* d_out, hipStream_t st);                                 \
+  int mlhip_tu_plan_fold_build_##NAME(mlhip_msm_plan* p, const void* d_points, size_t n, hipStream_t st);          \
   void mlhip_tu_release_cache_##NAME(void);
 // G1 points outside the prime-order subgroup (or off the curve) in an array of affine points: mlhip_bases_create's check
 int mlhip_tu_g1_count_outside_subgroup_Bls377(const void* d_pts, size_t n, uint32_t* d_bad, hipStream_t st);

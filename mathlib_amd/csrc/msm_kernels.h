@@ -51,4 +51,5 @@ constexpr int CHUNK_L = 8;            // buckets per level-1 reduction thread
 #include "msm_reduce.h"
 #include "msm_g2.h"
 #include "msm_scalar_mul.h"
+#include "msm_fold.h"
 #include "msm_plan.h"

@@ -36,17 +36,20 @@ inline bool plan_use_edwards(const mlhip_msm_plan* p) {
 // the buffers launch_sort works in (a plan's own, or those of a sort-ahead helper record: sort_ahead_prepare)
 inline int plan_alloc_sort(mlhip_msm_plan* p) {
   const size_t nbuckets = (size_t)p->W * p->M;
-  HIPCHK(hipMalloc(&p->d_digits, (size_t)p->W * p->max_n * 4));
-  HIPCHK(hipMalloc(&p->d_sorted, (size_t)p->W * p->max_n * 4));
+  // a folded plan (msm_fold.h) sorts one tile of its table at a time: at most fold_tile scalars, Wd entries each, whose
+  // indices run over the Wd fold_tile rows of the tile
+  const size_t sort_n = p->fold ? std::min(p->max_n, p->fold_tile) : p->max_n;
+  HIPCHK(hipMalloc(&p->d_digits, (size_t)p->Wd * sort_n * 4));
+  HIPCHK(hipMalloc(&p->d_sorted, (size_t)p->Wd * sort_n * 4));
   {
     // sort parameters: packed entry = fine bits | sign | index must fit 32 bits, coarse bins must fit LDS
     int idx_bits = 1;
-    while (((size_t)1 << idx_bits) < p->max_n) idx_bits++;
+    while (((size_t)1 << idx_bits) < (p->fold ? (size_t)p->Wd * p->fold_tile : p->max_n)) idx_bits++;
     int low = p->c - 1 < 8 ? p->c - 1 : 8;
     if (low > 31 - idx_bits) low = 31 - idx_bits;
     const char* legacy = getenv("MLHIP_LEGACY_SORT");
-    uint32_t nb = low >= 1 ? (uint32_t)p->W << (p->c - 1 - low) : 0;
-    if (low < 1 || nb > 4096 || (legacy && legacy[0] == '1')) {
+    uint32_t nb = low >= 1 ? (uint32_t)(nbuckets >> low) : 0;  // (plain plan: W << (c - 1 - low))
+    if (low < 1 || nb > 4096 || (legacy && legacy[0] == '1' && !p->fold)) {
       p->sort_low = 0;
       p->sort_nb = 0;
     } else {
@@ -67,7 +70,7 @@ inline int plan_alloc_sort(mlhip_msm_plan* p) {
   HIPCHK(hipMalloc(&p->d_binprefix, ((size_t)p->sort_nb + 2) * 4));
   if (p->sort_nb) {
     static_assert(SORT_TILE_MAX < 65536, "a block puts at most one entry per scalar into a coarse bin: the count fits 16 bits");
-    const size_t blocks = (p->max_n + SORT_TILE - 1) / SORT_TILE;
+    const size_t blocks = (sort_n + SORT_TILE - 1) / SORT_TILE;
     HIPCHK(hipMalloc(&p->d_blockhist, blocks * p->sort_nb * sizeof(uint16_t)));
   }
   HIPCHK(hipMalloc(&p->d_offsets, nbuckets * 4));
@@ -94,7 +97,7 @@ int plan_alloc(mlhip_msm_plan* p) {
   HIPCHK(hipMalloc(&p->d_biglist, nbuckets * 4));
   {
     // long buckets: at most W n / BIG_BUCKET_MIN of them, and W n / BIG_SLICE + one more slice per bucket
-    const size_t entries = (size_t)p->W * p->max_n;
+    const size_t entries = (size_t)p->Wd * (p->fold ? std::min(p->max_n, p->fold_tile) : p->max_n);
     const size_t nbig_max = std::min(nbuckets, entries / BIG_BUCKET_MIN + 1);
     HIPCHK(hipMalloc(&p->d_bigprefix, (nbig_max + 2) * 4));
     HIPCHK(hipMalloc(&p->d_bigpart, (entries / BIG_SLICE + nbig_max + 2) * p->xyzz_size));
@@ -116,7 +119,10 @@ int plan_alloc(mlhip_msm_plan* p) {
     const bool want28 = !mlhip_alt_switch("MLHIP_ACC32");
     // (a curve with a twisted Edwards model grows the buffer to the Niels triples' 168 B a point when the SRS promise is made)
     constexpr size_t kPoint28 = sizeof(Affine28<typename F::Curve>);
-    if (want28) {
+    if (want28 && p->fold) {
+      p->points28_elem = 0;  // the table is allocated by plan_fold_build, in the form the plan will read
+      p->points28_elem_ed = F::Curve::HAS_EDWARDS ? sizeof(EdNiels28<typename F::Curve>) : 0;
+    } else if (want28) {
       HIPCHK(hipMalloc(&p->d_points28, p->max_n * kPoint28));
       p->points28_elem = kPoint28;
       p->points28_elem_ed = F::Curve::HAS_EDWARDS ? sizeof(EdNiels28<typename F::Curve>) : 0;
@@ -129,7 +135,7 @@ int plan_alloc(mlhip_msm_plan* p) {
   if constexpr (std::is_same<F, Fp2Field<typename F::Curve>>::value && g2_carry_free_v<typename F::Curve>) {
     // G2 in the carry-free form (g2_carry_free_v above)
     if (!mlhip_alt_switch("MLHIP_ACC32")) {
-      HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(AffineG2_28<typename F::Curve>)));
+      if (!p->fold) HIPCHK(hipMalloc(&p->d_points28, p->max_n * sizeof(AffineG2_28<typename F::Curve>)));
       // ... and the lane-pair reduction reads the accumulators as the kernel leaves them (MLHIP_REDUCE32=1: boundary form)
       p->reduce28 = !mlhip_alt_switch("MLHIP_REDUCE32");
       if (p->reduce28) HIPCHK(hipMalloc(&p->d_state28, nbuckets * 2 * sizeof(XYZZ28L<Fp28<typename F::Curve>>)));
@@ -145,8 +151,13 @@ int plan_alloc(mlhip_msm_plan* p) {
     HIPCHK(hipMalloc(&p->d_A, (size_t)p->W * p->T * chunk_size));
     HIPCHK(hipMalloc(&p->d_W0, (size_t)p->W * p->T * chunk_size));
   }
-  HIPCHK(hipMalloc(&p->d_out, (size_t)p->W * p->nsel * p->xyzz_size));
-  HIPCHK(hipHostMalloc(&p->h_out, (size_t)p->W * p->nsel * p->xyzz_size, hipHostMallocDefault));
+  if (p->fold && p->W > 1 && p->W <= 32 && p->reduce28 && std::is_same<F, FpField<typename F::Curve>>::value) {
+    int lgW = 0;
+    while ((1 << lgW) < p->W) lgW++;
+    p->fold_nsel2 = 4 + p->nb + lgW;
+  }
+  HIPCHK(hipMalloc(&p->d_out, ((size_t)p->W * p->nsel + p->fold_nsel2) * p->xyzz_size));
+  HIPCHK(hipHostMalloc(&p->h_out, ((size_t)p->W * p->nsel + p->fold_nsel2) * p->xyzz_size, hipHostMallocDefault));
   for (int i = 0; i < 5; i++) HIPCHK(hipEventCreate(&p->ev[i]));
   HIPCHK(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
   {  // the auxiliary stream: point conversion beside the sort, and the uploads of a streamed host-buffer MSM
@@ -184,8 +195,64 @@ void host_tail_window(const void* in, int w, void* out) {
   for (int q = 0; q < 4; q++) xyzz_add<F>(acc, o[q]);
   memcpy(out, &acc, sizeof(acc));
 }
+// A folded plan (msm_fold.h): job g < W is the weighted sum V_g of bucket group g (as a window's), job W + g its PLAIN sum
+// S_g = out[g][2] + out[g][3] (the two halves of sum_t A[g][t]).  Bucket b of group g has weight g M + b + 1, so
+//   total = sum_g V_g + M sum_g g S_g
+// -- lg M doublings in all, where the windows of a plain plan need one per scalar bit.
+template <class F>
+void host_tail_group(const void* in, int job, void* out) {
+  const HostTailHeader& h = *static_cast<const HostTailHeader*>(in);
+  const int W = h.pad;
+  if (job < W) {
+    host_tail_window<F>(in, job, out);
+    return;
+  }
+  const XYZZ<F>* o = reinterpret_cast<const XYZZ<F>*>(static_cast<const unsigned char*>(in) + sizeof(HostTailHeader)) + (size_t)(job - W) * h.nsel;
+  XYZZ<F> acc = o[2];
+  xyzz_add<F>(acc, o[3]);
+  memcpy(out, &acc, sizeof(acc));
+}
+template <class F>
+void host_tail_fold(const mlhip_msm_plan* p, XYZZ<F>& total) {
+  if (p->fold_nsel2) {
+    // the device has combined the groups (k_group_combine_q): one window of W T chunks, summed on this thread
+    const size_t sums2 = (size_t)p->fold_nsel2 * sizeof(XYZZ<F>);
+    std::vector<unsigned char> blob2(sizeof(HostTailHeader) + sums2);
+    const HostTailHeader h2{p->fold_nsel2 - 4, p->lgL, p->fold_nsel2, 0};
+    memcpy(blob2.data(), &h2, sizeof(h2));
+    memcpy(blob2.data() + sizeof(h2), static_cast<const XYZZ<F>*>(p->h_out) + (size_t)p->W * p->nsel, sums2);
+    host_tail_window<F>(blob2.data(), 0, &total);
+    return;
+  }
+  const size_t sums = (size_t)p->W * p->nsel * sizeof(XYZZ<F>);
+  std::vector<unsigned char> blob(sizeof(HostTailHeader) + sums);
+  const HostTailHeader h{p->nb, p->lgL, p->nsel, p->W};
+  memcpy(blob.data(), &h, sizeof(h));
+  memcpy(blob.data() + sizeof(h), p->h_out, sums);
+  const int W = p->W;
+  std::vector<XYZZ<F>> VS(2 * (size_t)W);
+  mlhip_rt::host_parallel(W > 1 ? 2 * W : 1, host_tail_group<F>, blob.data(), blob.size(), VS.data(), sizeof(XYZZ<F>));
+  // sum_g g S_g as a running sum from the top group down (run += S_g; hi += run), then the lg M doublings
+  XYZZ<F> run, hi;
+  xyzz_set_inf<F>(run);
+  xyzz_set_inf<F>(hi);
+  for (int g = W - 1; g >= 1; g--) {
+    xyzz_add<F>(run, VS[(size_t)W + g]);
+    xyzz_add<F>(hi, run);
+  }
+  int lgM = 0;
+  while ((1u << lgM) < p->M) lgM++;
+  const int down0 = lgM;
+  horner_jac<F>(total, &hi, 1, &down0);  // total = 2^lgM hi
+  for (int g = 0; g < W; g++) xyzz_add<F>(total, VS[g]);
+}
+
 template <class F>
 void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
+  if (p->fold) {
+    host_tail_fold<F>(p, total);
+    return;
+  }
   const WinLayout wl = msm_win_layout(F::Curve::FR_BITS, p->c);
   const size_t sums = (size_t)p->W * p->nsel * sizeof(XYZZ<F>);
   std::vector<unsigned char> blob(sizeof(HostTailHeader) + sums);
@@ -224,16 +291,23 @@ void launch_big_slices(mlhip_msm_plan* p, const Affine<F>* d_points, hipStream_t
 template <class C>
 int launch_sort(mlhip_msm_plan* p, const void* d_scalars, int mont, size_t n, hipStream_t st, bool prof) {
   const size_t nbuckets = (size_t)p->W * p->M;
+  const int Wd = p->Wd;  // entries per scalar (== W on a plain plan)
+  const uint32_t fold_stride = p->fold ? (uint32_t)p->fold_tile : 0u;
+  if (p->fold && (p->sort_low <= 0 || n > p->fold_tile))
+    return mlhip_rt::fail(MLHIP_EINVAL, "folded plan: a sort covers at most one tile of the table, on the two-level path");
   if (p->sort_low > 0) {
     // two-level LDS counting sort (no per-key global atomics)
     int tile = sort_tile_for(n);
+    // (a folded plan's digits share the bins: a block may put tile * Wd entries into one bin, and the count is 16-bit)
+    // (plan_create_ex admits only digit counts for which the smallest tile fits: Wd SORT_TILE < 65536)
+    while (p->fold && tile > SORT_TILE && (size_t)tile * Wd >= 65536) tile /= 2;
     const uint32_t NB = p->sort_nb;
     // entries staged in LDS and written bin by bin (k_coarse_scatter_staged) when a block's tile * W entries fit beside
     // the three bin tables -- the tile shrinks to make them fit; MLHIP_SCATTER_STAGED=0: one store per entry (round 1)
     const char* staged_env = getenv("MLHIP_SCATTER_STAGED");  // read per launch so that a test can switch paths
     const bool staged_on = !(staged_env && staged_env[0] == '0');
     constexpr size_t kLdsMax = 160 * 1024 - 256;
-    auto staged_lds = [&](int t) { return (3 * (size_t)NB + (size_t)t * p->W) * 4; };
+    auto staged_lds = [&](int t) { return (3 * (size_t)NB + (size_t)t * Wd) * 4; };
     bool staged = false;
     if (staged_on) {
       int t = tile;
@@ -244,27 +318,27 @@ int launch_sort(mlhip_msm_plan* p, const void* d_scalars, int mont, size_t n, hi
       }
     }
     const unsigned blocks = (unsigned)((n + tile - 1) / tile);
-    k_coarse_hist<C><<<dim3(blocks), dim3(256), NB * 4, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low, NB,
-                                                            p->d_coarse_count, p->d_blockhist, tile);
+    k_coarse_hist<C><<<dim3(blocks), dim3(256), NB * 4, st>>>((const uint32_t*)d_scalars, n, mont, p->c, Wd, p->sort_low, NB,
+                                                            p->d_coarse_count, p->d_blockhist, tile, fold_stride);
     if (prof) HIPCHK(hipEventRecord(p->ev[1], st));
     launch_scan(p->d_coarse_count, p->d_coarse_off, p->d_tilesums, NB, st);
     if (staged) {
       int group = 1;  // lanes per bin in the write-out: the mean run length, rounded down to a power of two
-      while (group < 64 && (size_t)group * 2 * NB <= (size_t)tile * p->W) group *= 2;
+      while (group < 64 && (size_t)group * 2 * NB <= (size_t)tile * Wd) group *= 2;
       HIPCHK(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
       k_coarse_scatter_staged<C><<<dim3(blocks), dim3(1024), staged_lds(tile), st>>>(
-          (const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low, p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
-          p->d_digits, p->d_blockhist, tile, group);
+          (const uint32_t*)d_scalars, n, mont, p->c, Wd, p->sort_low, p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
+          p->d_digits, p->d_blockhist, tile, group, fold_stride);
     } else {
-      k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, p->W, p->sort_low,
+      k_coarse_scatter<C><<<dim3(blocks), dim3(256), NB * 8, st>>>((const uint32_t*)d_scalars, n, mont, p->c, Wd, p->sort_low,
                                                                  p->sort_idx_bits, NB, p->d_coarse_off, p->d_coarse_cursor,
-                                                                 p->d_digits, p->d_blockhist, tile);
+                                                                 p->d_digits, p->d_blockhist, tile, fold_stride);
     }
     // bins more than 8x the mean (and at least 32768 entries) are sorted by many workgroups
-    const uint32_t big_bin = (uint32_t)std::min<size_t>(std::max<size_t>(32768, 8 * ((size_t)p->W * n / NB)), 0x7fffffffu);
+    const uint32_t big_bin = (uint32_t)std::min<size_t>(std::max<size_t>(32768, 8 * ((size_t)Wd * n / NB)), 0x7fffffffu);
     k_fine_sort<<<dim3(NB), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->c, p->sort_low,
                                                p->sort_idx_bits, big_bin, p->d_counts, p->d_offsets, p->d_sorted);
-    if ((size_t)p->W * n > big_bin) {  // a bin holds at most all W n entries: small MSMs skip three near-empty launches
+    if ((size_t)Wd * n > big_bin) {  // a bin holds at most all W n entries: small MSMs skip three near-empty launches
       k_bigbin_prefix<<<dim3(1), dim3(1024), 0, st>>>(p->d_coarse_count, NB, big_bin, p->d_binprefix);
       k_bigbin_hist<<<dim3(1024), dim3(256), 0, st>>>(p->d_digits, p->d_coarse_off, p->d_coarse_count, p->d_binprefix, NB,
                                                      p->sort_low, p->sort_idx_bits, p->d_counts);
@@ -350,6 +424,9 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
           k_masked_sums_q28<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * sizeof(X28), st>>>(
               (const X28*)p->d_A, (const X28*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
         }
+        if (p->fold_nsel2)  // folded plan: the groups' sums combined into one window's (both forms leave Weierstrass sums)
+          k_group_combine_q<C, 256><<<dim3((unsigned)p->fold_nsel2), dim3(256), 64 * sizeof(X), st>>>(
+              (const X*)p->d_out, p->W, p->nsel, p->nb, (X*)p->d_out + (size_t)p->W * p->nsel);
       } else if constexpr (kBuildAlt) {  // boundary-form reductions: test build only
         if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created
           k_chunks<F><<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>((const X*)p->d_buckets, n_chunks,
@@ -385,6 +462,10 @@ template <class C, class F>
 int resident_tiles(const mlhip_msm_plan* p, size_t n) {
   constexpr bool kG2 = std::is_same<F, Fp2Field<C>>::value;
   if (!p->aux || !p->d_points28) return 1;
+  if (p->fold) {  // one pass per tile of the table (an entry index addresses the rows of one tile)
+    const size_t k = (n + p->fold_tile - 1) / p->fold_tile;
+    return k < 2 ? 1 : (int)std::min<size_t>(k, MLHIP_MAX_SEGMENTS);
+  }
   int lg = kG2 ? 20 : 21;
   size_t from = (size_t)1 << (kG2 ? 23 : 22);
   if (plan_use_edwards<C, F>(p)) {  // 168-byte Niels triples: 2^20 of them are what 2^21 Weierstrass points weigh
@@ -407,6 +488,12 @@ template <class C, class F>
 int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, int mont, size_t n, hipStream_t st) {
   typedef Affine<F> A;
   typedef XYZZ<F> X;
+  if (p->fold) {
+    // the points are the plan's own table (plan_fold_build): the caller's point argument only names the bases it was built from
+    if (n > p->fold_n || !p->d_points28 || !p->d_fold_pts || p->upload_src)
+      return mlhip_rt::fail(MLHIP_EINVAL, "folded plan: more scalars than tabulated bases, or no table");
+    d_points = p->d_fold_pts;
+  }
   if (n != 0 && !p->upload_src) {
     const int K = resident_tiles<C, F>(p, n);
     if (K > 1)
@@ -422,7 +509,8 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     // Buckets far longer than the mean (degenerate inputs: equal scalars, tiny scalars) are handed to a whole
     // workgroup each; the threshold scales with the mean length n / 2^(c-1) so that large n, and the sparser top
     // window (2-4x the mean for these group orders), stay on the one-thread-per-bucket path.
-    uint32_t big_threshold = (uint32_t)std::min<size_t>((n >> (p->c - 1)) * 8, 1u << 30);
+    // (a folded plan's buckets collect the entries of all Wd digits: the mean is Wd n / 2^(c-1))
+    uint32_t big_threshold = (uint32_t)std::min<size_t>((((size_t)(p->fold ? p->Wd : 1) * n) >> (p->c - 1)) * 8, 1u << 30);
     if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
     if (p->upload_src && !p->d_points28) {  // no auxiliary stream on this path: plain upload first
       HIPCHK(hipMemcpy(const_cast<void*>(d_points), p->upload_src, p->upload_bytes, hipMemcpyHostToDevice));
@@ -439,9 +527,9 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
       if (rc_sort) return rc_sort;
     }
     // resident bases: the carry-free copy of the first conv_n points of this very buffer is already there
-    const bool use_ed = plan_use_edwards<C, F>(p);
+    const bool use_ed = p->fold ? p->conv_ed : plan_use_edwards<C, F>(p);  // (a table is read in the form it was built in)
     p->last_ed = use_ed;
-    const bool conv_cached = p->points_static && p->conv_src == d_points && n <= p->conv_n && !p->upload_src && p->conv_ed == use_ed;
+    const bool conv_cached = p->fold || (p->points_static && p->conv_src == d_points && n <= p->conv_n && !p->upload_src && p->conv_ed == use_ed);
     if (p->d_points28 && conv_cached) {
       HIPCHK(hipEventRecord(p->ev_join, st));  // nothing to wait for
     } else if (p->d_points28) {
@@ -542,7 +630,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
           p->d_bigcount, (X*)p->d_buckets);
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[3], st));
-    if (n > big_threshold) {  // a bucket holds at most all n entries: small MSMs skip three near-empty launches
+    if ((size_t)(p->fold ? p->Wd : 1) * n > big_threshold) {  // a bucket holds at most all n entries (Wd n when folded): small MSMs skip three near-empty launches
       constexpr int BB = sizeof(X) <= 192 ? 256 : 128;  // 48 KB of LDS per block
       launch_big_slices<F, BB>(p, (const A*)d_points, st);
       bool folded = false;
@@ -581,7 +669,7 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
     }
     if (prof) HIPCHK(hipEventRecord(p->ev[4], st));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->W * p->nsel * sizeof(X), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, ((size_t)p->W * p->nsel + p->fold_nsel2) * sizeof(X), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(p->done, st));
   }
   return 0;
@@ -630,9 +718,15 @@ int stream_begin(mlhip_msm_plan* p, StreamCtx& cx, hipStream_t st, int min_K) {
   // resident points (h_points == nullptr): only the scalars travel (or nothing: h_scalars == nullptr); their carry-free
   // copy is either the plan's (resident bases) or made tile by tile
   cx.resident = cx.h_points == nullptr;
-  cx.ed = plan_use_edwards<C, F>(p);
+  cx.ed = p->fold ? p->conv_ed : plan_use_edwards<C, F>(p);
   p->last_ed = cx.ed;
   cx.conv_cached = cx.resident && p->points_static && p->conv_src == cx.d_points && cx.n <= p->conv_n && p->conv_ed == cx.ed;
+  if (p->fold) {
+    if (!cx.resident || cx.n > p->fold_n || !p->d_fold_pts)
+      return mlhip_rt::fail(MLHIP_EINVAL, "folded plan: the points are the plan's table; more scalars than tabulated bases");
+    cx.conv_cached = true;
+    cx.d_points = p->d_fold_pts;
+  }
   cx.prof = p->profiling && cx.h_scalars == nullptr;  // tiles of device-resident inputs: per-tile phase events
   if (cx.prof)
     for (int s = 0; s < cx.K; s++)
@@ -648,6 +742,34 @@ int stream_begin(mlhip_msm_plan* p, StreamCtx& cx, hipStream_t st, int min_K) {
     for (size_t off = 0; off < cx.n; off += seg) cx.bound[k++] = off;
     cx.bound[k] = cx.n;
     cx.K = k;
+  }
+  if (p->fold) {
+    // no segment may cross a tile of the table: cut at the tile boundaries; if that makes too many segments, fall back to
+    // the tiles themselves
+    if ((cx.n + p->fold_tile - 1) / p->fold_tile > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "folded plan: too many tiles");
+    size_t b[2 * MLHIP_MAX_SEGMENTS + 2];
+    int m = 0;
+    b[0] = 0;
+    for (int s2 = 0; s2 < cx.K; s2++) {
+      const size_t hi = cx.bound[s2 + 1];
+      for (size_t t = (b[m] / p->fold_tile + 1) * p->fold_tile; t < hi; t += p->fold_tile) b[++m] = t;
+      b[++m] = hi;
+    }
+    if (m > MLHIP_MAX_SEGMENTS) {
+      m = 0;
+      for (size_t t = p->fold_tile; t < cx.n; t += p->fold_tile) b[++m] = t;
+      b[++m] = cx.n;
+      if (m > MLHIP_MAX_SEGMENTS) return mlhip_rt::fail(MLHIP_EINVAL, "folded plan: too many tiles");
+    }
+    for (int s2 = 0; s2 <= m; s2++) cx.bound[s2] = b[s2];
+    cx.K = m;
+    for (int s2 = 0; s2 < cx.K; s2++) {  // (events of the segments the cut added)
+      if (!p->ev_seg[s2]) HIPCHK(hipEventCreateWithFlags(&p->ev_seg[s2], hipEventDisableTiming));
+      if (cx.prof)
+        for (int j = 0; j < 3; j++)
+          if (!p->ev_tile[s2][j]) HIPCHK(hipEventCreate(&p->ev_tile[s2][j]));
+    }
+    if (cx.prof) p->tiles_timed = cx.K;
   }
   cx.seg = 0;
   for (int s2 = 0; s2 < cx.K; s2++) cx.seg = std::max(cx.seg, cx.bound[s2 + 1] - cx.bound[s2]);
@@ -672,7 +794,9 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   const char* hp = (const char*)cx.h_points;
   const char* hs = (const char*)cx.h_scalars;
   char* dsc = (char*)cx.d_scalars + off * 32;
-  A* dpt = (A*)cx.d_points + off;
+  // where this segment's points start: plain arrays at `off`; a folded plan's table at the tile block that holds base `off`
+  const size_t row0 = p->fold ? fold_row(p, off) : off;
+  A* dpt = (A*)cx.d_points + row0;
   const bool prof = cx.prof;
   if (hs) HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
   // points and scalars both travel: the sort starts when the segment's scalars are there, under the upload of its points
@@ -710,7 +834,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   if (!uploads || split) HIPCHK(hipStreamWaitEvent(st, p->ev_seg[s], 0));  // only the accumulation waits for points / conversion
   if (prof) HIPCHK(hipEventRecord(p->ev_tile[s][1], st));
   const mlhip_msm_plan* sv = sorter ? sorter : p;  // whose entry lists the kernels read
-  uint32_t big_threshold = (uint32_t)std::min<size_t>((len >> (p->c - 1)) * 8, 1u << 30);
+  uint32_t big_threshold = (uint32_t)std::min<size_t>((((size_t)(p->fold ? p->Wd : 1) * len) >> (p->c - 1)) * 8, 1u << 30);
   if (big_threshold < BIG_BUCKET_MIN) big_threshold = BIG_BUCKET_MIN;
   if constexpr (kG2) {
     const dim3 grid((unsigned)((2 * nbuckets + p->acc_block - 1) / p->acc_block)), block(p->acc_block);
@@ -718,14 +842,14 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
     if constexpr (C::BETA == -1 && kBuildAlt) {
       if (g2_split_by_coordinate()) {
         k_accumulate28_kc_seg<C><<<grid, block, 0, st>>>(
-            (const AffineG2_28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+            (const AffineG2_28<C>*)p->d_points28 + row0, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
             big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
         kc = true;
       }
     }
     if (!kc)
       k_accumulate28_lp_seg<C><<<grid, block, 0, st>>>(
-          (const AffineG2_28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+          (const AffineG2_28<C>*)p->d_points28 + row0, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
           big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
     constexpr int BB = 128;
     launch_big_slices<F, BB>(p, dpt, st, sv);
@@ -738,7 +862,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
     if constexpr (C::HAS_EDWARDS) {
       if (cx.ed) {  // (implies MLHIP_SEG_KEEP28: the last tile leaves XYZZ28 for the reduction)
         k_accumulate_ed28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-            (const EdNiels28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+            (const EdNiels28<C>*)p->d_points28 + row0, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
             big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags);
         launch_big_slices<F, BB>(p, dpt, st, sv);
         k_accumulate_big_seg_ed<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
@@ -748,7 +872,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
     }
     if (!done_ed) {
       k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
-          (const Affine28<C>*)p->d_points28 + off, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
+          (const Affine28<C>*)p->d_points28 + row0, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
           big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
       launch_big_slices<F, BB>(p, dpt, st, sv);
       k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
@@ -775,7 +899,7 @@ int stream_end(mlhip_msm_plan* p, const StreamCtx& cx, hipStream_t st) {
   }
   if (cx.prof) HIPCHK(hipEventRecord(p->ev[4], st));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->W * p->nsel * sizeof(X), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(p->h_out, p->d_out, ((size_t)p->W * p->nsel + p->fold_nsel2) * sizeof(X), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(p->done, st));
   return 0;
 }
@@ -807,6 +931,9 @@ int sort_ahead_prepare(mlhip_msm_plan* p, size_t seg, bool& on) {
       h->device = p->device;
       h->c = p->c;
       h->W = p->W;
+      h->Wd = p->Wd;
+      h->fold = p->fold;
+      h->fold_tile = p->fold_tile;
       h->M = p->M;
       h->L = p->L;
       h->lgL = p->lgL;
@@ -873,7 +1000,7 @@ int sort_ahead_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s) {
 //       its scalars, under the upload of its points -- stream_tile.)
 // MLHIP_STREAM_SCHEDULE="w0,w1,..." (weights, at most MLHIP_MAX_SEGMENTS) overrides; MLHIP_STREAM_SEGMENTS = K keeps K equal
 // segments (what the tests use to force many segments on small inputs).
-inline void stream_schedule(StreamCtx& cx, bool points_travel, size_t tile) {
+inline void stream_schedule(StreamCtx& cx, bool points_travel, size_t tile, bool fold_tiles = false) {
   int w[MLHIP_MAX_SEGMENTS];
   int k = 0;
   if (const char* e = getenv("MLHIP_STREAM_SCHEDULE")) {
@@ -885,6 +1012,17 @@ inline void stream_schedule(StreamCtx& cx, bool points_travel, size_t tile) {
     }
   } else if (getenv("MLHIP_STREAM_SEGMENTS")) {
     return;  // K equal segments
+  } else if (fold_tiles && cx.n > tile && !points_travel) {
+    // a folded plan with several tiles: 3 x 2^16 pairs, the rest of the first tile, then the tiles (a segment cannot cross one)
+    const size_t first = (size_t)3 << 16;
+    int m = 0;
+    cx.bound[0] = 0;
+    if (tile > 2 * first) cx.bound[++m] = first;
+    for (size_t t = tile; t < cx.n && m + 1 < MLHIP_MAX_SEGMENTS; t += tile) cx.bound[++m] = t;
+    cx.bound[++m] = cx.n;
+    cx.K = m;
+    cx.scheduled = true;
+    return;
   } else if (cx.n >= ((size_t)1 << 20) && !points_travel) {
     // resident bases: 3 x 2^16 pairs first, then segments that grow fourfold (the scalars of the next segment -- 0.6 ns a
     // pair on the wire -- must arrive within the kernels of this one -- 2.5 ns a pair) up to one tile (2^21 pairs: what keeps
@@ -936,7 +1074,8 @@ int plan_stream(mlhip_msm_plan* p, void* d_points, void* d_scalars, const void* 
   cx.n = n;
   cx.K = K;
   if (h_scalars && std::is_same<F, FpField<C>>::value)
-    stream_schedule(cx, h_points != nullptr, (size_t)1 << (plan_use_edwards<C, F>(p) ? 20 : 21));  // the tile of resident_tiles
+    stream_schedule(cx, h_points != nullptr,
+                    p->fold ? p->fold_tile : (size_t)1 << (plan_use_edwards<C, F>(p) ? 20 : 21), p->fold != 0);  // the tile of resident_tiles
   int rc = stream_begin<C, F>(p, cx, st, 2);
   if (rc) return rc;
   bool ahead = false;
@@ -971,6 +1110,7 @@ int plan_stream_shared(mlhip_msm_plan* p1, mlhip_msm_plan* p2, void* d_points_g1
   typedef Fp2Field<C> F2;
   if (p1->c != p2->c || p1->W != p2->W || p1->M != p2->M)
     return mlhip_rt::fail(MLHIP_EINVAL, "the two plans of a shared-scalar MSM need the same window width");
+  if (p1->fold || p2->fold) return mlhip_rt::fail(MLHIP_EINVAL, "shared-scalar MSM: plans with shifted-base tables are not supported");
   int K = 1;
   if (h_scalars) {
     // uploads to hide: segments of 2^17 pairs, as a host-buffer G2 MSM (api.hip: stream_segments)

@@ -124,12 +124,14 @@ static inline int sort_tile_for(size_t n) {
 template <class C>
 __global__ void __launch_bounds__(256) k_coarse_hist(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
                                                      int low, uint32_t NB, uint32_t* __restrict__ coarse_count,
-                                                     uint16_t* __restrict__ blockhist, int tile) {
+                                                     uint16_t* __restrict__ blockhist, int tile, uint32_t fold_stride) {
   extern __shared__ uint32_t lds_u32[];
   uint32_t* hist = lds_u32;
   for (uint32_t b = threadIdx.x; b < NB; b += 256) hist[b] = 0;
   __syncthreads();
   const uint32_t cb_shift = (uint32_t)(c - 1 - low);  // coarse bins per window = 1 << cb_shift
+  // fold_stride != 0: a folded plan (msm_fold.h) -- the W digits of a scalar (same layout) share one bucket set (window 0 of
+  // the bin numbering) and digit w's entry carries the table row index i + w fold_stride
   const WinLayout wl = msm_win_layout(C::FR_BITS, c);
   for (int k = 0; k < tile / 256; k++) {
     size_t i = (size_t)blockIdx.x * tile + (size_t)k * 256 + threadIdx.x;
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(256) k_coarse_hist(const uint32_t* __restrict_
     uint32_t carry = 0, neg = 0;
     for (int w = 0; w < W; w++) {
       const uint32_t mag = msm_window_digit(s, msm_win_off(wl.base, wl.rem, w), msm_win_bits(wl.base, wl.rem, w), carry, neg);
-      if (mag) atomicAdd(&hist[((uint32_t)w << cb_shift) + ((mag - 1) >> low)], 1u);
+      if (mag) atomicAdd(&hist[((fold_stride ? 0u : (uint32_t)w) << cb_shift) + ((mag - 1) >> low)], 1u);
     }
   }
   __syncthreads();
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(256) k_coarse_scatter(const uint32_t* __restri
                                                         int low, int idx_bits, uint32_t NB,
                                                         const uint32_t* __restrict__ coarse_off,
                                                         uint32_t* __restrict__ coarse_cursor, uint32_t* __restrict__ tmp,
-                                                        const uint16_t* __restrict__ blockhist, int tile) {
+                                                        const uint16_t* __restrict__ blockhist, int tile, uint32_t fold_stride) {
   extern __shared__ uint32_t lds_u32[];
   uint32_t* hist = lds_u32;       // per-block count, then running rank
   uint32_t* base = lds_u32 + NB;  // global position of this block's slice of each bin
@@ -185,9 +187,9 @@ __global__ void __launch_bounds__(256) k_coarse_scatter(const uint32_t* __restri
       const uint32_t mag = msm_window_digit(s, msm_win_off(wl.base, wl.rem, w), msm_win_bits(wl.base, wl.rem, w), carry, neg);
       if (mag) {
         uint32_t bkt = mag - 1;
-        uint32_t bin = ((uint32_t)w << cb_shift) + (bkt >> low);
+        uint32_t bin = ((fold_stride ? 0u : (uint32_t)w) << cb_shift) + (bkt >> low);
         uint32_t pos = base[bin] + atomicAdd(&hist[bin], 1u);
-        tmp[pos] = ((bkt & low_mask) << (idx_bits + 1)) | (neg << idx_bits) | (uint32_t)i;
+        tmp[pos] = ((bkt & low_mask) << (idx_bits + 1)) | (neg << idx_bits) | ((uint32_t)i + (uint32_t)w * fold_stride);
       }
     }
   }
@@ -205,7 +207,8 @@ __global__ void __launch_bounds__(1024) k_coarse_scatter_staged(const uint32_t* 
                                                                 int W, int low, int idx_bits, uint32_t NB,
                                                                 const uint32_t* __restrict__ coarse_off,
                                                                 uint32_t* __restrict__ coarse_cursor, uint32_t* __restrict__ tmp,
-                                                                const uint16_t* __restrict__ blockhist, int tile, int group) {
+                                                                const uint16_t* __restrict__ blockhist, int tile, int group,
+                                                                uint32_t fold_stride) {
   extern __shared__ uint32_t lds_u32[];
   uint32_t* cnt = lds_u32;            // this block's count per bin, then the running rank
   uint32_t* loc = lds_u32 + NB;       // start of the bin's run in the staged image
@@ -256,9 +259,9 @@ __global__ void __launch_bounds__(1024) k_coarse_scatter_staged(const uint32_t* 
         const uint32_t mag = msm_window_digit(s, msm_win_off(wl.base, wl.rem, w), msm_win_bits(wl.base, wl.rem, w), carry, neg);
         if (mag) {
           const uint32_t bkt = mag - 1;
-          const uint32_t bin = ((uint32_t)w << cb_shift) + (bkt >> low);
+          const uint32_t bin = ((fold_stride ? 0u : (uint32_t)w) << cb_shift) + (bkt >> low);
           const uint32_t r = atomicAdd(&cnt[bin], 1u);
-          stage[loc[bin] + r] = ((bkt & low_mask) << (idx_bits + 1)) | (neg << idx_bits) | (uint32_t)i;
+          stage[loc[bin] + r] = ((bkt & low_mask) << (idx_bits + 1)) | (neg << idx_bits) | ((uint32_t)i + (uint32_t)w * fold_stride);
         }
       }
     }

@@ -29,4 +29,8 @@ int mlhip_tu_scalar_mul_Bls377(int group, const void* d_points, size_t point_str
     return scalar_mul_device<Bls377, FpField<Bls377>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
   return scalar_mul_device<Bls377, Fp2Field<Bls377>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
 }
+int mlhip_tu_plan_fold_build_Bls377(mlhip_msm_plan* p, const void* d_points, size_t n, hipStream_t st) {
+  if (p->group == MLHIP_GROUP_G1) return plan_fold_build<Bls377, FpField<Bls377>>(p, d_points, n, st);
+  return plan_fold_build<Bls377, Fp2Field<Bls377>>(p, d_points, n, st);
+}
 void mlhip_tu_release_cache_Bls377(void) { fixed_base_release(); }

@@ -29,4 +29,8 @@ int mlhip_tu_scalar_mul_Bn254(int group, const void* d_points, size_t point_stri
     return scalar_mul_device<Bn254, FpField<Bn254>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
   return scalar_mul_device<Bn254, Fp2Field<Bn254>>(d_points, point_stride, d_scalars, mont, n, d_out, st);
 }
+int mlhip_tu_plan_fold_build_Bn254(mlhip_msm_plan* p, const void* d_points, size_t n, hipStream_t st) {
+  if (p->group == MLHIP_GROUP_G1) return plan_fold_build<Bn254, FpField<Bn254>>(p, d_points, n, st);
+  return plan_fold_build<Bn254, Fp2Field<Bn254>>(p, d_points, n, st);
+}
 void mlhip_tu_release_cache_Bn254(void) { fixed_base_release(); }

@@ -1169,3 +1169,84 @@ def test_msm_g1g2_host_buffers(lib, mlhip, curve, monkeypatch):
         sc = _rand_scalars(n, 100 + cid, 252)
         threads = max(1, min(64, len(os.sched_getaffinity(0))))
         assert run(p1, p2, sc, n, 16) == (cref.msm(cid, 1, p1, sc, n, False, 16, threads), cref.msm(cid, 2, p2, sc, n, False, 16, threads))
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("curve", CURVES)
+def test_bases_shifted_tables(lib, mlhip, curve, group, monkeypatch):
+    """Shifted-base tables of a resident-bases handle (include/mlhip.h: mlhip_bases_create; msm_fold.h): rows 2^(c j) P_i,
+    one bucket set for all digits, bucket groups in the reduction, the group-weight host tail.  Against the C oracle: several
+    digit widths (one bucket group and many), tables of one tile and of several (ragged last tile), prefixes of the bases,
+    host and device scalars, segment schedules that must be cut at the tile boundaries, bases at infinity, scalars 0 / 1 /
+    r - 1 / all equal (long buckets: every digit of every scalar in one bucket), and the plain plan of the same bases."""
+    import numpy as np
+    import torch
+    from oracle import cref
+    from oracle import pyref as R
+
+    g = load_golden(curve)
+    cid = g["curve_id"]
+    r = R.CURVES[curve].r
+    g1b = mlhip.sizes(cid)[group]  # (bytes of a point of this group)
+    n = 6000 if group == 1 else 2500
+    pts = bytearray(cref.gen_points(cid, group, 55, 7, n))
+    pts[17 * g1b : 18 * g1b] = bytes(g1b)  # bases at infinity
+    pts[(n - 1) * g1b : n * g1b] = bytes(g1b)
+    pts = bytes(pts)
+    sc = _rand_scalars(n, 4100 + cid, 252)
+    for i, v in ((0, 0), (1, 1), (2, r - 1), (3, r - 1), (4, (1 << 200) - 1)):
+        sc[i] = [(v >> (64 * k)) & ((1 << 64) - 1) for k in range(4)]
+    same = np.tile(np.array([[(0x123456789ABCDEF0F0E1D2C3B4A59687 >> (64 * k)) & ((1 << 64) - 1) for k in range(2)] + [77, 5]], dtype=np.uint64), (n, 1))
+    want = {k: cref.msm(cid, group, pts, sc, k, False, 0, 8) for k in (n, 1, 2199)}
+    want_same = cref.msm(cid, group, pts, same, n, False, 0, 8)
+    dev = torch.device("cuda", 0)
+    d_sc = torch.frombuffer(bytearray(sc.tobytes()), dtype=torch.uint8).to(dev)
+    monkeypatch.setenv("MLHIP_BASES_TABLES", "1")
+    for c, tile_lg in ((13, 20), (17, 20), (19, 11), (20, 9), (8, 12), (5, 10)) if group == 1 else ((17, 20), (20, 10), (9, 8)):
+        monkeypatch.setenv("MLHIP_FOLD_WINDOW", str(c))
+        monkeypatch.setenv("MLHIP_FOLD_TILE_LOG2", str(tile_lg))
+        h = ctypes.c_void_p()
+        mlhip.check(lib.mlhip_bases_create(cid, group, pts, n, 0, ctypes.byref(h)))
+        plan = lib.mlhip_bases_plan(h)
+        assert plan
+        out = ctypes.create_string_buffer(g1b)
+        for k in (n, 1, 2199, n):
+            mlhip.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, k, out))
+            assert out.raw == want[k], (curve, c, tile_lg, k)
+        t = mlhip.plan_timings(lib, plan)
+        assert t["tables"] == 1.0 and t["window_c"] == c, t
+        mlhip.check(lib.mlhip_bases_msm_device(h, d_sc.data_ptr(), 0, n, torch.cuda.current_stream().cuda_stream, out))
+        assert out.raw == want[n], (curve, c, tile_lg, "device scalars")
+        mlhip.check(lib.mlhip_bases_msm(h, same.tobytes(), 0, n, out))
+        assert out.raw == want_same, (curve, c, tile_lg, "equal scalars")
+        for seg in ("5", "2"):  # streamed scalars, equal segments: cut again at the tile boundaries
+            monkeypatch.setenv("MLHIP_STREAM_SEGMENTS", seg)
+            mlhip.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, n, out))
+            assert out.raw == want[n], (curve, c, tile_lg, "segments", seg)
+        monkeypatch.delenv("MLHIP_STREAM_SEGMENTS")
+        monkeypatch.setenv("MLHIP_STREAM_SCHEDULE", "1,2,5")
+        mlhip.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, n, out))
+        assert out.raw == want[n], (curve, c, tile_lg, "schedule")
+        monkeypatch.delenv("MLHIP_STREAM_SCHEDULE")
+        mlhip.check(lib.mlhip_bases_destroy(h))
+    # digits below 5 bits are too many for the sort's 16-bit block counts: the width falls back to the default
+    monkeypatch.setenv("MLHIP_FOLD_WINDOW", "4")
+    h = ctypes.c_void_p()
+    mlhip.check(lib.mlhip_bases_create(cid, group, pts, n, 4, ctypes.byref(h)))
+    t = mlhip.plan_timings(lib, lib.mlhip_bases_plan(h))
+    assert t["tables"] == 1.0 and t["window_c"] == 20, t
+    out = ctypes.create_string_buffer(g1b)
+    mlhip.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, n, out))
+    assert out.raw == want[n]
+    mlhip.check(lib.mlhip_bases_destroy(h))
+    # no tables: an explicit window width, or the switch off
+    monkeypatch.delenv("MLHIP_FOLD_WINDOW")
+    monkeypatch.delenv("MLHIP_FOLD_TILE_LOG2")
+    monkeypatch.setenv("MLHIP_BASES_TABLES", "0")
+    h = ctypes.c_void_p()
+    mlhip.check(lib.mlhip_bases_create(cid, group, pts, n, 0, ctypes.byref(h)))
+    assert mlhip.plan_timings(lib, lib.mlhip_bases_plan(h))["tables"] == 0.0
+    out = ctypes.create_string_buffer(g1b)
+    mlhip.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, n, out))
+    assert out.raw == want[n]
+    mlhip.check(lib.mlhip_bases_destroy(h))

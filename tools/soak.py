@@ -146,19 +146,41 @@ while time.time() - t0 < budget:
             devs = (ctypes.c_int * nd)(*([0] * nd))
             _lib.check(lib.mlhip_msm_multi(cid, group, devs, nd, pts, sc.tobytes(), 0, n, c, out))
             done["multi"] = done.get("multi", 0) + 1
-        elif mode < 0.42 and group == 1:  # a resident table (BLS12-377: checked on the device, then Edwards bucket sums)
+        elif mode < 0.50:  # a resident table (BLS12-377 G1: checked on the device, then Edwards bucket sums)
+            # half of them with shifted-base tables (msm_fold.h) of a random digit width and tile length, G1 and G2
+            shifted = rnd.random() < 0.5
+            fw, ft = rnd.choice([5, 8, 11, 13, 16, 17, 19, 20]), rnd.choice([4, 6, 9, 12, 20])
+            if shifted:
+                while -(-n // (1 << ft)) > 24:  # at most MLHIP_MAX_SEGMENTS tiles
+                    ft += 1
+                os.environ.update({"MLHIP_BASES_TABLES": "1", "MLHIP_FOLD_WINDOW": str(fw), "MLHIP_FOLD_TILE_LOG2": str(ft)})
+            else:
+                os.environ["MLHIP_BASES_TABLES"] = "0"
             h = ctypes.c_void_p()
-            _lib.check(lib.mlhip_bases_create(cid, 1, pts, n, c, ctypes.byref(h)))
+            _lib.check(lib.mlhip_bases_create(cid, group, pts, n, 0 if shifted else c, ctypes.byref(h)))
+            for k2 in ("MLHIP_BASES_TABLES", "MLHIP_FOLD_WINDOW", "MLHIP_FOLD_TILE_LOG2"):
+                os.environ.pop(k2, None)
+            if shifted and _lib.plan_timings(lib, lib.mlhip_bases_plan(h)).get("tables") != 1.0:
+                print("NO TABLES on a forced handle", name, group, n, fw, ft, "seed", seed, flush=True)
+                sys.exit(1)
             k = rnd.randrange(1, n + 1)
             _lib.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, k, out))
-            if k != n and out.raw != cref.msm(cid, 1, pts, sc, k, False, 0, 16):
-                print("MISMATCH bases prefix", name, n, k, c, bits, "seed", seed, flush=True)
+            if k != n and out.raw != cref.msm(cid, group, pts, sc, k, False, 0, 16):
+                print("MISMATCH bases prefix", name, group, n, k, c, bits, "shifted", shifted, fw, ft, "seed", seed, flush=True)
                 sys.exit(1)
-            _lib.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, n, out))
-            if name == "BLS12-377":
+            if rnd.random() < 0.5:
+                _lib.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, n, out))
+            else:  # scalars already on the device
+                import torch
+
+                ds = torch.frombuffer(bytearray(sc.tobytes()), dtype=torch.uint8).to(torch.device("cuda", 0))
+                _lib.check(lib.mlhip_bases_msm_device(h, ds.data_ptr(), 0, n, torch.cuda.current_stream().cuda_stream, out))
+            if name == "BLS12-377" and group == 1:
                 done["tables_checked"] = done.get("tables_checked", 0) + lib.mlhip_bases_checked_subgroup(h)
             _lib.check(lib.mlhip_bases_destroy(h))
             done["bases"] = done.get("bases", 0) + 1
+            if shifted:
+                done["shifted_tables"] = done.get("shifted_tables", 0) + 1
         else:
             _lib.check(fn(cid, pts, sc.tobytes(), 0, n, c, out))
         if out.raw != exp:
