@@ -482,6 +482,20 @@ func (b *Bases) CheckedSubgroup() bool {
 	return b.h != nil && C.mlhip_bases_checked_subgroup(b.h) == 1
 }
 
+// ShiftedTables reports whether the handle keeps shifted-base tables (include/mlhip.h: mlhip_bases_create): 2^off(j) P_i for
+// every digit position, so that all digits of all scalars share one bucket set.
+func (b *Bases) ShiftedTables() bool {
+	if b.h == nil {
+		return false
+	}
+	p := C.mlhip_bases_plan(b.h)
+	if p == nil {
+		return false
+	}
+	var t [11]C.float
+	return C.mlhip_msm_plan_timings(p, &t[0], 11) >= 11 && t[10] == 1
+}
+
 func (b *Bases) Close() {
 	if b.h != nil {
 		C.mlhip_bases_destroy(b.h)

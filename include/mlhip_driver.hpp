@@ -583,6 +583,12 @@ class Bases {
   // every point of the table was verified on the device to lie in G1 (BLS12-377: its MSMs then sum their buckets in
   // twisted Edwards coordinates; a table with a point outside G1 keeps the Weierstrass kernels and the reference's result)
   bool CheckedSubgroup() const { return mlhip_bases_checked_subgroup(h_) == 1; }
+  // the handle keeps shifted-base tables (include/mlhip.h: mlhip_bases_create): one bucket set for all digits of a scalar
+  bool ShiftedTables() const {
+    float t[11] = {0};
+    mlhip_msm_plan* p = mlhip_bases_plan(h_);
+    return p && mlhip_msm_plan_timings(p, t, 11) >= 11 && t[10] == 1.0f;
+  }
 
  private:
   const Curve* curve_;

@@ -7,6 +7,8 @@
 // driver/gurvy/bls12-377.go:229-242): signed-digit windows, bucket accumulation in XYZZ
 // coordinates, bucket reduction, window combination.  Data layout and pipeline: DESIGN.md section 3.
 #pragma once
+#include <cstring>
+
 #include "ec.h"
 
 namespace mlhip {
@@ -158,6 +160,30 @@ MLHIP_HD void msm_chunk_body(size_t g, const XYZZ<F>* buckets, XYZZ<F>* A, XYZZ<
   add(acc, b[0]);
   A[g] = acc;
   W0[g] = w0;
+}
+
+// ---- host tail of one window (msm_plan.h: host_tail; here so that the host-math test library can run it) ------------
+// V = out[0..3] summed + 2^lgL sum_k 2^k out[4 + k]: nb + lgL doublings and nb + 4 additions
+struct HostTailHeader {
+  int nb, lgL, nsel, pad;
+};
+template <class F>
+void host_tail_window(const void* in, int w, void* out) {
+  const HostTailHeader& h = *static_cast<const HostTailHeader*>(in);
+  const XYZZ<F>* o = reinterpret_cast<const XYZZ<F>*>(static_cast<const unsigned char*>(in) + sizeof(HostTailHeader)) + (size_t)w * h.nsel;
+  XYZZ<F> acc, d;
+  xyzz_set_inf<F>(acc);
+  for (int k = h.nb - 1; k >= 0; k--) {
+    xyzz_dbl<F>(d, acc);
+    acc = d;
+    xyzz_add<F>(acc, o[4 + k]);
+  }
+  for (int k = 0; k < h.lgL; k++) {
+    xyzz_dbl<F>(d, acc);
+    acc = d;
+  }
+  for (int q = 0; q < 4; q++) xyzz_add<F>(acc, o[q]);
+  memcpy(out, &acc, sizeof(acc));
 }
 
 }  // namespace mlhip

@@ -15,45 +15,13 @@
 
 namespace mlhip {
 
-// rows[j stride + i] = 2^off(j) P_i, j = 0 .. Wd - 1, off(j) = the first bit of digit j (msm_win_layout: the digits of a
-// scalar are as wide as each other up to one bit, so no digit position is sparse), one lane per base: off(j) - off(j - 1)
-// Jacobian doublings (ec_jac.h) per row and one inversion to make the row affine.  A base at infinity (0, 0), or one whose multiple reaches infinity (points of small
-// order exist outside the prime-order subgroup), gives rows (0, 0): the accumulation kernels skip them.
+// rows[j stride + i] = 2^off(j) P_i, j = 0 .. Wd - 1: one lane per base (fold_rows_body, msm_fold_body.h)
 template <class C, class F>
 __global__ void __launch_bounds__(64) k_fold_rows(const Affine<F>* __restrict__ pts, size_t n, int c, size_t stride,
                                                   Affine<F>* __restrict__ rows) {
-  const WinLayout wl = msm_win_layout(C::FR_BITS, c);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Affine<F> P = pts[i];
-  rows[i] = P;
-  Jac<F> acc;
-  if (F::is_zero(P.x) && F::is_zero(P.y)) {
-    jac_set_inf<F>(acc);
-  } else {
-    acc.x = P.x;
-    acc.y = P.y;
-    F::one(acc.z);
-  }
-#pragma unroll 1
-  for (int j = 1; j < wl.W; j++) {
-    const int steps = msm_win_off(wl.base, wl.rem, j) - msm_win_off(wl.base, wl.rem, j - 1);
-#pragma unroll 1
-    for (int k = 0; k < steps; k++) jac_dbl<F>(acc, acc);
-    Affine<F> r;
-    if (jac_is_inf<F>(acc)) {
-      F::zero(r.x);
-      F::zero(r.y);
-    } else {
-      typename F::T zi, z2;
-      F::inv(zi, acc.z);
-      F::sqr(z2, zi);
-      F::mul(r.x, acc.x, z2);
-      F::mul(z2, z2, zi);
-      F::mul(r.y, acc.y, z2);
-    }
-    rows[(size_t)j * stride + i] = r;
-  }
+  fold_rows_body<F>(pts[i], C::FR_BITS, c, stride, rows + i);
 }
 
 // first row of the table block that holds base `off` (tile-major layout, mlhip_internal.h)

@@ -36,6 +36,7 @@
 #include "fp2_lanes.h"
 #include "mlhip_internal.h"
 #include "msm_body.h"
+#include "msm_fold_body.h"
 
 namespace mlhip {
 

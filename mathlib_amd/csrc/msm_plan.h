@@ -174,27 +174,6 @@ int plan_alloc(mlhip_msm_plan* p) {
 // workers (mlhip_rt::host_parallel); what stays sequential is the Horner pass over the windows, one doubling per scalar
 // bit.  2^20 points, c = 16: 0.20 -> 0.10 ms.  MLHIP_HOST_THREADS=1 keeps everything on the calling thread.
 // (host_parallel copies its input blob: {nb, lgL, nsel} then the W x nsel partial sums as the device left them)
-struct HostTailHeader {
-  int nb, lgL, nsel, pad;
-};
-template <class F>
-void host_tail_window(const void* in, int w, void* out) {
-  const HostTailHeader& h = *static_cast<const HostTailHeader*>(in);
-  const XYZZ<F>* o = reinterpret_cast<const XYZZ<F>*>(static_cast<const unsigned char*>(in) + sizeof(HostTailHeader)) + (size_t)w * h.nsel;
-  XYZZ<F> acc, d;
-  xyzz_set_inf<F>(acc);
-  for (int k = h.nb - 1; k >= 0; k--) {
-    xyzz_dbl<F>(d, acc);
-    acc = d;
-    xyzz_add<F>(acc, o[4 + k]);
-  }
-  for (int k = 0; k < h.lgL; k++) {
-    xyzz_dbl<F>(d, acc);
-    acc = d;
-  }
-  for (int q = 0; q < 4; q++) xyzz_add<F>(acc, o[q]);
-  memcpy(out, &acc, sizeof(acc));
-}
 // A folded plan (msm_fold.h): job g < W is the weighted sum V_g of bucket group g (as a window's), job W + g its PLAIN sum
 // S_g = out[g][2] + out[g][3] (the two halves of sum_t A[g][t]).  Bucket b of group g has weight g M + b + 1, so
 //   total = sum_g V_g + M sum_g g S_g

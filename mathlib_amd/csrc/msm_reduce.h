@@ -314,16 +314,8 @@ __global__ void __launch_bounds__(BLOCK) k_group_combine_q(const XYZZ<FpField<C>
   Fp<C> acc, v;
   quad_set_inf<C>(acc);
   if (quad < NQ) {  // quad-uniform
-    const int g = (int)(quad >> 1), h = (int)(quad & 1u);
-    int src = -1;
-    if (o == 0)
-      src = h;
-    else if (o == 1)
-      src = 2 + h;
-    else if (o >= 4 && o < 4 + nb)
-      src = h == 0 ? o : -1;
-    else if (o >= 4 + nb)
-      src = ((g >> (o - 4 - nb)) & 1) ? 2 + h : -1;
+    const int g = (int)(quad >> 1);
+    const int src = fold_combine_src(o, g, (int)(quad & 1u), nb);
     if (src >= 0) quad_load<C>(acc, in, (size_t)g * nsel + src);
   }
   quad_store<C>(sh, quad, acc);

@@ -521,6 +521,13 @@ class Bases:
         """every point of the table was verified on the device to lie in G1 (BLS12-377: Edwards bucket sums)"""
         return self._lib.mlhip_bases_checked_subgroup(self._h) == 1
 
+    def ShiftedTables(self) -> bool:
+        """the handle keeps shifted-base tables (include/mlhip.h: mlhip_bases_create): one bucket set for all digits"""
+        from ._lib import plan_timings
+
+        plan = self._lib.mlhip_bases_plan(self._h)
+        return bool(plan) and plan_timings(self._lib, plan).get("tables") == 1.0
+
     def Close(self) -> None:
         if self._h:
             self._lib.mlhip_bases_destroy(self._h)

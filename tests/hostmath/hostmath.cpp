@@ -4,9 +4,11 @@
 // and nothing in the product path links or loads it.
 #include <stdint.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "../../mathlib_amd/csrc/pairing.h"
 #include "../../mathlib_amd/csrc/msm_body.h"
+#include "../../mathlib_amd/csrc/msm_fold_body.h"
 #include "../../mathlib_amd/csrc/codec.h"
 #include "../../mathlib_amd/csrc/ec28.h"
 #include "../../mathlib_amd/csrc/ec_jac.h"
@@ -193,6 +195,82 @@ struct Ops {
       memcpy(out, &r, sizeof(A2));
     }
     return 0;
+  }
+  // A whole MSM over shifted-base tables (msm_fold.h), replayed on the host with the kernels' own bodies: the table rows
+  // (fold_rows_body), the signed digits of the even layout into ONE bucket set (msm_window_digit, xyzz_madd), the bucket
+  // groups reduced like windows (msm_chunk_body, the plain / masked sums of k_masked_sums), the groups combined into one
+  // window (fold_combine_src, k_group_combine_q) and that window's host tail (host_tail_window).  Digit width c, groups
+  // of 2^lgM buckets, chunks of 2^lgL.  group 1 or 2; affine result.
+  template <class F>
+  static int fold_msm_t(const void* pts, const void* scalars, int n, int c, int lgM, int lgL, void* out) {
+    typedef Affine<F> A;
+    typedef XYZZ<F> X;
+    const WinLayout wl = msm_win_layout(C::FR_BITS, c);
+    const int Wd = wl.W;
+    const size_t nbuckets = (size_t)1 << (c - 1);
+    const size_t M = std::min(nbuckets, (size_t)1 << lgM), W = nbuckets / M;
+    const size_t L = (size_t)1 << lgL, T = M / L;
+    if (T < 1 || (T & (T - 1)) || W > 32) return -4;
+    int nb = 0;
+    while (((size_t)1 << nb) < T) nb++;
+    const int nsel = 4 + nb;
+    const A* P = (const A*)pts;
+    std::vector<A> rows((size_t)Wd * n);
+    for (int i = 0; i < n; i++) fold_rows_body<F>(P[i], C::FR_BITS, c, (size_t)n, rows.data() + i);
+    std::vector<X> B(nbuckets);
+    for (auto& b : B) xyzz_set_inf<F>(b);
+    for (int i = 0; i < n; i++) {
+      uint32_t s[8];
+      fr_canonical<C>(s, (const uint32_t*)scalars + 8 * i, false);
+      uint32_t carry = 0, neg = 0;
+      for (int w = 0; w < Wd; w++) {
+        const uint32_t mag = msm_window_digit(s, msm_win_off(wl.base, wl.rem, w), msm_win_bits(wl.base, wl.rem, w), carry, neg);
+        if (mag) xyzz_madd<F>(B[mag - 1], rows[(size_t)w * n + i], neg != 0);
+      }
+    }
+    // per group: chunk sums, then the nsel sums of k_masked_sums
+    std::vector<X> outg(W * nsel);
+    for (size_t g = 0; g < W; g++) {
+      std::vector<X> Ach(T), W0(T);
+      for (size_t t = 0; t < T; t++)
+        msm_chunk_body<F>(t, B.data() + g * M, Ach.data(), W0.data(), (int)L, [](X& a, const X& q) { xyzz_add<F>(a, q); });
+      X* o = outg.data() + g * nsel;
+      for (int k = 0; k < nsel; k++) xyzz_set_inf<F>(o[k]);
+      const size_t half = (T + 1) / 2;
+      for (size_t t = 0; t < T; t++) {
+        xyzz_add<F>(o[t < half ? 0 : 1], W0[t]);
+        xyzz_add<F>(o[t < half ? 2 : 3], Ach[t]);
+        for (int k = 0; k < nb; k++)
+          if ((t >> k) & 1) xyzz_add<F>(o[4 + k], Ach[t]);
+      }
+    }
+    // the groups combined into one window of W T chunks
+    int lgW = 0;
+    while (((size_t)1 << lgW) < W) lgW++;
+    const int nsel2 = 4 + nb + lgW;
+    std::vector<unsigned char> blob(sizeof(HostTailHeader) + (size_t)nsel2 * sizeof(X));
+    const HostTailHeader h{nb + lgW, lgL, nsel2, 0};
+    memcpy(blob.data(), &h, sizeof(h));
+    X* comb = reinterpret_cast<X*>(blob.data() + sizeof(h));
+    for (int o = 0; o < nsel2; o++) {
+      X acc;
+      xyzz_set_inf<F>(acc);
+      for (size_t g = 0; g < W; g++)
+        for (int hh = 0; hh < 2; hh++) {
+          const int src = fold_combine_src(o, (int)g, hh, nb);
+          if (src >= 0) xyzz_add<F>(acc, outg[g * nsel + src]);
+        }
+      memcpy(&comb[o], &acc, sizeof(X));
+    }
+    X total;
+    host_tail_window<F>(blob.data(), 0, &total);
+    A r;
+    xyzz_to_affine<F>(r, total);
+    memcpy(out, &r, sizeof(A));
+    return Wd;
+  }
+  static int fold_msm(int group, const void* pts, const void* scalars, int n, int c, int lgM, int lgL, void* out) {
+    return group == 1 ? fold_msm_t<FpField<C>>(pts, scalars, n, c, lgM, lgL, out) : fold_msm_t<Fp2Field<C>>(pts, scalars, n, c, lgM, lgL, out);
   }
   static int g1dec(const uint8_t* w, int compressed, int subgroup, void* out) {
     A1 p;
@@ -847,6 +925,9 @@ int hm_g1_tree(int curve, const void* pts, int n, void* out) { DISPATCH(curve, g
 int hm_g2_tree(int curve, const void* pts, int n, void* out) { DISPATCH(curve, g2_tree(pts, n, out)) }
 int hm_digits(int curve, const void* scalar, int mont, int c, uint32_t* out, int cap) { DISPATCH(curve, digits(scalar, mont, c, out, cap)) }
 int hm_horner(int curve, int group, const void* pts, int W, const int* down, int which, void* out) { DISPATCH(curve, horner(group, pts, W, down, which, out)) }
+int hm_fold_msm(int curve, int group, const void* pts, const void* scalars, int n, int c, int lgM, int lgL, void* out) {
+  DISPATCH(curve, fold_msm(group, pts, scalars, n, c, lgM, lgL, out))
+}
 int hm_chunks(int curve, const void* pts, int n_chunks, void* outA, void* outW0) { DISPATCH(curve, chunks(pts, n_chunks, outA, outW0)) }
 int hm_g1_decode(int curve, const uint8_t* w, int compressed, int subgroup, void* out) { DISPATCH(curve, g1dec(w, compressed, subgroup, out)) }
 int hm_g1_encode(int curve, const void* pt, int compressed, uint8_t* w) { DISPATCH(curve, g1enc(pt, compressed, w)) }

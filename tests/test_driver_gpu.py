@@ -361,17 +361,21 @@ def test_g2_wire_round_trips(curve):
         c.NewG2FromBytes(bytes(bad))
 
 
+@pytest.mark.parametrize("tables", ["0", "1"])
 @pytest.mark.parametrize("segments", ["0", "3"])
-def test_resident_bases_match_multiscalarmul(curve, segments, monkeypatch):
+def test_resident_bases_match_multiscalarmul(curve, segments, tables, monkeypatch):
     """the upload-once point table gives the same element as MultiScalarMul, for the full table and
-    for a prefix of it, on repeated calls -- in one pass and with the scalars streamed in three segments."""
+    for a prefix of it, on repeated calls -- in one pass and with the scalars streamed in three segments; over the plain
+    table and over shifted-base tables (forced: a table of 40 bases does not get them by itself)."""
     monkeypatch.setenv("MLHIP_STREAM_SEGMENTS", segments)
+    monkeypatch.setenv("MLHIP_BASES_TABLES", tables)
     c = curve
     g = c.GenG1()
     pts = [g.Mul(c.NewRandomZr(c._rng)) for _ in range(40)]
     bases = c.NewBases(pts)
     from mathlib_amd import _lib
 
+    assert bases.ShiftedTables() == (tables == "1")
     # the table is checked on the device where a curve has the twisted Edwards model that needs it (BLS12-377)
     assert bases.CheckedSubgroup() == (c.id == _lib.CURVE_BLS12_377)
     for n in (40, 17, 1, 40):

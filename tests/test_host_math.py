@@ -102,6 +102,38 @@ def test_host_tail_horner_in_jacobian_coordinates(hostmath, name):
 
 
 @pytest.mark.parametrize("name", CURVES)
+def test_shifted_base_tables_msm_on_the_host(hostmath, name):
+    """msm_fold.h (round 4): a whole MSM over shifted-base tables replayed with the kernels' own bodies (hm_fold_msm: table
+    rows 2^off(j) P_i by Jacobian doublings, all signed digits into ONE bucket set, bucket groups reduced like windows, the
+    groups combined into one window by k_group_combine_q's selection, that window's host tail) against sum_i [s_i] P_i in
+    Python integers: G1 and G2, one bucket group and several, digit widths that divide the scalar unevenly, scalars 0 / 1 /
+    r - 1 / equal, a base at infinity."""
+    cp = R.CURVES[name]
+    L, cid, fb = hostmath, cp.curve_id, cp.fp_bytes
+    d = R.Drbg("hm/fold/" + name)
+    for group in (1, 2):
+        rand, add, mul = (R.random_g1, R.g1_add, R.g1_mul_unreduced) if group == 1 else (R.random_g2, R.g2_add, R.g2_mul_unreduced)
+        enc = R.g1_to_mont_bytes if group == 1 else R.g2_to_mont_bytes
+        dec = R.g1_from_mont_bytes if group == 1 else R.g2_from_mont_bytes
+        size = (2 if group == 1 else 4) * fb
+        n = 14 if group == 1 else 6
+        pts = [rand(cp, d) for _ in range(n)]
+        pts[3] = None
+        sc = [d.below(cp.r) for _ in range(n)]
+        sc[0], sc[1], sc[2], sc[4], sc[5] = 0, 1, cp.r - 1, sc[n - 1], (1 << 200) - 1
+        want = None
+        for p, k in zip(pts, sc):
+            if p is not None and k:
+                want = add(cp, want, mul(cp, p, k))
+        buf = b"".join(enc(cp, p) for p in pts)
+        sb = b"".join(k.to_bytes(32, "little") for k in sc)
+        for c, lgM, lgL in ((7, 4, 2), (7, 6, 3), (9, 5, 2), (6, 2, 1), (11, 8, 4)) if group == 1 else ((7, 4, 2), (6, 5, 3)):
+            out = ctypes.create_string_buffer(size)
+            assert L.hm_fold_msm(cid, group, buf, sb, n, c, lgM, lgL, out) == -(-(cp.r.bit_length() + 1) // c)
+            assert dec(cp, out.raw) == want, (name, group, c, lgM, lgL)
+
+
+@pytest.mark.parametrize("name", CURVES)
 def test_group_law_including_exceptional_cases(hostmath, name):
     cp = R.CURVES[name]
     L, cid, n = hostmath, cp.curve_id, cp.fp_bytes

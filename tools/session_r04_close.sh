@@ -4,7 +4,8 @@
 #   B  configs 2, 3, 5: rocprofv3 kernel stats + FETCH_SIZE / WRITE_SIZE passes, THEN profiles/r04_pmc_traffic.json is made on the
 #      box (so that every bench line printed after it carries `traffic`), THEN the default bench line and the lines of 3 and 5
 #   C  config 4: the same order
-# Usage (GPU box, repo root): MLHIP_COMMIT=<short hash> bash tools/session_r04_close.sh A|B|C
+#   D  kernel stats of the shifted-base-table path (tools/perf_fold.py under rocprofv3)
+# Usage (GPU box, repo root): MLHIP_COMMIT=<short hash> bash tools/session_r04_close.sh A|B|C|D
 out=gpurun_out/r04z
 mkdir -p $out
 export TMPDIR=/tmp
@@ -51,6 +52,11 @@ C)
   profile_configs "4"
   make_traffic C
   python3 bench.py --config 4 --steps 5 --warmup 2 > "$out/bench_c4.json" 2> "$out/bench_c4.err"; echo "config 4 bench line done"
+  ;;
+D)
+  # the shifted-base-table path (msm_fold.h): kernel stats of tools/perf_fold.py (plain table and tables, alternating), 2^20 BLS12-381 G1
+  rocprofv3 --kernel-trace --stats -d "$out/stats_fold" -o t --output-format csv -- python3 tools/perf_fold.py BLS12-381 20 20 > "$out/perf_fold_under_rocprof.txt" 2> "$out/stats_fold.err"
+  echo "fold kernel stats done"
   ;;
 esac
 echo part-$1-done
