@@ -304,6 +304,8 @@ def main() -> None:
                 parts.append((g, plans[(slot, g)].finish()))
                 if record:
                     for kname, v in plans[(slot, g)].timings().items():
+                        if kname in ("window_c", "digits_per_scalar", "edwards", "tables"):
+                            continue  # (not times: the plan's geometry and path flags)
                         phase[(g, kname)] = phase.get((g, kname), 0.0) + v
             tx = time.perf_counter()
             totals = mdist.combine_many(CURVE, parts, dev)  # one all-gather (RCCL) + local EC adds; identity at N = 1
