@@ -209,10 +209,11 @@ MLHIP_API int mlhip_scalar_mul(int curve, int group, const void* points, size_t 
  * time per handle); handles are independent of each other. */
 typedef struct mlhip_bases mlhip_bases;
 /* window_c = 0 leaves the geometry to the library, and lets it keep SHIFTED-BASE TABLES for the handle (tables of at least
- * 2^17 bases that fit a quarter of the free device memory; MLHIP_BASES_TABLES=0 never, =1 always): besides P_i the device
- * holds 2^off(j) P_i for every digit position j (first bit off(j)) of a signed-digit scalar (13-14 rows a base, 2.9 GB for 2^20 BLS12-381
- * G1 bases, built once in ~60 ms), so that all digits of all scalars add into ONE set of 2^(c-1) buckets: a wider digit at the
- * same reduction cost (13-19 % fewer bucket additions) and a host tail of 15 doublings instead of 256.  Same result bytes.
+ * 2^10 bases that fit a quarter of the free device memory; MLHIP_BASES_TABLES=0 never, =1 always): besides P_i the device
+ * holds 2^off(j) P_i for every digit position j (first bit off(j)) of a signed-digit scalar (13 rows a base from 2^16 bases
+ * on -- 20-bit digits, 2.9 GB for 2^20 BLS12-381 G1 bases, built once in ~60 ms --, 16 to 20 rows below), so that all digits
+ * of all scalars add into ONE set of 2^(c-1) buckets: a wider digit at the same reduction cost (19 % fewer bucket additions)
+ * and a host tail of at most 19 doublings instead of 256.  Same result bytes.
  * An explicit window_c asks for that Pippenger geometry over the plain table (what BASELINE's "c = 16" names).  The
  * reference has no counterpart: its MultiScalarMul takes fresh slices (driver/gurvy/bls12381/bls12-381.go:766-783). */
 MLHIP_API int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** bases);
@@ -290,7 +291,7 @@ MLHIP_API int mlhip_fp_mul_device(int curve, const void* d_a, const void* d_b, s
  *     MLHIP_FIXED_BASE_MIN=n, MLHIP_FB_WINDOW=w, MLHIP_FB_CACHE=0   batched Mul of one base: table from n scalars on, width, no reuse
  *     MLHIP_EDWARDS=0                  BLS12-377 G1 over a checked SRS: keep the Weierstrass bucket sums
  *     MLHIP_BASES_TABLES=0|1           mlhip_bases_create: never / always keep shifted-base tables (default: see there)
- *     MLHIP_FOLD_WINDOW=c, MLHIP_FOLD_TILE_LOG2=t   ... their digit width (default 20) and tile (2^20 bases)
+ *     MLHIP_FOLD_WINDOW=c, MLHIP_FOLD_TILE_LOG2=t   ... their digit width (default 13 .. 20 by size) and tile (2^20 bases)
  *     MLHIP_PAIRING_QUAD=0|1           BLS12-381: never / always one pairing per quad of lanes (default: up to 2^14 elements)
  *   2nd impl (parity tests; DESIGN.md section 2 lists which test runs which)
  *     MLHIP_ACC32=1                    boundary-form (32-bit limb) bucket accumulation, G1 and G2

@@ -134,11 +134,16 @@ int ilog2(size_t v) {
 // from 8 to 16: 13-14 bits win from 2^11 to 2^15 points (2^14: 0.81 ms instead of 1.11), 16 from 2^16 on.  For large n on
 // the curves whose 254 / 255 scalar bits fit 15 windows of 17 bits (BLS12-377, BN254) one window less is one addition
 // per scalar less (BLS12-377 2^22: 12.5 ms instead of 13.5); BLS12-381's 256 bits need 16 windows either way.
+// Round 4 (profiles/r04_sweep_window.txt, the same sweep on this round's kernels): 10 bits from 2^10 to 2^11 points
+// (0.47 / 0.49 ms against 0.50 at c = 8 / 0.53 at c = 13), and for the group orders whose bits fit 17 windows of 15 (BN254,
+// BLS12-377) 15 bits from 2^16 to 2^17 points (BN254 0.505 / 0.587 ms against 0.554 / 0.617 at c = 16).
 int pick_window(size_t n, int fr_bits) {
   if (n <= 128) return 4;
-  if (n <= 1024) return 8;
-  if (n <= 4096) return 13;
+  if (n <= 512) return 8;
+  if (n <= 2048) return 10;
+  if (n <= 8192) return 13;
   if (n <= 32768) return 14;
+  if (n < ((size_t)1 << 18) && msm_num_windows(fr_bits, 15) == 17) return 15;
   if (n >= ((size_t)1 << 22) && msm_num_windows(fr_bits, 17) < msm_num_windows(fr_bits, 16)) return 17;
   return 16;
 }
@@ -1116,15 +1121,15 @@ static int tu_plan_fold_build(mlhip_msm_plan* p, const void* d_pts, size_t n, hi
 
 // Shifted-base tables for a table of n resident bases (msm_fold.h)?  They cost Wd rows per base (208 B a row for a 48-byte
 // field: 2.9 GB for 2^20 BLS12-381 G1 bases) and ~60 ms per 2^20 bases to build, and pay from the first few MSMs on.
-//   MLHIP_BASES_TABLES = 0: never; = 1: always (any size: what the tests use); unset: for tables of at least 2^17 bases
+//   MLHIP_BASES_TABLES = 0: never; = 1: always (any size: what the tests use); unset: for tables of at least 2^10 bases
 //   created with window_c = 0 (an explicit window width asks for that Pippenger geometry) that fit a quarter of the free memory.
-//   MLHIP_FOLD_WINDOW = c: the digit width (default 20, see below); MLHIP_FOLD_TILE_LOG2 = t: tiles of 2^t bases (20).
+//   MLHIP_FOLD_WINDOW = c: the digit width (default by size, see below); MLHIP_FOLD_TILE_LOG2 = t: tiles of 2^t bases (20).
 static bool bases_want_tables(int group, size_t n, int window_c, int fr_bits, size_t ptsz, int* c_out, size_t* tile_out) {
   const char* e = getenv("MLHIP_BASES_TABLES");
   const bool forced = e && e[0] == '1';
   if (e && e[0] == '0') return false;
-  (void)group;
-  if (!forced && (n < ((size_t)1 << 17) || window_c != 0)) return false;
+  // (G2 was measured from 2^20 bases down to 2^17 only: its small tables stay plain)
+  if (!forced && (n < ((size_t)1 << (group == MLHIP_GROUP_G1 ? 10 : 17)) || window_c != 0)) return false;
   int lg_tile = 20;
   if (const char* t = getenv("MLHIP_FOLD_TILE_LOG2")) {
     const int v = atoi(t);
@@ -1134,11 +1139,14 @@ static bool bases_want_tables(int group, size_t n, int window_c, int fr_bits, si
   if (n < tile) tile = n;
   int c = 0;
   if (const char* w = getenv("MLHIP_FOLD_WINDOW")) c = atoi(w);
-  // 20 bits (13 digits for a 253-255-bit group order) at every size from 2^17 on: narrower digits mean more of them and, in
+  // 20 bits (13 digits for a 253-255-bit group order) at every size from 2^16 on: narrower digits mean more of them and, in
   // the even digit layout, most of the 2^(c-1) buckets half-used -- same-box runs (profiles/r04_fold.txt), BLS12-381 G1,
   // resident scalars, c = 18 / 19 / 20 against the plain table: 2^17 1.11 / 0.83 / 0.80 (0.90) ms, 2^18 1.68 / 1.10 / 1.02
-  // (1.19), 2^19 - / 1.61 / 1.50 (1.75), 2^20 5.15 / 3.10 / 2.75 (3.16)
-  if (c < 5 || c > 20) c = 20;
+  // (1.19), 2^19 - / 1.61 / 1.50 (1.75), 2^20 5.15 / 3.10 / 2.75 (3.16).  Below 2^16 bases an MSM is latency, not work -- the
+  // reduction's dependent chains grow with the bucket count, the accumulation's with the entries per bucket -- and what the
+  // tables save is mostly the host tail's 256 doublings (0.14 ms): 13 / 14 / 16 bits from 2^10 / 2^12 / 2^13 bases:
+  // 2^10 0.35 (plain 0.49) ms, 2^11 0.39 (0.52), 2^12 0.46 (0.56), 2^14 0.57 (0.67), 2^15 0.70 (0.72), 2^16 at 20 bits 0.75 (0.81)
+  if (c < 5 || c > 20) c = n < ((size_t)1 << 12) ? 13 : n < ((size_t)1 << 13) ? 14 : n < ((size_t)1 << 16) ? 16 : 20;
   const size_t tiles = (n + tile - 1) / tile;
   const size_t rows = tiles * (size_t)msm_num_windows(fr_bits, c) * tile;
   if (!forced) {

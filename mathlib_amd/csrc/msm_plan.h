@@ -404,7 +404,7 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
               (const X28*)p->d_A, (const X28*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
         }
         if (p->fold_nsel2)  // folded plan: the groups' sums combined into one window's (both forms leave Weierstrass sums)
-          k_group_combine_q<C, 256><<<dim3((unsigned)p->fold_nsel2), dim3(256), 64 * sizeof(X), st>>>(
+          k_group_combine_q<C, 256><<<dim3((unsigned)p->fold_nsel2), dim3((unsigned)std::max(64, 8 * p->W)), 64 * sizeof(X), st>>>(
               (const X*)p->d_out, p->W, p->nsel, p->nb, (X*)p->d_out + (size_t)p->W * p->nsel);
       } else if constexpr (kBuildAlt) {  // boundary-form reductions: test build only
         if (p->reduce_one_lane) {  // MLHIP_REDUCE_ONE_LANE=1 when the plan was created

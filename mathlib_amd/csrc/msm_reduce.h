@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(BLOCK) k_group_combine_q(const XYZZ<FpField<C>
   quad_store<C>(sh, quad, acc);
   __syncthreads();
 #pragma unroll 1
-  for (uint32_t s = (uint32_t)BLOCK / 8; s > 0; s >>= 1) {
+  for (uint32_t s = NQ / 2; s > 0; s >>= 1) {  // (launched with 8 W threads: one quad per input slot)
     if (quad < s) {  // quad-uniform
       quad_load<C>(v, sh, quad + s);
       quad_xyzz_add<C, B>(acc, v);

@@ -105,7 +105,7 @@ static void runMultiScalarMul(const Curve& c, uint64_t& st) {
   {  // resident bases: same element as the host-slice call, for the whole table and a prefix
     Bases bases(c, ps);
     EXPECT(bases.CheckedSubgroup() == (c.id == MLHIP_CURVE_BLS12_377));  // the curve whose tables are checked (Edwards path)
-    EXPECT(!bases.ShiftedTables());                                    // four bases: the plain table (2^17 and more get shifted-base tables)
+    EXPECT(!bases.ShiftedTables());                                    // four bases: the plain table (2^10 and more get shifted-base tables)
     EXPECT(bases.MultiScalarMul(ss).Equals(fixed));
     std::vector<Zr> few(ss.begin(), ss.begin() + 3);
     std::vector<G1> fewp(ps.begin(), ps.begin() + 3);

@@ -14,6 +14,8 @@ from mathlib_amd import _lib  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "BLS12-381"
 group = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+step = int(sys.argv[3]) if len(sys.argv) > 3 else 2  # sizes 2^lg0, 2^(lg0 + step), ...
+lg0 = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
@@ -35,11 +37,11 @@ P = torch.empty(nmax * sz, dtype=torch.uint8, device=dev)
 _lib.check(lib.mlhip_scalar_mul_device(cid, group, base.data_ptr(), 0, rnd(nmax).data_ptr(), 0, nmax, P.data_ptr(), st))
 S = rnd(nmax)
 torch.cuda.synchronize()
-lg = 4
+lg = lg0
 while (1 << lg) <= nmax:
     n = 1 << lg
     res = {}
-    for c in range(4, 19):
+    for c in range(4, 21):
         if c > lg + 6:
             break
         try:
@@ -47,7 +49,7 @@ while (1 << lg) <= nmax:
         except Exception:
             continue
         best = 1e9
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
             plan.run(P.data_ptr(), S.data_ptr(), n, False, st)
             best = min(best, time.perf_counter() - t0)
@@ -55,4 +57,4 @@ while (1 << lg) <= nmax:
         res[c] = best * 1e3
     bc = min(res, key=res.get)
     print("%s G%d n=2^%d: best c=%d (%.3f ms)  " % (name, group, lg, bc, res[bc]) + " ".join("c%d=%.3f" % (c, t) for c, t in sorted(res.items()) if t < 1.5 * res[bc]), flush=True)
-    lg += 2
+    lg += step
