@@ -217,6 +217,9 @@ typedef struct mlhip_bases mlhip_bases;
  * An explicit window_c asks for that Pippenger geometry over the plain table (what BASELINE's "c = 16" names).  The
  * reference has no counterpart: its MultiScalarMul takes fresh slices (driver/gurvy/bls12381/bls12-381.go:766-783). */
 MLHIP_API int mlhip_bases_create(int curve, int group, const void* points, size_t n, int window_c, mlhip_bases** bases);
+/* the same handle from n affine points that are already in the current device's memory (a copy is taken; the caller's
+ * buffer may be reused at once): always one device, never spread */
+MLHIP_API int mlhip_bases_create_device(int curve, int group, const void* d_points, size_t n, int window_c, mlhip_bases** bases);
 /* the table cut into contiguous shards over an explicit device list (mlhip_bases_create does this by itself with the
  * process's list from MLHIP_MULTI_MIN bases on): every mlhip_bases_msm then moves each device's scalars over its own
  * PCIe link and adds the per-device partial sums on the host */

@@ -57,6 +57,7 @@ SYMBOLS = [
     "mlhip_scalar_mul",
     "mlhip_bases_create",
     "mlhip_bases_msm",
+    "mlhip_bases_create_device",
     "mlhip_bases_msm_device",
     "mlhip_bases_plan",
     "mlhip_bases_checked_subgroup",
@@ -191,6 +192,7 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.mlhip_scalar_mul.argtypes = [ci, ci, vp, sz, vp, ci, sz, vp]
     lib.mlhip_bases_create.argtypes = [ci, ci, vp, sz, ci, ctypes.POINTER(c_void_p)]
     lib.mlhip_bases_msm.argtypes = [vp, vp, ci, sz, vp]
+    lib.mlhip_bases_create_device.argtypes = [ci, ci, vp, sz, ci, ctypes.POINTER(c_void_p)]
     lib.mlhip_bases_msm_device.argtypes = [vp, vp, ci, sz, vp, vp]
     lib.mlhip_bases_plan.argtypes = [vp]
     lib.mlhip_bases_plan.restype = c_void_p

@@ -1160,7 +1160,7 @@ static bool bases_want_tables(int group, size_t n, int window_c, int fr_bits, si
 }
 
 static int bases_create_single(int curve, int group, const void* points, size_t n, int window_c, size_t ptsz,
-                               mlhip_bases** out) {
+                               mlhip_bases** out, bool points_on_device = false) {
   int rc = ensure_device();
   if (rc) return rc;
   mlhip_bases* b = new mlhip_bases();
@@ -1180,7 +1180,7 @@ static int bases_create_single(int curve, int group, const void* points, size_t 
   rc = b->plan ? 0 : mlhip_msm_plan_create(curve, group, n, window_c, &b->plan);
   if (!rc && (hipMalloc(&b->d_pts, n * b->ptsz) != hipSuccess || hipMalloc(&b->d_sc, n * 32) != hipSuccess))
     rc = mlhip_rt::fail(MLHIP_ENOMEM, "hipMalloc of the bases failed");
-  if (!rc && hipMemcpy(b->d_pts, points, n * b->ptsz, hipMemcpyHostToDevice) != hipSuccess)
+  if (!rc && hipMemcpy(b->d_pts, points, n * b->ptsz, points_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess)
     rc = mlhip_rt::fail(MLHIP_EHIP, "upload of the bases failed");
   if (!rc && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess)
     rc = mlhip_rt::fail(MLHIP_EHIP, "hipStreamCreate failed");
@@ -1266,6 +1266,16 @@ int mlhip_bases_create(int curve, int group, const void* points, size_t n, int w
   const std::vector<int> devs = spread_devices(n, false);
   if (!devs.empty()) return bases_create_on(devs, curve, group, points, n, window_c, ptsz, out);
   return bases_create_single(curve, group, points, n, window_c, ptsz, out);
+}
+
+int mlhip_bases_create_device(int curve, int group, const void* d_points, size_t n, int window_c, mlhip_bases** out) {
+  if (!out) return mlhip_rt::fail(MLHIP_EINVAL, "null output pointer");
+  *out = nullptr;
+  Sizes sz;
+  if (!curve_sizes(curve, sz)) return mlhip_rt::fail(MLHIP_EINVAL, "unknown curve id");
+  if (group != MLHIP_GROUP_G1 && group != MLHIP_GROUP_G2) return mlhip_rt::fail(MLHIP_EINVAL, "group must be 1 (G1) or 2 (G2)");
+  if (!d_points || n == 0) return mlhip_rt::fail(MLHIP_EINVAL, "bases need at least one point");
+  return bases_create_single(curve, group, d_points, n, window_c, group == MLHIP_GROUP_G1 ? sz.g1 : sz.g2, out, true);
 }
 
 int mlhip_bases_create_multi(int curve, int group, const int* devices, int n_devices, const void* points, size_t n,

@@ -643,4 +643,40 @@ __global__ void __launch_bounds__(BLOCK) k_masked_sums_lp28(const XYZZ28L<Fp28<C
   }
 }
 
+// ---- folded plans (msm_fold.h): the W bucket groups' sums combined into one window's, on lane pairs -----------------
+// k_group_combine_q (msm_reduce.h) for G2: one block per output of the combined window, one lane PAIR per input slot
+// (group g, half h; fold_combine_src), an LDS tree of lane-pair additions in the boundary form.  Launched with 4 W threads.
+// Host tail of a 2^20-point G2 MSM over shifted-base tables: 0.30 ms (2 W jobs on the host pool, 3 W additions) -> one
+// window's 19 doublings on the calling thread.
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_group_combine_lp(const XYZZ<Fp2Field<C>>* __restrict__ in, int W, int nsel, int nb,
+                                                            XYZZ<Fp2Field<C>>* __restrict__ out) {
+  typedef Fp2LField<C> FL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<Fp2Field<C>>* sh = reinterpret_cast<XYZZ<Fp2Field<C>>*>(smem);
+  const uint32_t pid = threadIdx.x >> 1;
+  const int hi = lane_is_hi() ? 1 : 0;
+  const int o = blockIdx.x;
+  const uint32_t NP = 2u * (uint32_t)W;
+  XYZZ<FL> acc, b;
+  xyzz_set_inf<FL>(acc);
+  if (pid < NP) {  // pair-uniform
+    const int g = (int)(pid >> 1);
+    const int src = fold_combine_src(o, g, (int)(pid & 1u), nb);
+    if (src >= 0) lp_load_xyzz<C>(acc, in, (size_t)g * nsel + src, hi);
+  }
+  lp_store_xyzz<C>(sh, pid, acc, hi);
+  __syncthreads();
+#pragma unroll 1
+  for (uint32_t s = NP / 2; s > 0; s >>= 1) {
+    if (pid < s) {  // pair-uniform
+      lp_load_xyzz<C>(b, sh, pid + s, hi);
+      xyzz_add_lp_ool<C>(acc, b);
+      lp_store_xyzz<C>(sh, pid, acc, hi);
+    }
+    __syncthreads();
+  }
+  if (pid == 0) lp_store_xyzz<C>(out, (size_t)o, acc, hi);
+}
+
 }  // namespace mlhip

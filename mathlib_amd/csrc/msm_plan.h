@@ -151,7 +151,7 @@ int plan_alloc(mlhip_msm_plan* p) {
     HIPCHK(hipMalloc(&p->d_A, (size_t)p->W * p->T * chunk_size));
     HIPCHK(hipMalloc(&p->d_W0, (size_t)p->W * p->T * chunk_size));
   }
-  if (p->fold && p->W > 1 && p->W <= 32 && p->reduce28 && std::is_same<F, FpField<typename F::Curve>>::value) {
+  if (p->fold && p->W > 1 && p->W <= 32 && p->reduce28) {  // (G1: k_group_combine_q on quads; G2: k_group_combine_lp on lane pairs)
     int lgW = 0;
     while ((1 << lgW) < p->W) lgW++;
     p->fold_nsel2 = 4 + p->nb + lgW;
@@ -369,6 +369,9 @@ int launch_reduce(mlhip_msm_plan* p, hipStream_t st) {
           constexpr int RB = 512;  // 256 lane pairs, 128 slots x 448 B = 56 KB of LDS per block
           k_masked_sums_lp28<C, RB><<<dim3((unsigned)(p->W * p->nsel)), dim3(RB), (RB / 4) * 2 * sizeof(X28), st>>>(
               (const X28*)p->d_A, (const X28*)p->d_W0, p->T, p->nsel, (X*)p->d_out);
+          if (p->fold_nsel2)  // folded plan: the groups' sums combined into one window's
+            k_group_combine_lp<C, 128><<<dim3((unsigned)p->fold_nsel2), dim3((unsigned)(4 * p->W)), 2 * p->W * sizeof(X), st>>>(
+                (const X*)p->d_out, p->W, p->nsel, p->nb, (X*)p->d_out + (size_t)p->W * p->nsel);
           done28 = true;
         }
       }

@@ -1219,6 +1219,15 @@ def test_bases_shifted_tables(lib, mlhip, curve, group, monkeypatch):
         assert out.raw == want[n], (curve, c, tile_lg, "device scalars")
         mlhip.check(lib.mlhip_bases_msm(h, same.tobytes(), 0, n, out))
         assert out.raw == want_same, (curve, c, tile_lg, "equal scalars")
+        if c == 17:  # the same handle made from points that are already on the device
+            d_pts = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
+            h2 = ctypes.c_void_p()
+            mlhip.check(lib.mlhip_bases_create_device(cid, group, d_pts.data_ptr(), n, 0, ctypes.byref(h2)))
+            d_pts.zero_()  # (the handle holds its own copy)
+            torch.cuda.synchronize()
+            mlhip.check(lib.mlhip_bases_msm(h2, sc.tobytes(), 0, n, out))
+            assert out.raw == want[n], (curve, c, "device points")
+            mlhip.check(lib.mlhip_bases_destroy(h2))
         for seg in ("5", "2"):  # streamed scalars, equal segments: cut again at the tile boundaries
             monkeypatch.setenv("MLHIP_STREAM_SEGMENTS", seg)
             mlhip.check(lib.mlhip_bases_msm(h, sc.tobytes(), 0, n, out))
