@@ -211,7 +211,7 @@ typedef struct mlhip_bases mlhip_bases;
 /* window_c = 0 leaves the geometry to the library, and lets it keep SHIFTED-BASE TABLES for the handle (tables of at least
  * 2^10 bases that fit a quarter of the free device memory; MLHIP_BASES_TABLES=0 never, =1 always): besides P_i the device
  * holds 2^off(j) P_i for every digit position j (first bit off(j)) of a signed-digit scalar (13 rows a base from 2^16 bases
- * on -- 20-bit digits, 2.9 GB for 2^20 BLS12-381 G1 bases, built once in ~60 ms --, 16 to 20 rows below), so that all digits
+ * on -- 20-bit digits, 1.5 GB for 2^20 BLS12-381 G1 bases, built once in ~60 ms --, 16 to 20 rows below), so that all digits
  * of all scalars add into ONE set of 2^(c-1) buckets: a wider digit at the same reduction cost (19 % fewer bucket additions)
  * and a host tail of at most 19 doublings instead of 256.  Same result bytes.
  * An explicit window_c asks for that Pippenger geometry over the plain table (what BASELINE's "c = 16" names).  The

@@ -862,8 +862,7 @@ int mlhip_msm_plan_destroy(mlhip_msm_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->device);
   void* ptrs[] = {p->d_digits, p->d_sorted, p->d_zero, p->d_offsets, p->d_biglist, p->d_buckets, p->d_A, p->d_W0, p->d_out,
-                  p->d_order, p->d_hist, p->d_tilesums, p->d_coarse_off, p->d_points28, p->d_blockhist, p->d_state28, p->d_bigprefix, p->d_bigpart, p->d_binprefix,
-                  p->d_fold_pts};
+                  p->d_order, p->d_hist, p->d_tilesums, p->d_coarse_off, p->d_points28, p->d_blockhist, p->d_state28, p->d_bigprefix, p->d_bigpart, p->d_binprefix};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (p->h_out) (void)hipHostFree(p->h_out);
@@ -1119,8 +1118,8 @@ static int tu_plan_fold_build(mlhip_msm_plan* p, const void* d_pts, size_t n, hi
   }
 }
 
-// Shifted-base tables for a table of n resident bases (msm_fold.h)?  They cost Wd rows per base (208 B a row for a 48-byte
-// field: 2.9 GB for 2^20 BLS12-381 G1 bases) and ~60 ms per 2^20 bases to build, and pay from the first few MSMs on.
+// Shifted-base tables for a table of n resident bases (msm_fold.h)?  They cost Wd rows per base (112 B a row for a 48-byte
+// field: 1.5 GB for 2^20 BLS12-381 G1 bases) and ~60 ms per 2^20 bases to build, and pay from the first few MSMs on.
 //   MLHIP_BASES_TABLES = 0: never; = 1: always (any size: what the tests use); unset: for tables of at least 2^10 bases
 //   created with window_c = 0 (an explicit window width asks for that Pippenger geometry) that fit a quarter of the free memory.
 //   MLHIP_FOLD_WINDOW = c: the digit width (default by size, see below); MLHIP_FOLD_TILE_LOG2 = t: tiles of 2^t bases (20).
@@ -1152,7 +1151,8 @@ static bool bases_want_tables(int group, size_t n, int window_c, int fr_bits, si
   if (!forced) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
-    if (rows * (ptsz + ptsz + ptsz / 6 + 56) > free_b / 4) return false;  // boundary-form rows + carry-free rows (or Niels triples)
+    // carry-free rows (or Niels triples: 7/4 of a G1 point) + one tile of boundary-form rows while the table is built
+    if (rows * (ptsz + ptsz * 3 / 4) + (size_t)msm_num_windows(fr_bits, c) * tile * ptsz > free_b / 4) return false;
   }
   *c_out = c;
   *tile_out = tile;

@@ -57,8 +57,7 @@ struct mlhip_msm_plan {
   // never crosses a tile.
   int Wd = 0, fold = 0;
   size_t fold_tile = 0, fold_n = 0;  // rows per digit block; bases tabulated
-  size_t fold_rows = 0;              // rows allocated in d_points28 / d_fold_pts (tiles x Wd x fold_tile)
-  void* d_fold_pts = nullptr;        // the rows in the boundary form (Affine<F>): what the sliced sums of long buckets read
+  size_t fold_rows = 0;              // rows allocated in d_points28 (tiles x Wd x fold_tile): carry-free rows or Niels triples
   // the W groups' sums are combined on the device into the sums of one window of W T chunks (k_group_combine_q / _lp);
   // d_out / h_out then hold fold_nsel2 = 4 + nb + lg W more entries behind the W x nsel ones, and the host tail reads those
   int fold_nsel2 = 0;

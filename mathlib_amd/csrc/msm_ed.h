@@ -123,4 +123,69 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate_big_seg_ed(const uint32_t*
   }
 }
 
+// ---- the slice sums of long buckets from the CARRY-FREE rows (round 4: a shifted-base table keeps no boundary-form rows) --
+// k_big_slices (msm_accumulate.h) with the per-thread loop of the accumulation kernels: Weierstrass rows (Affine28, xyzz28_madd)
+// or, ED, Niels triples (ed28_madd); the thread's sum is converted to the boundary form for the LDS tree, so the partial sums
+// have the format the combine kernels (k_accumulate_big_seg, k_accumulate_big_seg_ed) already read.
+template <class C, int BLOCK, bool ED>
+__global__ void __launch_bounds__(BLOCK) k_big_slices28(const void* __restrict__ rows, const uint32_t* __restrict__ sorted,
+                                                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                        const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
+                                                        const uint32_t* __restrict__ prefix,
+                                                        XYZZ<FpField<C>>* __restrict__ partials) {
+  typedef FpField<C> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+  __shared__ uint32_t s_bi;
+  const uint32_t nbig = *big_count;
+  if (nbig == 0) return;
+  const uint32_t total = prefix[nbig];
+  for (uint32_t sid = blockIdx.x; sid < total; sid += gridDim.x) {
+    if (threadIdx.x == 0) {  // the bucket this slice belongs to: last entry with prefix <= sid
+      uint32_t lo = 0, hi = nbig - 1;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (prefix[mid] <= sid)
+          lo = mid;
+        else
+          hi = mid - 1;
+      }
+      s_bi = lo;
+    }
+    __syncthreads();
+    const uint32_t bi = s_bi;
+    const uint32_t g = big_list[bi];
+    const size_t first = offsets[g], last = first + counts[g];
+    const size_t begin = first + (size_t)(sid - prefix[bi]) * BIG_SLICE;
+    const size_t end = begin + BIG_SLICE < last ? begin + BIG_SLICE : last;
+    XYZZ28<C> w;
+    bool inf = true;
+    if constexpr (ED) {
+      if constexpr (C::HAS_EDWARDS) {
+        const EdNiels28<C>* pts = static_cast<const EdNiels28<C>*>(rows);
+        EdExt28<C> acc;
+        ed28_set_identity<C>(acc);
+        for (size_t k = begin + threadIdx.x; k < end; k += BLOCK) {
+          const uint32_t e = sorted[k];
+          const EdNiels28<C> q = pts[e & 0x7fffffffu];
+          ed28_madd<C>(acc, q, (e >> 31) != 0);
+        }
+        ed28_to_xyzz28<C>(w, inf, acc);
+      }
+    } else {
+      const Affine28<C>* pts = static_cast<const Affine28<C>*>(rows);
+      for (size_t k = begin + threadIdx.x; k < end; k += BLOCK) {
+        const uint32_t e = sorted[k];
+        const Affine28<C> q = pts[e & 0x7fffffffu];
+        xyzz28_madd<C>(w, inf, q, (e >> 31) != 0);
+      }
+    }
+    XYZZ<F> acc;
+    xyzz28_to<C>(acc, w, inf);
+    block_tree_sum_auto<F, BLOCK>(sh, acc);
+    if (threadIdx.x == 0) partials[sid] = sh[0];
+    __syncthreads();
+  }
+}
+
 }  // namespace mlhip

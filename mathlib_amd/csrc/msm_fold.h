@@ -29,9 +29,10 @@ static inline size_t fold_row(const mlhip_msm_plan* p, size_t off) {
   return (off / p->fold_tile) * (size_t)p->Wd * p->fold_tile + off % p->fold_tile;
 }
 
-// Build the table of a folded plan from n affine bases in device memory: the boundary-form rows (d_fold_pts: what the sliced
-// sums of long buckets gather from) and their carry-free copy (d_points28: what the accumulation kernels gather from).
-// Runs on `st`; the plan is ready for launches on any stream once `st` has drained (the caller synchronizes).
+// Build the table of a folded plan from n affine bases in device memory: tile by tile, the boundary-form rows of a tile in a
+// temporary buffer (Wd fold_tile rows: 1.3 GB for 2^20 G1 bases), then their carry-free copy -- Weierstrass rows or, for a
+// subgroup-checked table on a curve with the model, Niels triples -- into d_points28, the only form the plan keeps (every
+// kernel of a folded plan, the slices of long buckets included, gathers from it).  Runs on `st` and returns when it is done.
 template <class C, class F>
 int plan_fold_build(mlhip_msm_plan* p, const void* d_points, size_t n, hipStream_t st) {
   typedef Affine<F> A;
@@ -40,7 +41,8 @@ int plan_fold_build(mlhip_msm_plan* p, const void* d_points, size_t n, hipStream
   if (n == 0 || n > p->max_n) return mlhip_rt::fail(MLHIP_EINVAL, "plan_fold_build: n out of range");
   const size_t TL = p->fold_tile;
   const size_t tiles = (n + TL - 1) / TL;
-  const size_t rows = tiles * (size_t)p->Wd * TL;
+  const size_t tile_rows = (size_t)p->Wd * TL;
+  const size_t rows = tiles * tile_rows;
   const bool use_ed = [&] {
     if constexpr (C::HAS_EDWARDS && !kG2) {
       const char* e = getenv("MLHIP_EDWARDS");
@@ -52,43 +54,45 @@ int plan_fold_build(mlhip_msm_plan* p, const void* d_points, size_t n, hipStream
   if constexpr (C::HAS_EDWARDS && !kG2) {
     if (use_ed) elem = sizeof(EdNiels28<C>);
   }
-  if (p->d_fold_pts && p->fold_rows < rows) {
-    (void)hipFree(p->d_fold_pts);
-    p->d_fold_pts = nullptr;
-  }
   if (p->d_points28 && (p->fold_rows < rows || p->points28_elem < elem)) {
     (void)hipFree(p->d_points28);
     p->d_points28 = nullptr;
   }
-  if (!p->d_fold_pts) HIPCHK(hipMalloc(&p->d_fold_pts, rows * sizeof(A)));
   if (!p->d_points28) {
     HIPCHK(hipMalloc(&p->d_points28, rows * elem));
     p->points28_elem = elem;
   }
   p->fold_rows = rows;
-  HIPCHK(hipMemsetAsync(p->d_fold_pts, 0, rows * sizeof(A), st));  // rows past the last base of a partial tile: infinity
-  for (size_t k = 0; k < tiles; k++) {
+  void* tmp = nullptr;
+  HIPCHK(hipMalloc(&tmp, tile_rows * sizeof(A)));
+  int rc = 0;
+  for (size_t k = 0; k < tiles && !rc; k++) {
     const size_t lo = k * TL, len = std::min(TL, n - lo);
-    k_fold_rows<C, F><<<dim3((unsigned)((len + 63) / 64)), dim3(64), 0, st>>>((const A*)d_points + lo, len, p->c, TL,
-                                                                            (A*)p->d_fold_pts + k * (size_t)p->Wd * TL);
-  }
-  if constexpr (kG2) {
-    k_points_to28_g2<C><<<dim3((unsigned)((4 * rows + 255) / 256)), dim3(256), 0, st>>>((const A*)p->d_fold_pts, rows,
-                                                                                         (AffineG2_28<C>*)p->d_points28);
-  } else {
-    bool converted = false;
-    if constexpr (C::HAS_EDWARDS) {
-      if (use_ed) {
-        k_points_to_ed28<C><<<dim3((unsigned)(((rows + 3) / 4 + 255) / 256)), dim3(256), 0, st>>>((const A*)p->d_fold_pts, rows,
-                                                                                                (EdNiels28<C>*)p->d_points28);
-        converted = true;
+    char* dst = (char*)p->d_points28 + k * tile_rows * elem;
+    // rows past the last base of a partial tile: the point at infinity
+    if (hipMemsetAsync(tmp, 0, tile_rows * sizeof(A), st) != hipSuccess) rc = MLHIP_EHIP;
+    k_fold_rows<C, F><<<dim3((unsigned)((len + 63) / 64)), dim3(64), 0, st>>>((const A*)d_points + lo, len, p->c, TL, (A*)tmp);
+    if constexpr (kG2) {
+      k_points_to28_g2<C><<<dim3((unsigned)((4 * tile_rows + 255) / 256)), dim3(256), 0, st>>>((const A*)tmp, tile_rows,
+                                                                                                (AffineG2_28<C>*)dst);
+    } else {
+      bool converted = false;
+      if constexpr (C::HAS_EDWARDS) {
+        if (use_ed) {
+          k_points_to_ed28<C><<<dim3((unsigned)(((tile_rows + 3) / 4 + 255) / 256)), dim3(256), 0, st>>>((const A*)tmp, tile_rows,
+                                                                                                       (EdNiels28<C>*)dst);
+          converted = true;
+        }
       }
+      if (!converted)
+        k_points_to28<C><<<dim3((unsigned)((tile_rows + 255) / 256)), dim3(256), 0, st>>>((const A*)tmp, tile_rows,
+                                                                                          (Affine28<C>*)dst);
     }
-    if (!converted)
-      k_points_to28<C><<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st>>>((const A*)p->d_fold_pts, rows,
-                                                                                   (Affine28<C>*)p->d_points28);
   }
-  HIPCHK(hipGetLastError());
+  if (!rc && hipGetLastError() != hipSuccess) rc = MLHIP_EHIP;
+  if (hipStreamSynchronize(st) != hipSuccess) rc = MLHIP_EHIP;
+  (void)hipFree(tmp);
+  if (rc) return mlhip_rt::fail(rc, "building the shifted-base table failed");
   p->fold_n = n;
   p->points_static = true;
   p->conv_src = d_points;

@@ -679,4 +679,83 @@ __global__ void __launch_bounds__(BLOCK) k_group_combine_lp(const XYZZ<Fp2Field<
   if (pid == 0) lp_store_xyzz<C>(out, (size_t)o, acc, hi);
 }
 
+// k_big_slices_lp from the carry-free rows of a shifted-base table (AffineG2_28; see k_big_slices28, msm_ed.h): the pair's
+// sum is accumulated with the lane-pair carry-free mixed addition and converted to the boundary form for the LDS tree.
+template <class C, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_big_slices_lp28(const AffineG2_28<C>* __restrict__ points,
+                                                           const uint32_t* __restrict__ sorted,
+                                                           const uint32_t* __restrict__ offsets,
+                                                           const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ big_list,
+                                                           const uint32_t* __restrict__ big_count,
+                                                           const uint32_t* __restrict__ prefix,
+                                                           XYZZ<Fp2Field<C>>* __restrict__ partials) {
+  typedef Fp2LField<C> FL;
+  typedef PairDevice<C> B;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XYZZ<Fp2Field<C>>* sh = reinterpret_cast<XYZZ<Fp2Field<C>>*>(smem);
+  __shared__ uint32_t s_bi;
+  constexpr uint32_t PAIRS = BLOCK / 2;
+  const uint32_t pid = threadIdx.x >> 1;
+  const int hi = lane_is_hi() ? 1 : 0;
+  const uint32_t nbig = *big_count;
+  if (nbig == 0) return;
+  const uint32_t total = prefix[nbig];
+  for (uint32_t sid = blockIdx.x; sid < total; sid += gridDim.x) {
+    if (threadIdx.x == 0) {
+      uint32_t lo = 0, up = nbig - 1;
+      while (lo < up) {
+        const uint32_t mid = (lo + up + 1) >> 1;
+        if (prefix[mid] <= sid)
+          lo = mid;
+        else
+          up = mid - 1;
+      }
+      s_bi = lo;
+    }
+    __syncthreads();
+    const uint32_t bi = s_bi;
+    const uint32_t g = big_list[bi];
+    const size_t first = offsets[g], last = first + counts[g];
+    const size_t begin = first + (size_t)(sid - prefix[bi]) * BIG_SLICE;
+    const size_t end = begin + BIG_SLICE < last ? begin + BIG_SLICE : last;
+    XYZZ28L<Fp28<C>> a28;
+    bool inf = true;
+    for (size_t k = begin + pid; k < end; k += PAIRS) {  // pair-uniform bounds
+      const uint32_t e = sorted[k];
+      Affine28L<Fp28<C>> q;
+      q.x = points[e & 0x7fffffffu].c[hi];
+      q.y = points[e & 0x7fffffffu].c[2 + hi];
+      xyzz28_lp_madd<C, B>(a28, inf, q, (e >> 31) != 0);
+    }
+    XYZZ<FL> acc, b;
+    if (inf) {
+      xyzz_set_inf<FL>(acc);
+    } else {
+      fp28_to_fp<C>(acc.x.v, a28.x);
+      fp28_to_fp<C>(acc.y.v, a28.y);
+      fp28_to_fp<C>(acc.zz.v, a28.zz);
+      fp28_to_fp<C>(acc.zzz.v, a28.zzz);
+    }
+    lp_store_xyzz<C>(sh, pid, acc, hi);
+    __syncthreads();
+    for (uint32_t s2 = PAIRS / 2; s2 > 0; s2 >>= 1) {
+      if (pid < s2) {  // pair-uniform
+        XYZZ<FL> a;
+        lp_load_xyzz<C>(a, sh, pid, hi);
+        lp_load_xyzz<C>(b, sh, pid + s2, hi);
+        xyzz_add_lp_ool<C>(a, b);
+        lp_store_xyzz<C>(sh, pid, a, hi);
+      }
+      __syncthreads();
+    }
+    if (pid == 0) {
+      XYZZ<FL> a;
+      lp_load_xyzz<C>(a, sh, 0, hi);
+      lp_store_xyzz<C>(partials, sid, a, hi);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace mlhip

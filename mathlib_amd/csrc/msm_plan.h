@@ -249,11 +249,35 @@ void host_tail(const mlhip_msm_plan* p, XYZZ<F>& total) {
 
 // slice sums of the long buckets listed by the accumulation kernel (nothing to do, two near-empty launches, when
 // there are none)
+// (`row0`: a folded plan keeps carry-free rows only -- the slices gather from d_points28 + row0, in the form the table holds)
 template <class F, int BB>
-void launch_big_slices(mlhip_msm_plan* p, const Affine<F>* d_points, hipStream_t st, const mlhip_msm_plan* sv = nullptr) {
+void launch_big_slices(mlhip_msm_plan* p, const Affine<F>* d_points, hipStream_t st, const mlhip_msm_plan* sv = nullptr,
+                       size_t row0 = 0) {
   typedef typename F::Curve C;
   if (!sv) sv = p;  // the plan whose entry lists (sorted / offsets / counts) describe this tile
   k_big_prefix<<<dim3(1), dim3(1024), 0, st>>>(sv->d_counts, p->d_biglist, p->d_bigcount, p->d_bigprefix);
+  if (p->fold) {
+    if constexpr (std::is_same<F, Fp2Field<C>>::value) {
+      k_big_slices_lp28<C, 256><<<dim3(1024), dim3(256), 128 * sizeof(XYZZ<F>), st>>>(
+          (const AffineG2_28<C>*)p->d_points28 + row0, sv->d_sorted, sv->d_offsets, sv->d_counts, p->d_biglist, p->d_bigcount,
+          p->d_bigprefix, (XYZZ<F>*)p->d_bigpart);
+    } else {
+      bool done_ed = false;
+      if constexpr (C::HAS_EDWARDS) {
+        if (p->conv_ed) {
+          k_big_slices28<C, BB, true><<<dim3(1024), dim3(BB), BB * sizeof(XYZZ<F>), st>>>(
+              (const EdNiels28<C>*)p->d_points28 + row0, sv->d_sorted, sv->d_offsets, sv->d_counts, p->d_biglist, p->d_bigcount,
+              p->d_bigprefix, (XYZZ<F>*)p->d_bigpart);
+          done_ed = true;
+        }
+      }
+      if (!done_ed)
+        k_big_slices28<C, BB, false><<<dim3(1024), dim3(BB), BB * sizeof(XYZZ<F>), st>>>(
+            (const Affine28<C>*)p->d_points28 + row0, sv->d_sorted, sv->d_offsets, sv->d_counts, p->d_biglist, p->d_bigcount,
+            p->d_bigprefix, (XYZZ<F>*)p->d_bigpart);
+    }
+    return;
+  }
   if constexpr (std::is_same<F, Fp2Field<C>>::value) {
     // G2: 128 lane pairs per slice (48 KB of LDS)
     k_big_slices_lp<C, 256><<<dim3(1024), dim3(256), 128 * sizeof(XYZZ<F>), st>>>(d_points, sv->d_sorted, sv->d_offsets,
@@ -472,9 +496,9 @@ int plan_launch(mlhip_msm_plan* p, const void* d_points, const void* d_scalars, 
   typedef XYZZ<F> X;
   if (p->fold) {
     // the points are the plan's own table (plan_fold_build): the caller's point argument only names the bases it was built from
-    if (n > p->fold_n || !p->d_points28 || !p->d_fold_pts || p->upload_src)
+    if (n > p->fold_n || !p->d_points28 || p->upload_src)
       return mlhip_rt::fail(MLHIP_EINVAL, "folded plan: more scalars than tabulated bases, or no table");
-    d_points = p->d_fold_pts;
+    d_points = p->d_points28;  // (never read as Affine<F>: every kernel of a folded plan gathers from the carry-free rows)
   }
   if (n != 0 && !p->upload_src) {
     const int K = resident_tiles<C, F>(p, n);
@@ -704,10 +728,10 @@ int stream_begin(mlhip_msm_plan* p, StreamCtx& cx, hipStream_t st, int min_K) {
   p->last_ed = cx.ed;
   cx.conv_cached = cx.resident && p->points_static && p->conv_src == cx.d_points && cx.n <= p->conv_n && p->conv_ed == cx.ed;
   if (p->fold) {
-    if (!cx.resident || cx.n > p->fold_n || !p->d_fold_pts)
+    if (!cx.resident || cx.n > p->fold_n || !p->d_points28)
       return mlhip_rt::fail(MLHIP_EINVAL, "folded plan: the points are the plan's table; more scalars than tabulated bases");
     cx.conv_cached = true;
-    cx.d_points = p->d_fold_pts;
+    cx.d_points = p->d_points28;  // (a token: never read as Affine<F>)
   }
   cx.prof = p->profiling && cx.h_scalars == nullptr;  // tiles of device-resident inputs: per-tile phase events
   if (cx.prof)
@@ -778,7 +802,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
   char* dsc = (char*)cx.d_scalars + off * 32;
   // where this segment's points start: plain arrays at `off`; a folded plan's table at the tile block that holds base `off`
   const size_t row0 = p->fold ? fold_row(p, off) : off;
-  A* dpt = (A*)cx.d_points + row0;
+  A* dpt = p->fold ? nullptr : (A*)cx.d_points + row0;  // (folded: the slices of long buckets gather from d_points28 + row0)
   const bool prof = cx.prof;
   if (hs) HIPCHK(hipMemcpyAsync(dsc, hs + off * 32, len * 32, hipMemcpyHostToDevice, p->aux));
   // points and scalars both travel: the sort starts when the segment's scalars are there, under the upload of its points
@@ -834,7 +858,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
           (const AffineG2_28<C>*)p->d_points28 + row0, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
           big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28L<Fp28<C>>*)p->d_state28, flags, (X*)p->d_buckets);
     constexpr int BB = 128;
-    launch_big_slices<F, BB>(p, dpt, st, sv);
+    launch_big_slices<F, BB>(p, dpt, st, sv, row0);
     k_accumulate_big_seg_g2<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
         p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28L<Fp28<C>>*)p->d_state28, flags,
         (X*)p->d_buckets);
@@ -846,7 +870,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
         k_accumulate_ed28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
             (const EdNiels28<C>*)p->d_points28 + row0, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
             big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags);
-        launch_big_slices<F, BB>(p, dpt, st, sv);
+        launch_big_slices<F, BB>(p, dpt, st, sv, row0);
         k_accumulate_big_seg_ed<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
             p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28, flags);
         done_ed = true;
@@ -856,7 +880,7 @@ int stream_tile(mlhip_msm_plan* p, const StreamCtx& cx, int s, hipStream_t st, c
       k_accumulate28_seg<C><<<dim3((unsigned)((nbuckets + p->acc_block - 1) / p->acc_block)), dim3(p->acc_block), 0, st>>>(
           (const Affine28<C>*)p->d_points28 + row0, sv->d_sorted, sv->d_offsets, sv->d_counts, nbuckets, sv->d_order,
           big_threshold, p->d_biglist, p->d_bigcount, (XYZZ28<C>*)p->d_state28, flags, (X*)p->d_buckets);
-      launch_big_slices<F, BB>(p, dpt, st, sv);
+      launch_big_slices<F, BB>(p, dpt, st, sv, row0);
       k_accumulate_big_seg<C, BB><<<dim3(256), dim3(BB), BB * sizeof(X), st>>>(
           p->d_biglist, p->d_bigcount, p->d_bigprefix, (const X*)p->d_bigpart, (XYZZ28<C>*)p->d_state28, flags,
           (X*)p->d_buckets);
