@@ -562,6 +562,32 @@ def main() -> None:
                     "group": "G1", "pairs": n, "calls_timed": ntimed, "calls_untimed_first": nwarm,
                     "match_resident_result": bool(same_b and same_c),
                 }
+                if G2 in groups:
+                    # config 4's G2 half over a handle made from the points already on the device (mlhip_bases_create_device),
+                    # scalars resident: with the G1 figure above, what the step costs over shifted-base tables (two handles, two
+                    # sorts -- the shared-scalar sort of `value` is not available to them)
+                    t1 = time.perf_counter()
+                    _lib.check(lib.mlhip_bases_create_device(CURVE, G2, points[G2].data_ptr(), n, 0, ctypes.byref(handle)))
+                    create2_ms = (time.perf_counter() - t1) * 1e3
+                    g2plan = lib.mlhip_bases_plan(handle)
+                    _lib.check(lib.mlhip_msm_plan_set_profiling(g2plan, 1))
+                    out_g2 = ctypes.create_string_buffer(g2b)
+                    tg2 = []
+                    for i in range(2 + 3):
+                        t1 = time.perf_counter()
+                        _lib.check(lib.mlhip_bases_msm_device(handle, scalars.data_ptr(), 0, n, stream, out_g2))
+                        if i >= 2:
+                            tg2.append((time.perf_counter() - t1) * 1e3)
+                    g2ph = _lib.plan_timings(lib, g2plan)
+                    _lib.check(lib.mlhip_bases_destroy(handle))
+                    g1t = extra["resident_bases_library_geometry"]["scalars_resident_ms"]["median"]
+                    extra["resident_bases_library_geometry"]["g2"] = {
+                        "shifted_base_tables": g2ph.get("tables", 0.0) == 1.0, "digits_per_scalar": g2ph.get("digits_per_scalar"), "create_ms": create2_ms,
+                        "scalars_resident_ms": {"median": statistics.median(tg2), "min": min(tg2), "max": max(tg2)},
+                        "phase_ms": {k: g2ph[k] for k in ("digits", "sort", "accumulate", "reduce", "device_total", "host_tail") if k in g2ph},
+                        "match_resident_result": bool(world > 1 or out_g2.raw == res[G2]),
+                        "g1_plus_g2_ms": g1t + statistics.median(tg2), "pairs_per_s": n / ((g1t + statistics.median(tg2)) * 1e-3),
+                    }
                 extra["headline_protocol_b"] = extra["pcie_inclusive"]["protocol_b_scalar_muls_per_s"]
                 extra["headline_protocol_b_library_geometry"] = extra["resident_bases_library_geometry"]["protocol_b_scalar_muls_per_s"]
                 del hp, hs

@@ -1151,8 +1151,10 @@ static bool bases_want_tables(int group, size_t n, int window_c, int fr_bits, si
   if (!forced) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
-    // carry-free rows (or Niels triples: 7/4 of a G1 point) + one tile of boundary-form rows while the table is built
-    if (rows * (ptsz + ptsz * 3 / 4) + (size_t)msm_num_windows(fr_bits, c) * tile * ptsz > free_b / 4) return false;
+    // carry-free rows: at most 5/4 of the boundary form's bytes a coordinate (10 x 4 B for a 32-byte field, 14 x 4 B for a 48-byte
+    // one); a G1 row may be a Niels triple (three coordinates instead of two); + one tile of boundary-form rows during the build
+    const size_t row_bytes = group == MLHIP_GROUP_G1 ? ptsz / 2 * 3 * 5 / 4 : ptsz * 5 / 4;
+    if (rows * row_bytes + (size_t)msm_num_windows(fr_bits, c) * tile * ptsz > free_b / 4) return false;
   }
   *c_out = c;
   *tile_out = tile;
