@@ -344,3 +344,70 @@ def test_config4_whole_n1(mlhip):
         mlhip.check((lib.mlhip_g1_sum if group == 1 else lib.mlhip_g2_sum)(cid, parts, shards, out))
         assert out.raw == whole[group], group
         assert whole[group] == want[group], group
+
+
+@pytest.mark.parametrize("shape", ["uniform", "below_2_32_dups", "two_values"])
+def test_msm_2_20_over_shifted_base_tables_vs_oracle(mlhip, shape):
+    """BASELINE configs[1]'s size over a resident-bases handle with the library's geometry (window_c = 0: shifted-base tables,
+    13 digits of 20 bits into one bucket set; msm_fold.h): the C oracle on the whole input, for uniform scalars, for the
+    skewed distribution (all below 2^32, 1 % duplicated pairs: every high digit is zero and the low ones collide) and for
+    two scalar values only (13 x 2 buckets hold everything: the sliced long-bucket sums from the carry-free rows); scalars
+    from the host (streamed in two segments) and already on the device; the handle made from device points."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from oracle import cref
+
+    n = 1 << 20
+    lib, cid, pts, s, k, st = _setup(mlhip, n, seed=9)
+    sc = s.clone().view(torch.int64).reshape(n, 4)
+    if shape == "below_2_32_dups":
+        sc[:, 1:] = 0
+        sc[:, 0] &= 0xFFFFFFFF
+        p2 = pts.clone().reshape(n, 96)
+        p2[::100] = p2[0]
+        sc[::100] = sc[0]
+        pts = p2.reshape(-1).contiguous()
+    elif shape == "two_values":
+        sc[::2] = sc[0]
+        sc[1::2] = sc[1]
+    sc8 = sc.view(torch.uint8).reshape(n, 32).contiguous()
+    hp = pts.cpu().numpy()
+    hs = sc8.cpu().numpy().view(np.uint64).reshape(n, 4)
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    exp = cref.msm(cid, 1, hp, hs, n, False, 16, threads)
+    h = ctypes.c_void_p()
+    mlhip.check(lib.mlhip_bases_create_device(cid, 1, pts.data_ptr(), n, 0, ctypes.byref(h)))
+    t = mlhip.plan_timings(lib, lib.mlhip_bases_plan(h))
+    assert t["tables"] == 1.0 and t["window_c"] == 20 and t["digits_per_scalar"] == 13, t
+    out = ctypes.create_string_buffer(96)
+    mlhip.check(lib.mlhip_bases_msm_device(h, sc8.data_ptr(), 0, n, st, out))
+    assert out.raw == exp, shape
+    mlhip.check(lib.mlhip_bases_msm(h, hs.tobytes(), 0, n, out))
+    assert out.raw == exp, shape
+    half = n // 2 + 777
+    mlhip.check(lib.mlhip_bases_msm(h, hs.tobytes(), 0, half, out))
+    assert out.raw == cref.msm(cid, 1, hp, hs, half, False, 16, threads), shape
+    mlhip.check(lib.mlhip_bases_destroy(h))
+
+
+def test_msm_2_21_over_shifted_base_tables_two_tiles(mlhip):
+    """2^21 + 5 bases: three tiles of the table (2^20, 2^20, 5), the bucket state carried from tile to tile; the halves add up
+    and the whole equals the plain plan's result on the same device inputs (itself checked against the oracle at this size
+    by the tests above)."""
+    n = (1 << 21) + 5
+    lib, cid, pts, s, k, st = _setup(mlhip, n, seed=10)
+    plan = mlhip.MsmPlan(cid, 1, n, 16)
+    want = plan.run(pts.data_ptr(), s.data_ptr(), n, False, st)
+    plan.close()
+    h = ctypes.c_void_p()
+    mlhip.check(lib.mlhip_bases_create_device(cid, 1, pts.data_ptr(), n, 0, ctypes.byref(h)))
+    assert mlhip.plan_timings(lib, lib.mlhip_bases_plan(h))["tables"] == 1.0
+    out = ctypes.create_string_buffer(96)
+    mlhip.check(lib.mlhip_bases_msm_device(h, s.data_ptr(), 0, n, st, out))
+    assert out.raw == want
+    mlhip.check(lib.mlhip_bases_msm(h, s.cpu().numpy().tobytes(), 0, n, out))
+    assert out.raw == want
+    mlhip.check(lib.mlhip_bases_destroy(h))
