@@ -135,15 +135,16 @@ int ilog2(size_t v) {
 // the curves whose 254 / 255 scalar bits fit 15 windows of 17 bits (BLS12-377, BN254) one window less is one addition
 // per scalar less (BLS12-377 2^22: 12.5 ms instead of 13.5); BLS12-381's 256 bits need 16 windows either way.
 // Round 4 (profiles/r04_sweep_window.txt, the same sweep on this round's kernels): 10 bits from 2^10 to 2^11 points
-// (0.47 / 0.49 ms against 0.50 at c = 8 / 0.53 at c = 13), and for the group orders whose bits fit 17 windows of 15 (BN254,
-// BLS12-377) 15 bits from 2^16 to 2^17 points (BN254 0.505 / 0.587 ms against 0.554 / 0.617 at c = 16).
+// (0.47 / 0.49 ms against 0.50 at c = 8 / 0.53 at c = 13), and for BN254 (254-bit order, 10-limb field: its reduction weighs
+// more against its additions) 15 bits from 2^16 to 2^17 points (0.505 / 0.587 ms against 0.554 / 0.617 at c = 16) -- not for
+// BLS12-377, whose 253 bits also fit 17 windows of 15: 0.93 / 1.14 ms against 0.88 / 1.00 at c = 16.
 int pick_window(size_t n, int fr_bits) {
   if (n <= 128) return 4;
   if (n <= 512) return 8;
   if (n <= 2048) return 10;
   if (n <= 8192) return 13;
   if (n <= 32768) return 14;
-  if (n < ((size_t)1 << 18) && msm_num_windows(fr_bits, 15) == 17) return 15;
+  if (n < ((size_t)1 << 18) && fr_bits == 254) return 15;
   if (n >= ((size_t)1 << 22) && msm_num_windows(fr_bits, 17) < msm_num_windows(fr_bits, 16)) return 17;
   return 16;
 }
